@@ -1,0 +1,246 @@
+"""ctypes binding of the C ABI (include/cuba_hip.h -> csrc/libcuba_hip.so).
+
+This is plumbing for tests and bench.py: every call goes straight through the C ABI to the HIP
+kernels.  There is no CPU fallback -- if the shared library is missing or no GPU is visible the
+constructor raises.  The method names mirror CudaBlockSolver's stage methods
+(/root/reference/src/cuda_bundle_adjustment.cpp:115-562).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libcuba_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "cuba_hip.h")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+ARRAY_IDS = dict(bp=0, bsc=1, xp=2, xl=3, lm_sys=4, hsc=5)
+PROFILE_KEYS = (  # same strings as CudaBlockSolver::getTimeProfile (src/cuda_bundle_adjustment.cpp:545-562)
+    "0: Initialize Optimizer", "1: Build Structure", "2: Compute Error", "3: Build System",
+    "4: Schur Complement", "5: Symbolic Decomposition", "6: Numerical Decomposition", "7: Update Solution")
+
+
+class CubaHipError(RuntimeError):
+    pass
+
+
+def build_library(force=False):
+    """Compile csrc/*.hip for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + [HEADER]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "libcuba_hip.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CubaHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    sig = {
+        "cuba_hip_create": [C.c_int, C.POINTER(H)],
+        "cuba_hip_destroy": [H],
+        "cuba_hip_set_stream": [H, C.c_void_p],
+        "cuba_hip_set_option": [H, C.c_char_p, C.c_double],
+        "cuba_hip_set_graph": [H, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _ip, _u8p, _dp, _dp],
+        "cuba_hip_set_robust_kernel": [H, C.c_int, C.c_int, C.c_double],
+        "cuba_hip_build_structure": [H],
+        "cuba_hip_compute_errors": [H, _dp],
+        "cuba_hip_build_system": [H],
+        "cuba_hip_max_diagonal": [H, _dp],
+        "cuba_hip_set_lambda": [H, C.c_double],
+        "cuba_hip_restore_diagonal": [H],
+        "cuba_hip_schur": [H],
+        "cuba_hip_solve_reduced": [H, C.POINTER(C.c_int)],
+        "cuba_hip_back_substitute": [H],
+        "cuba_hip_solve": [H, C.POINTER(C.c_int)],
+        "cuba_hip_update": [H],
+        "cuba_hip_compute_scale": [H, C.c_double, _dp],
+        "cuba_hip_push": [H],
+        "cuba_hip_pop": [H],
+        "cuba_hip_optimize": [H, C.c_int, _dp, C.POINTER(C.c_int)],
+        "cuba_hip_get_solution": [H, _dp, _dp, _dp],
+        "cuba_hip_set_solution": [H, _dp, _dp, _dp],
+        "cuba_hip_chi_squares": [H, _dp],
+        "cuba_hip_get_profile": [H, _dp],
+        "cuba_hip_get_counters": [H, C.POINTER(C.c_int64)],
+        "cuba_hip_get_hsc_structure": [H, _ip, _ip, C.POINTER(C.c_int)],
+        "cuba_hip_get_array": [H, C.c_int, _dp, C.POINTER(C.c_size_t)],
+        "cuba_hip_reduction_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.cuba_hip_last_error.argtypes = [H]
+    lib.cuba_hip_last_error.restype = C.c_char_p
+    lib.cuba_hip_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class HipSolver:
+    """One bundle-adjustment problem on one GPU, driven through the C ABI."""
+
+    def __init__(self, fp=None, robust=((0, 0.0), (0, 0.0)), device=0, stream=None, **options):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.cuba_hip_create(int(device), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise CubaHipError(f"cuba_hip_create failed with status {rc} (4 = no HIP device visible)")
+        if stream is not None:
+            self._ck(self.lib.cuba_hip_set_stream(self.h, C.c_void_p(int(stream))))
+        for k, v in options.items():
+            self.set_option(k, v)
+        self.fp = None
+        for et, (kind, delta) in enumerate(robust):
+            self.set_robust_kernel(et, kind, delta)
+        if fp is not None:
+            self.set_graph(fp)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cuba_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CubaHipError(f"status {rc}: {self.lib.cuba_hip_last_error(self.h).decode()}")
+
+    def set_option(self, key, value):
+        self._ck(self.lib.cuba_hip_set_option(self.h, key.encode(), float(value)))
+
+    def set_robust_kernel(self, edge_type, kind, delta):
+        self._ck(self.lib.cuba_hip_set_robust_kernel(self.h, int(edge_type), int(kind), float(delta)))
+
+    def set_graph(self, fp):
+        self.fp = fp
+        q, t, cam, Xw = (np.ascontiguousarray(a, dtype=np.float64) for a in (fp.q, fp.t, fp.cam, fp.Xw))
+        eP = np.ascontiguousarray(fp.eP, dtype=np.int32)
+        eL = np.ascontiguousarray(fp.eL, dtype=np.int32)
+        eD = np.ascontiguousarray(fp.eDim, dtype=np.uint8)
+        meas = np.ascontiguousarray(fp.meas, dtype=np.float64)
+        om = np.ascontiguousarray(fp.omega, dtype=np.float64)
+        self._ck(self.lib.cuba_hip_set_graph(self.h, fp.Pt, fp.Pf, fp.Lt, fp.Lf, _d(q), _d(t), _d(cam), _d(Xw), len(eP),
+                                             eP.ctypes.data_as(_ip), eL.ctypes.data_as(_ip), eD.ctypes.data_as(_u8p),
+                                             _d(meas), _d(om)))
+
+    # ---- stages --------------------------------------------------------------------------------
+    def build_structure(self): self._ck(self.lib.cuba_hip_build_structure(self.h))
+
+    def compute_errors(self):
+        v = C.c_double()
+        self._ck(self.lib.cuba_hip_compute_errors(self.h, C.byref(v)))
+        return v.value
+
+    def build_system(self): self._ck(self.lib.cuba_hip_build_system(self.h))
+
+    def max_diagonal(self):
+        v = C.c_double()
+        self._ck(self.lib.cuba_hip_max_diagonal(self.h, C.byref(v)))
+        return v.value
+
+    def set_lambda(self, lam): self._ck(self.lib.cuba_hip_set_lambda(self.h, float(lam)))
+    def restore_diagonal(self): self._ck(self.lib.cuba_hip_restore_diagonal(self.h))
+    def schur(self): self._ck(self.lib.cuba_hip_schur(self.h))
+
+    def solve_reduced(self):
+        ok = C.c_int()
+        self._ck(self.lib.cuba_hip_solve_reduced(self.h, C.byref(ok)))
+        return bool(ok.value)
+
+    def back_substitute(self): self._ck(self.lib.cuba_hip_back_substitute(self.h))
+
+    def solve(self):
+        ok = C.c_int()
+        self._ck(self.lib.cuba_hip_solve(self.h, C.byref(ok)))
+        return bool(ok.value)
+
+    def update(self): self._ck(self.lib.cuba_hip_update(self.h))
+
+    def compute_scale(self, lam):
+        v = C.c_double()
+        self._ck(self.lib.cuba_hip_compute_scale(self.h, float(lam), C.byref(v)))
+        return v.value
+
+    def push(self): self._ck(self.lib.cuba_hip_push(self.h))
+    def pop(self): self._ck(self.lib.cuba_hip_pop(self.h))
+
+    def optimize(self, niter):
+        chi2 = np.zeros(max(niter, 1))
+        n = C.c_int()
+        self._ck(self.lib.cuba_hip_optimize(self.h, int(niter), _d(chi2), C.byref(n)))
+        return dict(chi2=chi2[:n.value])
+
+    # ---- results -------------------------------------------------------------------------------
+    def state(self):
+        q, t, X = np.zeros((self.fp.Pt, 4)), np.zeros((self.fp.Pt, 3)), np.zeros((self.fp.Lt, 3))
+        self._ck(self.lib.cuba_hip_get_solution(self.h, _d(q), _d(t), _d(X)))
+        return q, t, X
+
+    def set_state(self, q, t, X):
+        q, t, X = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, t, X))
+        self._ck(self.lib.cuba_hip_set_solution(self.h, _d(q), _d(t), _d(X)))
+
+    def chi_squares(self):
+        out = np.zeros(self.fp.E)
+        self._ck(self.lib.cuba_hip_chi_squares(self.h, _d(out)))
+        return out
+
+    def profile(self):
+        out = np.zeros(8)
+        self._ck(self.lib.cuba_hip_get_profile(self.h, _d(out)))
+        return dict(zip(PROFILE_KEYS, out.tolist()))
+
+    def counters(self):
+        c = (C.c_int64 * 4)()
+        self._ck(self.lib.cuba_hip_get_counters(self.h, c))
+        return dict(pcg_iterations=int(c[0]), lm_trials=int(c[1]), hsc_blocks=int(c[2]), schur_products=int(c[3]))
+
+    def array(self, name):
+        n = C.c_size_t()
+        self._ck(self.lib.cuba_hip_get_array(self.h, ARRAY_IDS[name], None, C.byref(n)))
+        out = np.zeros(n.value)
+        if n.value:
+            self._ck(self.lib.cuba_hip_get_array(self.h, ARRAY_IDS[name], _d(out), C.byref(n)))
+        return out
+
+    def hsc_structure(self):
+        nb = C.c_int()
+        self._ck(self.lib.cuba_hip_get_hsc_structure(self.h, None, None, C.byref(nb)))
+        rp, ci = np.zeros(self.fp.Pf + 1, dtype=np.int32), np.zeros(nb.value, dtype=np.int32)
+        self._ck(self.lib.cuba_hip_get_hsc_structure(self.h, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), C.byref(nb)))
+        return rp, ci
+
+    def hsc(self):
+        """(rowptr, colind, values[nblk,6,6] indexed [blk][row][col]) of the upper-triangular BSR."""
+        rp, ci = self.hsc_structure()
+        v = self.array("hsc").reshape(len(ci), 6, 6).transpose(0, 2, 1).copy()
+        return rp, ci, v
+
+    def reduction_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.cuba_hip_reduction_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value

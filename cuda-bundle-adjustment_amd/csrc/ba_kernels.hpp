@@ -1,0 +1,97 @@
+// ba_kernels.hpp -- launch interface of the gfx950 kernels (implemented in ba_kernels.hip).
+//
+// Device data model (all SoA, fp64 + int32):
+//   poses      q[4*Pt] t[3*Pt] cam[5*Pt]          free poses [0,Pf) first, fixed after
+//   landmarks  Xw[3*Lt]                           free [0,Lf) first
+//   edges      sorted by (landmark, pose): e_pose (bit 31 = stereo), e_lm, e_mu/e_mv/e_mr, e_w
+//              lm_ptr[Lt+1] = edge range of each landmark
+//   wave list  wave_lm[2*nWaves]: each 64-lane wavefront owns whole landmarks with <= 64 edges in total,
+//              one lane per edge -> Hll/bl are reduced inside the wave, no atomics on the landmark side
+//   Hsc        upper-triangular BSR (row_ptr/col_ind, 6x6 col-major blocks, diagonal block first in
+//              each row), pair_blk = destination block of every Schur product, adj_* = full symmetric
+//              adjacency over the same storage for the PCG SpMV
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "ba_math.hpp"
+
+namespace cubahip
+{
+
+constexpr int NSLOT = 16;            // partial-sum slots for global reductions (spreads same-address atomics)
+constexpr int WAVE = 64;
+constexpr int LIN_BLOCK = 256;       // 4 wavefronts per workgroup in the landmark-major kernels
+constexpr int STEREO_BIT = 0x40000000;
+
+struct DeviceGraph
+{
+	int Pt = 0, Pf = 0, Lt = 0, Lf = 0, E = 0;
+	Scalar *q = nullptr, *t = nullptr, *cam = nullptr, *Xw = nullptr;
+	int *e_pose = nullptr, *e_lm = nullptr;
+	Scalar *e_mu = nullptr, *e_mv = nullptr, *e_mr = nullptr, *e_w = nullptr;
+	int* lm_ptr = nullptr;
+	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
+};
+
+struct DeviceStructure
+{
+	int nWaves = 0;
+	int* wave_lm = nullptr;            // [2*nWaves] first / one-past-last landmark of each wave
+	int nBig = 0;
+	int* big_lm = nullptr;             // landmarks with more than 64 edges (own workgroup each)
+	long long* big_scratch_ofs = nullptr;  // [nBig] offset (in edges) into big_hpl
+	Scalar* big_hpl = nullptr;         // 18 doubles per edge of a big landmark
+	int nblk = 0;
+	int *hsc_rowptr = nullptr, *hsc_colind = nullptr;
+	int* pair_blk = nullptr;           // destination block of each (i<j) product, landmark-major
+	long long* lm_pair_base = nullptr; // [Lf] offset of a landmark's pairs in pair_blk
+	int* lm_nfree = nullptr;           // [Lf] number of edges of the landmark whose pose is free
+	int *adj_ptr = nullptr, *adj_blk = nullptr, *adj_col = nullptr;  // adj_blk bit 31 = use transposed
+};
+
+struct DeviceSystem
+{
+	Scalar* hsc = nullptr;     // [36*nblk]  } one contiguous allocation (multi-GPU reduction buffer)
+	Scalar* bsc = nullptr;     // [6*Pf]     }
+	Scalar* bp = nullptr;      // [6*Pf]     }
+	Scalar* lm_sys = nullptr;  // [9*Lf]  6 unique of Hll or inv(Hll+lambda I), then bl
+	Scalar* xp = nullptr;      // [6*Pf]
+	Scalar* xl = nullptr;      // [3*Lf]
+	Scalar* slots = nullptr;   // [4*NSLOT] chi2 | landmark scale (back_substitute) | per-edge chi2 scratch | stage scale
+	unsigned long long* maxdiag = nullptr;  // bit pattern of a non-negative double
+	int* fail = nullptr;       // numeric failure flag
+	// PCG work
+	Scalar *minv = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *ap = nullptr;
+	Scalar *rz = nullptr, *pq = nullptr;   // [(maxIter+2)*NSLOT] each
+	int* iters = nullptr;      // device iteration counter
+};
+
+// residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
+// per_edge (optional, sorted edge order): non-robust omega*|r|^2.
+void launch_residual_chi2(const DeviceGraph& g, Scalar* slots, Scalar* per_edge, hipStream_t st);
+
+// mode 0: assemble only (Hpp -> diagonal blocks of hsc, bp, Hll/bl -> lm_sys, max diagonal of Hll)
+// mode 1: full linearise + Schur reduction with damping lambda (hsc, bsc, bp, inv(Hll+lambda)/bl -> lm_sys)
+void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s);
+
+// max over the diagonal of the diagonal blocks of hsc (Hpp after an assemble pass) folded into sys.maxdiag
+void launch_pose_maxdiag(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
+
+// xl = inv(Hll+lambda)(bl - Hpl^T xp); accumulates sum xl (lambda xl + bl) into slots[NSLOT..2*NSLOT)
+void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);
+
+// pose-side part of the gain-ratio denominator: sum xp (lambda xp + bp) -> slots[0..NSLOT)
+void launch_pose_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
+// landmark-side part recomputed from xl and the stored bl (stage API; the fused path gets it from back_substitute)
+void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
+
+void launch_update_poses(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
+void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
+
+// block-Jacobi PCG on the upper-BSR reduced system
+void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);
+void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
+
+}  // namespace cubahip

@@ -1,0 +1,783 @@
+// ba_solver.hip -- host orchestration of one bundle-adjustment problem on one MI355X + the C ABI
+// (include/cuba_hip.h).  Behavioural counterpart of class CudaBlockSolver and of the LM loop in
+// CudaBundleAdjustmentImpl::optimize (/root/reference/src/cuda_bundle_adjustment.cpp:73-673, 793-857),
+// re-organised around landmark-sorted edges and fused kernels (see ba_kernels.hip).
+//
+// There is deliberately no CPU fallback: every entry point fails with CUBA_HIP_ERR_NO_DEVICE /
+// CUBA_HIP_ERR_RUNTIME when no gfx950 device is usable.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/cuba_hip.h"
+#include "ba_kernels.hpp"
+
+using namespace cubahip;
+
+namespace
+{
+
+struct HipError { hipError_t code; const char* what; const char* file; int line; };
+
+#define HIP_TRY(expr)                                                    \
+	do {                                                                 \
+		hipError_t err__ = (expr);                                       \
+		if (err__ != hipSuccess) throw HipError{ err__, #expr, __FILE__, __LINE__ }; \
+	} while (0)
+
+struct StateError { std::string msg; };
+struct ArgError { std::string msg; };
+
+template <typename T>
+class DevBuf
+{
+public:
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	~DevBuf() { release(); }
+	void release()
+	{
+		if (ptr_) (void)hipFree(ptr_);
+		ptr_ = nullptr; size_ = cap_ = 0;
+	}
+	void resize(size_t n)
+	{
+		if (n > cap_)
+		{
+			release();
+			if (n) HIP_TRY(hipMalloc((void**)&ptr_, n * sizeof(T)));
+			cap_ = n;
+		}
+		size_ = n;
+	}
+	void upload(const std::vector<T>& h, hipStream_t s)
+	{
+		resize(h.size());
+		if (!h.empty()) HIP_TRY(hipMemcpyAsync(ptr_, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+	}
+	void zero(hipStream_t s) { if (size_) HIP_TRY(hipMemsetAsync(ptr_, 0, size_ * sizeof(T), s)); }
+	T* data() const { return ptr_; }
+	size_t size() const { return size_; }
+private:
+	T* ptr_ = nullptr;
+	size_t size_ = 0, cap_ = 0;
+};
+
+using Clock = std::chrono::steady_clock;
+
+}  // namespace
+
+struct cuba_hip_solver
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	std::string lastError;
+
+	// options
+	double pcgTol = 1e-10;
+	int pcgMaxIter = 0;          // 0 = automatic
+	int pcgCheckEvery = 32;
+	bool profile = false;
+
+	// host copy of the problem (solver order) and of the sort permutation
+	int Pt = 0, Pf = 0, Lt = 0, Lf = 0, E = 0;
+	bool haveGraph = false, haveStructure = false;
+	std::vector<int> perm;       // sorted position -> caller edge index
+	std::vector<int> h_lmptr, h_epose;   // sorted, e_pose without the stereo bit
+	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
+
+	// device: state [q | t | Xw] contiguous (push/pop = one copy), edges, structure, system
+	DevBuf<Scalar> d_state, d_backup, d_cam;
+	DevBuf<int> d_epose, d_elm, d_lmptr;
+	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
+	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_pairBlk, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
+	DevBuf<long long> d_bigOfs, d_lmPairBase;
+	DevBuf<Scalar> d_bigHpl;
+	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
+	DevBuf<Scalar> d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
+	DevBuf<unsigned long long> d_maxdiag;
+	DevBuf<int> d_fail, d_iters;
+	std::vector<int> h_rowptr, h_colind;
+	Scalar* h_pinned = nullptr;   // 4*NSLOT doubles + small ints
+
+	DeviceGraph g;
+	DeviceStructure st;
+	DeviceSystem sys;
+
+	double lambda = 0;
+	int maxIterAlloc = 0;
+	long long nmul = 0;
+	int64_t cntPcgIters = 0, cntTrials = 0;
+	double prof[CUBA_HIP_PROFILE_ITEMS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+
+	~cuba_hip_solver()
+	{
+		if (h_pinned) (void)hipHostFree(h_pinned);
+		if (ownStream && stream) (void)hipStreamDestroy(stream);
+	}
+
+	void sync() { HIP_TRY(hipStreamSynchronize(stream)); }
+
+	struct StageTimer
+	{
+		cuba_hip_solver* s; int item; Clock::time_point t0;
+		StageTimer(cuba_hip_solver* s_, int item_) : s(s_), item(item_)
+		{
+			if (s->profile) { s->sync(); t0 = Clock::now(); }
+		}
+		~StageTimer()
+		{
+			if (s->profile)
+			{
+				(void)hipStreamSynchronize(s->stream);
+				s->prof[item] += std::chrono::duration<double>(Clock::now() - t0).count();
+			}
+		}
+	};
+
+	// ---------------------------------------------------------------------------------------------
+	void setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,
+		int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega)
+	{
+		if (Pt_ < 0 || Lt_ < 0 || E_ < 0 || Pf_ < 0 || Pf_ > Pt_ || Lf_ < 0 || Lf_ > Lt_) throw ArgError{ "bad vertex counts" };
+		if (Pt_ >= STEREO_BIT) throw ArgError{ "too many poses" };
+		if ((Pt_ && (!q || !t || !cam)) || (Lt_ && !Xw) || (E_ && (!ep || !el || !edim || !meas || !omega))) throw ArgError{ "null array" };
+		const auto t0 = Clock::now();
+		Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
+		haveStructure = false;
+		for (int e = 0; e < E; e++)
+		{
+			if (ep[e] < 0 || ep[e] >= Pt || el[e] < 0 || el[e] >= Lt) throw ArgError{ "edge index out of range" };
+			if (edim[e] != 2 && edim[e] != 3) throw ArgError{ "edge_dim must be 2 or 3" };
+			if (ep[e] >= Pf && el[e] >= Lf) throw ArgError{ "edge with both ends fixed (must be dropped by the caller)" };
+		}
+		// sort edges by (landmark, pose, original index): counting sort on the landmark, small sorts inside
+		h_lmptr.assign(Lt + 1, 0);
+		for (int e = 0; e < E; e++) h_lmptr[el[e] + 1]++;
+		for (int l = 0; l < Lt; l++) h_lmptr[l + 1] += h_lmptr[l];
+		perm.assign(E, 0);
+		{
+			std::vector<int> cursor(h_lmptr.begin(), h_lmptr.end() - 1);
+			for (int e = 0; e < E; e++) perm[cursor[el[e]]++] = e;
+			for (int l = 0; l < Lt; l++)
+				std::sort(perm.begin() + h_lmptr[l], perm.begin() + h_lmptr[l + 1],
+					[&](int a, int b) { return ep[a] != ep[b] ? ep[a] < ep[b] : a < b; });
+		}
+		std::vector<int> sPose(E), sLm(E);
+		std::vector<Scalar> mu(E), mv(E), mr(E), w(E);
+		h_epose.assign(E, 0);
+		for (int i = 0; i < E; i++)
+		{
+			const int e = perm[i];
+			h_epose[i] = ep[e];
+			sPose[i] = ep[e] | (edim[e] == 3 ? STEREO_BIT : 0);
+			sLm[i] = el[e];
+			mu[i] = meas[3 * (size_t)e]; mv[i] = meas[3 * (size_t)e + 1];
+			mr[i] = edim[e] == 3 ? meas[3 * (size_t)e + 2] : 0.0;
+			w[i] = omega[e];
+		}
+		std::vector<Scalar> state((size_t)7 * Pt + (size_t)3 * Lt);
+		if (Pt) { std::memcpy(state.data(), q, sizeof(double) * 4 * Pt); std::memcpy(state.data() + 4 * (size_t)Pt, t, sizeof(double) * 3 * Pt); }
+		if (Lt) std::memcpy(state.data() + 7 * (size_t)Pt, Xw, sizeof(double) * 3 * Lt);
+		std::vector<Scalar> camv(cam, cam + 5 * (size_t)Pt);
+
+		d_state.upload(state, stream);
+		d_backup.resize(state.size());
+		d_cam.upload(camv, stream);
+		d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream);
+		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
+		d_perEdge.resize(E);
+		d_slots.resize(4 * NSLOT); d_maxdiag.resize(1); d_fail.resize(1); d_iters.resize(1);
+		d_fail.zero(stream); d_iters.zero(stream);
+		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
+		sync();   // host staging vectors go out of scope
+
+		g = DeviceGraph();
+		g.Pt = Pt; g.Pf = Pf; g.Lt = Lt; g.Lf = Lf; g.E = E;
+		g.q = d_state.data(); g.t = d_state.data() + 4 * (size_t)Pt; g.Xw = d_state.data() + 7 * (size_t)Pt;
+		g.cam = d_cam.data();
+		g.e_pose = d_epose.data(); g.e_lm = d_elm.data(); g.lm_ptr = d_lmptr.data();
+		g.e_mu = d_mu.data(); g.e_mv = d_mv.data(); g.e_mr = d_mr.data(); g.e_w = d_w.data();
+		g.rk[0] = rk[0]; g.rk[1] = rk[1];
+		haveGraph = true;
+		lambda = 0;
+		for (double& v : prof) v = 0;
+		cntPcgIters = cntTrials = 0;
+		prof[0] += std::chrono::duration<double>(Clock::now() - t0).count();
+	}
+
+	// ---------------------------------------------------------------------------------------------
+	// Symbolic structure: Hsc pattern from landmark co-visibility (ref: HschurSparseBlockMatrix::
+	// constructFromVertices, src/sparse_block_matrix.cpp:55-133 -- here sort/unique instead of a dense
+	// P x P map, and every free pose always owns its diagonal block), destination block of every Schur
+	// product (ref: findHschureMulBlockIndicesKernel, cuda_block_solver.cu:979-1000), symmetric adjacency
+	// for the PCG, wave work list.
+	// ---------------------------------------------------------------------------------------------
+	void buildStructure()
+	{
+		if (!haveGraph) throw StateError{ "set_graph must be called first" };
+		if (haveStructure) return;
+		const auto t0 = Clock::now();
+		std::vector<int> nfree(Lf, 0);
+		std::vector<long long> pairBase(Lf, 0);
+		nmul = 0;
+		long long npairs = 0;
+		for (int l = 0; l < Lf; l++)
+		{
+			int n = 0;
+			for (int i = h_lmptr[l]; i < h_lmptr[l + 1]; i++) n += h_epose[i] < Pf;
+			nfree[l] = n;
+			pairBase[l] = npairs;
+			npairs += (long long)n * (n - 1) / 2;
+			nmul += (long long)n * (n + 1) / 2;
+		}
+		if (npairs >= (1LL << 31)) throw ArgError{ "graph too dense: more than 2^31 Schur block products" };
+		// unique (row, col) keys of the upper triangle
+		std::vector<uint64_t> keys;
+		keys.reserve((size_t)npairs + Pf);
+		for (int i = 0; i < Pf; i++) keys.push_back(((uint64_t)i << 32) | (uint32_t)i);
+		for (int l = 0; l < Lf; l++)
+		{
+			const int b = h_lmptr[l], n = nfree[l];
+			for (int a = 0; a < n; a++)
+				for (int c = a + 1; c < n; c++)
+					keys.push_back(((uint64_t)h_epose[b + a] << 32) | (uint32_t)h_epose[b + c]);
+		}
+		std::sort(keys.begin(), keys.end());
+		keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+		const int nblk = (int)keys.size();
+		h_rowptr.assign(Pf + 1, 0);
+		h_colind.assign(nblk, 0);
+		for (int k = 0; k < nblk; k++)
+		{
+			h_rowptr[(keys[k] >> 32) + 1]++;
+			h_colind[k] = (int)(keys[k] & 0xffffffffu);
+		}
+		for (int i = 0; i < Pf; i++) h_rowptr[i + 1] += h_rowptr[i];
+		// destination block of every product
+		std::vector<int> pairBlk((size_t)npairs);
+		for (int l = 0; l < Lf; l++)
+		{
+			const int b = h_lmptr[l], n = nfree[l];
+			long long idx = pairBase[l];
+			for (int a = 0; a < n; a++)
+			{
+				const int pa = h_epose[b + a];
+				const int* rb = h_colind.data() + h_rowptr[pa];
+				const int* re = h_colind.data() + h_rowptr[pa + 1];
+				const int* cur = rb;
+				for (int c = a + 1; c < n; c++, idx++)
+				{
+					const int pc = h_epose[b + c];
+					cur = std::lower_bound(cur, re, pc);
+					pairBlk[idx] = (int)(cur - h_colind.data()) | (pc == pa ? 0x40000000 : 0);
+				}
+			}
+		}
+		// symmetric adjacency over the upper storage
+		std::vector<int> adjPtr(Pf + 1, 0);
+		for (int i = 0; i < Pf; i++)
+			for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++)
+			{
+				adjPtr[i + 1]++;
+				if (h_colind[k] != i) adjPtr[h_colind[k] + 1]++;
+			}
+		for (int i = 0; i < Pf; i++) adjPtr[i + 1] += adjPtr[i];
+		std::vector<int> adjBlk(adjPtr[Pf]), adjCol(adjPtr[Pf]);
+		{
+			std::vector<int> cur(adjPtr.begin(), adjPtr.end() - 1);
+			// lower part first (neighbours j < i arrive in increasing j), then the row's own upper part
+			for (int i = 0; i < Pf; i++)
+				for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++)
+				{
+					const int j = h_colind[k];
+					if (j != i) { adjBlk[cur[j]] = k | (int)0x80000000; adjCol[cur[j]] = i; cur[j]++; }
+				}
+			for (int i = 0; i < Pf; i++)
+				for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) { adjBlk[cur[i]] = k; adjCol[cur[i]] = h_colind[k]; cur[i]++; }
+		}
+		// wave work list: whole landmarks, at most 64 edges per wave; larger landmarks get a workgroup each
+		std::vector<int> waveLm, bigLm;
+		std::vector<long long> bigOfs;
+		long long bigEdges = 0;
+		{
+			int start = -1, cnt = 0;
+			auto flush = [&](int end) { if (start >= 0 && cnt > 0) { waveLm.push_back(start); waveLm.push_back(end); } start = -1; cnt = 0; };
+			for (int l = 0; l < Lt; l++)
+			{
+				const int n = h_lmptr[l + 1] - h_lmptr[l];
+				if (n > WAVE)
+				{
+					flush(l);
+					bigLm.push_back(l); bigOfs.push_back(bigEdges); bigEdges += n;
+					continue;
+				}
+				if (n == 0) continue;   // empty landmarks inside a run are harmless (no lanes)
+				if (start >= 0 && cnt + n > WAVE) flush(l);
+				if (start < 0) start = l;
+				cnt += n;
+			}
+			flush(Lt);
+		}
+
+		d_waveLm.upload(waveLm, stream); d_bigLm.upload(bigLm, stream); d_bigOfs.upload(bigOfs, stream);
+		d_bigHpl.resize((size_t)bigEdges * 18);
+		d_rowptr.upload(h_rowptr, stream); d_colind.upload(h_colind, stream);
+		d_pairBlk.upload(pairBlk, stream); d_lmPairBase.upload(pairBase, stream); d_lmNfree.upload(nfree, stream);
+		d_adjPtr.upload(adjPtr, stream); d_adjBlk.upload(adjBlk, stream); d_adjCol.upload(adjCol, stream);
+
+		d_red.resize((size_t)36 * nblk + (size_t)12 * Pf);
+		d_lmSys.resize((size_t)9 * Lf); d_xp.resize((size_t)6 * Pf); d_xl.resize((size_t)3 * Lf);
+		d_minv.resize((size_t)36 * Pf);
+		d_r.resize((size_t)6 * Pf); d_z.resize((size_t)6 * Pf); d_p0.resize((size_t)6 * Pf); d_p1.resize((size_t)6 * Pf); d_ap.resize((size_t)6 * Pf);
+		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
+		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
+		maxIterAlloc = mi;
+		d_rz.resize((size_t)(mi + 2) * NSLOT); d_pq.resize((size_t)(mi + 2) * NSLOT);
+		sync();
+
+		st = DeviceStructure();
+		st.nWaves = (int)waveLm.size() / 2; st.wave_lm = d_waveLm.data();
+		st.nBig = (int)bigLm.size(); st.big_lm = d_bigLm.data(); st.big_scratch_ofs = d_bigOfs.data(); st.big_hpl = d_bigHpl.data();
+		st.nblk = nblk; st.hsc_rowptr = d_rowptr.data(); st.hsc_colind = d_colind.data();
+		st.pair_blk = d_pairBlk.data(); st.lm_pair_base = d_lmPairBase.data(); st.lm_nfree = d_lmNfree.data();
+		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
+		sys = DeviceSystem();
+		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
+		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = d_slots.data();
+		sys.maxdiag = d_maxdiag.data(); sys.fail = d_fail.data();
+		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
+		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data();
+		haveStructure = true;
+		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
+		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;   // pattern of Hsc doubles as the "symbolic" phase of the reduced solver
+	}
+
+	void need() { if (!haveGraph) throw StateError{ "set_graph must be called first" }; buildStructure(); g.rk[0] = rk[0]; g.rk[1] = rk[1]; }
+
+	double readSlots(int which)
+	{
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data() + which * NSLOT, sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
+		sync();
+		double s = 0;
+		for (int i = 0; i < NSLOT; i++) s += h_pinned[i];
+		return s;
+	}
+
+	double computeErrors()
+	{
+		need();
+		StageTimer tm(this, 2);
+		HIP_TRY(hipMemsetAsync(d_slots.data(), 0, sizeof(Scalar) * NSLOT, stream));
+		launch_residual_chi2(g, d_slots.data(), nullptr, stream);
+		return readSlots(0);
+	}
+
+	double maxDiagonal()
+	{
+		need();
+		StageTimer tm(this, 3);
+		d_red.zero(stream);
+		d_maxdiag.zero(stream);
+		launch_linearize(g, st, sys, 0, 0.0, stream);
+		launch_pose_maxdiag(g, st, sys, stream);
+		unsigned long long bits = 0;
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8, hipMemcpyDeviceToHost, stream));
+		sync();
+		std::memcpy(&bits, h_pinned, 8);
+		double v; std::memcpy(&v, &bits, 8);
+		return v;
+	}
+
+	void schur()
+	{
+		need();
+		StageTimer tm(this, 4);
+		d_red.zero(stream);
+		launch_linearize(g, st, sys, 1, lambda, stream);
+	}
+
+	bool solveReduced()
+	{
+		need();
+		StageTimer tm(this, 6);
+		if (Pf == 0) return true;
+		const int maxIter = maxIterAlloc;
+		const Scalar tol2 = pcgTol * pcgTol;
+		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
+		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
+		d_fail.zero(stream);
+		launch_pcg_setup(g, st, sys, lambda, stream);
+		const int chunk = std::max(1, pcgCheckEvery);
+		int* hInts = (int*)(h_pinned + 2 * NSLOT);
+		bool converged = false;
+		for (int k0 = 0; k0 < maxIter && !converged; k0 += chunk)
+		{
+			const int k1 = std::min(maxIter, k0 + chunk);
+			for (int k = k0; k < k1; k++) launch_pcg_iteration(g, st, sys, k, maxIter, tol2, stream);
+			HIP_TRY(hipMemcpyAsync(h_pinned, d_rz.data(), sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(h_pinned + NSLOT, d_rz.data() + (size_t)k1 * NSLOT, sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(hInts, d_fail.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(hInts + 1, d_iters.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
+			sync();
+			double rz0 = 0, rzk = 0;
+			for (int i = 0; i < NSLOT; i++) { rz0 += h_pinned[i]; rzk += h_pinned[NSLOT + i]; }
+			if (hInts[0] != 0) { cntPcgIters += hInts[1]; return false; }
+			// a finished solve leaves rz[k1] untouched (= 0) once the kernels turned into no-ops
+			if (!(rzk > tol2 * rz0) || hInts[1] < k1) converged = true;
+		}
+		cntPcgIters += hInts[1];
+		return true;   // hitting max_iter returns the best iterate, like an inexact LM step
+	}
+
+	void backSubstitute()
+	{
+		need();
+		StageTimer tm(this, 4);
+		HIP_TRY(hipMemsetAsync(d_slots.data() + NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
+		launch_back_substitute(g, st, sys, lambda, stream);
+	}
+
+	bool solve()
+	{
+		schur();
+		if (!solveReduced()) return false;
+		backSubstitute();
+		return true;
+	}
+
+	void update()
+	{
+		need();
+		StageTimer tm(this, 7);
+		launch_update_poses(g, sys, stream);
+		launch_update_landmarks(g, sys, stream);
+	}
+
+	// Stage-API version of sum x (lambda x + b): recomputed from xp/bp and xl/bl, valid for any lambda.
+	double computeScale(double lam)
+	{
+		need();
+		HIP_TRY(hipMemsetAsync(d_slots.data() + 3 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
+		launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
+		launch_landmark_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
+		return readSlots(3);
+	}
+
+	void push() { need(); HIP_TRY(hipMemcpyAsync(d_backup.data(), d_state.data(), d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, stream)); }
+	void pop() { need(); HIP_TRY(hipMemcpyAsync(d_state.data(), d_backup.data(), d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, stream)); }
+
+	// Levenberg-Marquardt, control flow of CudaBundleAdjustmentImpl::optimize (:793-857).
+	int optimize(int niter, double* chi2Out)
+	{
+		need();
+		const int maxq = 10;
+		const double tau = 1e-5;
+		double nu = 2, lam = 0, F = 0;
+		int done = 0;
+		for (int it = 0; it < niter; it++)
+		{
+			F = computeErrors();
+			if (it == 0) lam = tau * maxDiagonal();
+			int qn = 0;
+			double rho = -1;
+			for (; qn < maxq && rho < 0; qn++)
+			{
+				cntTrials++;
+				push();
+				lambda = lam;
+				const bool ok = solve();
+				if (ok) update();
+				const double Fhat = computeErrors();
+				double scale = 0;
+				if (ok) scale = scaleOfLastSolve(lam);
+				scale += 1e-3;
+				rho = ok ? (F - Fhat) / scale : -1;
+				if (rho > 0)
+				{
+					const double a = 1 - std::pow(2 * rho - 1, 3);
+					lam *= std::max(1. / 3, std::min(a, 2. / 3));
+					nu = 2;
+					F = Fhat;
+					break;
+				}
+				else
+				{
+					lam *= nu;
+					nu *= 2;
+					pop();
+				}
+			}
+			if (chi2Out) chi2Out[it] = F;
+			done = it + 1;
+			if (qn == maxq || rho <= 0 || !std::isfinite(lam)) break;
+		}
+		lambda = lam;
+		return done;
+	}
+
+	// Fused version used by optimize(): the landmark part was accumulated by back_substitute (same lambda),
+	// only the 6*Pf pose part is added here.
+	double scaleOfLastSolve(double lam)
+	{
+		HIP_TRY(hipMemsetAsync(d_slots.data() + 3 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
+		launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data() + NSLOT, sizeof(Scalar) * 3 * NSLOT, hipMemcpyDeviceToHost, stream));
+		sync();
+		double v = 0;
+		for (int i = 0; i < NSLOT; i++) v += h_pinned[i] + h_pinned[2 * NSLOT + i];
+		return v;
+	}
+
+	void chiSquares(double* out)
+	{
+		need();
+		HIP_TRY(hipMemsetAsync(d_slots.data() + 2 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
+		launch_residual_chi2(g, d_slots.data() + 2 * NSLOT, d_perEdge.data(), stream);
+		std::vector<double> sorted(E);
+		if (E) HIP_TRY(hipMemcpyAsync(sorted.data(), d_perEdge.data(), sizeof(double) * E, hipMemcpyDeviceToHost, stream));
+		sync();
+		for (int i = 0; i < E; i++) out[perm[i]] = sorted[i];
+	}
+};
+
+// -----------------------------------------------------------------------------------------------------
+// C ABI
+// -----------------------------------------------------------------------------------------------------
+namespace
+{
+std::string g_createError;
+
+template <typename F>
+int guarded(cuba_hip_solver* s, F&& f)
+{
+	if (!s) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	try
+	{
+		if (hipSetDevice(s->device) != hipSuccess) { s->lastError = "hipSetDevice failed"; return CUBA_HIP_ERR_RUNTIME; }
+		f();
+		return CUBA_HIP_OK;
+	}
+	catch (const HipError& e)
+	{
+		char buf[512];
+		std::snprintf(buf, sizeof buf, "HIP error %d (%s) in `%s` at %s:%d", (int)e.code, hipGetErrorString(e.code), e.what, e.file, e.line);
+		s->lastError = buf;
+		return CUBA_HIP_ERR_RUNTIME;
+	}
+	catch (const StateError& e) { s->lastError = e.msg; return CUBA_HIP_ERR_STATE; }
+	catch (const ArgError& e) { s->lastError = e.msg; return CUBA_HIP_ERR_INVALID_ARGUMENT; }
+	catch (const std::exception& e) { s->lastError = e.what(); return CUBA_HIP_ERR_RUNTIME; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* cuba_hip_version(void) { return "cuba-hip 0.1 (gfx950, fp64)"; }
+
+int cuba_hip_create(int device, cuba_hip_solver** out)
+{
+	if (!out) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CUBA_HIP_ERR_NO_DEVICE;
+	if (device < 0 || device >= n) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	if (hipSetDevice(device) != hipSuccess) return CUBA_HIP_ERR_RUNTIME;
+	cuba_hip_solver* s = new (std::nothrow) cuba_hip_solver;
+	if (!s) return CUBA_HIP_ERR_RUNTIME;
+	s->device = device;
+	if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return CUBA_HIP_ERR_RUNTIME; }
+	s->ownStream = true;
+	*out = s;
+	return CUBA_HIP_OK;
+}
+
+int cuba_hip_destroy(cuba_hip_solver* s)
+{
+	if (!s) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	(void)hipSetDevice(s->device);
+	(void)hipStreamSynchronize(s->stream);
+	delete s;
+	return CUBA_HIP_OK;
+}
+
+const char* cuba_hip_last_error(const cuba_hip_solver* s) { return s ? s->lastError.c_str() : "null solver handle"; }
+
+int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream)
+{
+	return guarded(s, [&] {
+		s->sync();
+		if (s->ownStream && s->stream) { HIP_TRY(hipStreamDestroy(s->stream)); s->ownStream = false; }
+		s->stream = (hipStream_t)hip_stream;
+	});
+}
+
+int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
+{
+	return guarded(s, [&] {
+		if (!key) throw ArgError{ "null key" };
+		const std::string k(key);
+		if (k == "pcg_tol") s->pcgTol = value;
+		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
+		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
+		else if (k == "profile") s->profile = value != 0;
+		else throw ArgError{ "unknown option: " + k };
+	});
+}
+
+int cuba_hip_set_graph(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf, const double* q, const double* t, const double* cam,
+	const double* Xw, int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
+	const double* meas, const double* omega)
+{
+	return guarded(s, [&] { s->setGraph(Pt, Pf, Lt, Lf, q, t, cam, Xw, E, edge_pose, edge_landmark, edge_dim, meas, omega); });
+}
+
+int cuba_hip_set_robust_kernel(cuba_hip_solver* s, int edge_type, int kind, double delta)
+{
+	return guarded(s, [&] {
+		if (edge_type < 0 || edge_type > 1 || kind < 0 || kind > 2) throw ArgError{ "bad robust kernel" };
+		s->rk[edge_type] = RobustKernel{ kind, delta };
+	});
+}
+
+int cuba_hip_build_structure(cuba_hip_solver* s) { return guarded(s, [&] { s->buildStructure(); s->sync(); }); }
+
+int cuba_hip_compute_errors(cuba_hip_solver* s, double* chi2)
+{
+	return guarded(s, [&] { if (!chi2) throw ArgError{ "null output" }; *chi2 = s->computeErrors(); });
+}
+
+int cuba_hip_build_system(cuba_hip_solver* s) { return guarded(s, [&] { s->need(); }); }
+
+int cuba_hip_max_diagonal(cuba_hip_solver* s, double* v)
+{
+	return guarded(s, [&] { if (!v) throw ArgError{ "null output" }; *v = s->maxDiagonal(); });
+}
+
+int cuba_hip_set_lambda(cuba_hip_solver* s, double lambda) { return guarded(s, [&] { s->lambda = lambda; }); }
+int cuba_hip_restore_diagonal(cuba_hip_solver* s) { return guarded(s, [&] { s->lambda = 0; }); }
+
+int cuba_hip_schur(cuba_hip_solver* s) { return guarded(s, [&] { s->schur(); }); }
+
+int cuba_hip_solve_reduced(cuba_hip_solver* s, int* ok)
+{
+	return guarded(s, [&] { const bool r = s->solveReduced(); if (ok) *ok = r ? 1 : 0; });
+}
+
+int cuba_hip_back_substitute(cuba_hip_solver* s) { return guarded(s, [&] { s->backSubstitute(); }); }
+
+int cuba_hip_solve(cuba_hip_solver* s, int* ok)
+{
+	return guarded(s, [&] { const bool r = s->solve(); if (ok) *ok = r ? 1 : 0; });
+}
+
+int cuba_hip_update(cuba_hip_solver* s) { return guarded(s, [&] { s->update(); }); }
+
+int cuba_hip_compute_scale(cuba_hip_solver* s, double lambda, double* scale)
+{
+	return guarded(s, [&] {
+		if (!scale) throw ArgError{ "null output" };
+		*scale = s->computeScale(lambda);
+	});
+}
+
+int cuba_hip_push(cuba_hip_solver* s) { return guarded(s, [&] { s->push(); }); }
+int cuba_hip_pop(cuba_hip_solver* s) { return guarded(s, [&] { s->pop(); }); }
+
+int cuba_hip_optimize(cuba_hip_solver* s, int niterations, double* chi2_per_iter, int* n_done)
+{
+	return guarded(s, [&] {
+		if (niterations < 0) throw ArgError{ "negative iteration count" };
+		const int n = s->optimize(niterations, chi2_per_iter);
+		if (n_done) *n_done = n;
+	});
+}
+
+int cuba_hip_get_solution(cuba_hip_solver* s, double* q, double* t, double* Xw)
+{
+	return guarded(s, [&] {
+		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		const Scalar* base = s->d_state.data();
+		if (q && s->Pt) HIP_TRY(hipMemcpyAsync(q, base, sizeof(double) * 4 * s->Pt, hipMemcpyDeviceToHost, s->stream));
+		if (t && s->Pt) HIP_TRY(hipMemcpyAsync(t, base + 4 * (size_t)s->Pt, sizeof(double) * 3 * s->Pt, hipMemcpyDeviceToHost, s->stream));
+		if (Xw && s->Lt) HIP_TRY(hipMemcpyAsync(Xw, base + 7 * (size_t)s->Pt, sizeof(double) * 3 * s->Lt, hipMemcpyDeviceToHost, s->stream));
+		s->sync();
+	});
+}
+
+int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, const double* Xw)
+{
+	return guarded(s, [&] {
+		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		Scalar* base = s->d_state.data();
+		if (q && s->Pt) HIP_TRY(hipMemcpyAsync(base, q, sizeof(double) * 4 * s->Pt, hipMemcpyHostToDevice, s->stream));
+		if (t && s->Pt) HIP_TRY(hipMemcpyAsync(base + 4 * (size_t)s->Pt, t, sizeof(double) * 3 * s->Pt, hipMemcpyHostToDevice, s->stream));
+		if (Xw && s->Lt) HIP_TRY(hipMemcpyAsync(base + 7 * (size_t)s->Pt, Xw, sizeof(double) * 3 * s->Lt, hipMemcpyHostToDevice, s->stream));
+		s->sync();
+	});
+}
+
+int cuba_hip_chi_squares(cuba_hip_solver* s, double* out)
+{
+	return guarded(s, [&] { if (!out && s->E) throw ArgError{ "null output" }; s->chiSquares(out); });
+}
+
+int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITEMS])
+{
+	return guarded(s, [&] { for (int i = 0; i < CUBA_HIP_PROFILE_ITEMS; i++) seconds[i] = s->prof[i]; });
+}
+
+int cuba_hip_get_counters(cuba_hip_solver* s, int64_t c[4])
+{
+	return guarded(s, [&] { c[0] = s->cntPcgIters; c[1] = s->cntTrials; c[2] = s->st.nblk; c[3] = s->nmul; });
+}
+
+int cuba_hip_get_hsc_structure(cuba_hip_solver* s, int32_t* row_ptr, int32_t* col_ind, int* nblk)
+{
+	return guarded(s, [&] {
+		s->need();
+		if (nblk) *nblk = (int)s->h_colind.size();
+		if (row_ptr) std::memcpy(row_ptr, s->h_rowptr.data(), sizeof(int) * s->h_rowptr.size());
+		if (col_ind) std::memcpy(col_ind, s->h_colind.data(), sizeof(int) * s->h_colind.size());
+	});
+}
+
+int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count)
+{
+	return guarded(s, [&] {
+		s->need();
+		const Scalar* src = nullptr; size_t n = 0;
+		switch (which)
+		{
+		case CUBA_HIP_ARRAY_BP: src = s->sys.bp; n = (size_t)6 * s->Pf; break;
+		case CUBA_HIP_ARRAY_BSC: src = s->sys.bsc; n = (size_t)6 * s->Pf; break;
+		case CUBA_HIP_ARRAY_XP: src = s->sys.xp; n = (size_t)6 * s->Pf; break;
+		case CUBA_HIP_ARRAY_XL: src = s->sys.xl; n = (size_t)3 * s->Lf; break;
+		case CUBA_HIP_ARRAY_LM_SYS: src = s->sys.lm_sys; n = (size_t)9 * s->Lf; break;
+		case CUBA_HIP_ARRAY_HSC: src = s->sys.hsc; n = (size_t)36 * s->st.nblk; break;
+		default: throw ArgError{ "unknown array id" };
+		}
+		if (count) *count = n;
+		if (out && n) { HIP_TRY(hipMemcpyAsync(out, src, n * sizeof(double), hipMemcpyDeviceToHost, s->stream)); s->sync(); }
+	});
+}
+
+int cuba_hip_reduction_buffer(cuba_hip_solver* s, void** device_ptr, size_t* count)
+{
+	return guarded(s, [&] {
+		s->need();
+		if (device_ptr) *device_ptr = s->d_red.data();
+		if (count) *count = s->d_red.size();
+	});
+}
+
+}  // extern "C"

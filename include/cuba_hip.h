@@ -1,0 +1,188 @@
+/*
+ * cuba_hip.h -- C ABI of the MI355X (gfx950) bundle-adjustment hot path.
+ *
+ * This is the drop-in boundary: everything the reference's host layer (class CudaBlockSolver,
+ * /root/reference/src/cuda_bundle_adjustment.cpp:73-673) asks of its device layer -- the 27 functions
+ * of namespace cuba::gpu (src/cuda_block_solver.h:29-94) plus SparseLinearSolver::{initialize,solve}
+ * (src/cuda_linear_solver.h:28-39) -- is reachable through the entry points below, one solver handle
+ * per graph.  Plain pointers and sizes only; no C++/torch types.  Each entry point names the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *   - every call returns a cuba_hip_status (0 = ok); nothing throws across the ABI;
+ *     cuba_hip_last_error() gives the message of the last failure on that handle.
+ *   - all array arguments are HOST pointers, caller-owned, only read/written during the call.
+ *   - Scalar is fp64.  Quaternions are (x,y,z,w), poses are world->camera, small matrices
+ *     column-major (as in the reference, src/cuda_block_solver.cu:79-105).
+ *   - vertices arrive in "solver order": free poses first [0,Pf), then fixed [Pf,Pt); same for
+ *     landmarks (that is what CudaBlockSolver::initialize produces, :142-200).  Edges may come in
+ *     any order; per-edge outputs are returned in the caller's order.
+ *   - a handle is bound to one device and one HIP stream; it is not re-entrant, distinct handles
+ *     may be driven from distinct host threads.
+ */
+#ifndef CUBA_HIP_H_
+#define CUBA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cuba_hip_solver cuba_hip_solver;
+
+typedef enum cuba_hip_status
+{
+	CUBA_HIP_OK = 0,
+	CUBA_HIP_ERR_INVALID_ARGUMENT = 1,
+	CUBA_HIP_ERR_RUNTIME = 2,       /* a HIP runtime call failed (reference: CUDA_CHECK only prints, src/macro.h:22-27) */
+	CUBA_HIP_ERR_STATE = 3,         /* call order violated (e.g. solve before set_graph) */
+	CUBA_HIP_ERR_NO_DEVICE = 4
+} cuba_hip_status;
+
+/* robust kernel kinds / edge types: include/cuda_bundle_adjustment_types.h:143-148,213-218 */
+enum { CUBA_HIP_ROBUST_NONE = 0, CUBA_HIP_ROBUST_HUBER = 1, CUBA_HIP_ROBUST_TUKEY = 2 };
+enum { CUBA_HIP_EDGE_MONOCULAR = 0, CUBA_HIP_EDGE_STEREO = 1 };
+
+/* profile buckets, same order and meaning as CudaBlockSolver::ProfileItem (src/cuda_bundle_adjustment.cpp:77-88).
+   Bucket 5 ("symbolic decomposition") holds the reduced-system structure analysis, bucket 6
+   ("numerical decomposition") the block-PCG solve that replaces cuSOLVER's factor+solve. */
+enum { CUBA_HIP_PROFILE_ITEMS = 8 };
+
+/* arrays retrievable with cuba_hip_get_array (introspection for parity tests) */
+enum
+{
+	CUBA_HIP_ARRAY_BP = 0,      /* 6*Pf   gradient-side vector bp                  (d_bp_)      */
+	CUBA_HIP_ARRAY_BSC = 1,     /* 6*Pf   reduced right-hand side                   (d_bsc_)     */
+	CUBA_HIP_ARRAY_XP = 2,      /* 6*Pf   pose increments                           (d_xp_)      */
+	CUBA_HIP_ARRAY_XL = 3,      /* 3*Lf   landmark increments                       (d_xl_)      */
+	CUBA_HIP_ARRAY_LM_SYS = 4,  /* 9*Lf   per landmark: 6 unique entries (00,01,02,11,12,22) of Hll
+	                                       (after cuba_hip_max_diagonal) or of inv(Hll+lambda I)
+	                                       (after cuba_hip_schur), then bl (3)                   */
+	CUBA_HIP_ARRAY_HSC = 5      /* 36*nblk upper-triangular BSR values of Hsc (col-major 6x6);
+	                                       after cuba_hip_max_diagonal the diagonal blocks hold Hpp */
+};
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* Replaces: CudaBundleAdjustment::create() -> CudaBlockSolver construction (src/cuda_bundle_adjustment.cpp:905-908). */
+int cuba_hip_create(int device, cuba_hip_solver** out);
+int cuba_hip_destroy(cuba_hip_solver* s);
+const char* cuba_hip_last_error(const cuba_hip_solver* s);
+const char* cuba_hip_version(void);
+
+/* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
+int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
+
+/* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-10), "pcg_max_iter"
+   (default 20*6*Pf capped at 100000), "pcg_check_every" (default 32), "profile" (0/1: per-stage
+   synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */
+int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value);
+
+/* ---- graph upload ---------------------------------------------------------------------------- */
+
+/* Replaces: the SoA gather + uploads of CudaBlockSolver::initialize / buildStructure
+   (src/cuda_bundle_adjustment.cpp:115-261, :319-354).
+   q[4*Pt], t[3*Pt], cam[5*Pt] = (fx,fy,cx,cy,bf) per pose, Xw[3*Lt];
+   edge_pose[E], edge_landmark[E] solver indices; edge_dim[E] in {2,3};
+   meas[3*E] (third component ignored for monocular edges); omega[E] scalar information.
+   Edges whose two ends are both fixed must already be removed (as the reference does, :204-243). */
+int cuba_hip_set_graph(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
+	const double* q, const double* t, const double* cam, const double* Xw,
+	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
+	const double* meas, const double* omega);
+
+/* Replaces: CudaBundleAdjustment::setRobustKernels (src/cuda_bundle_adjustment.cpp:781-784). */
+int cuba_hip_set_robust_kernel(cuba_hip_solver* s, int edge_type, int kind, double delta);
+
+/* Replaces: CudaBlockSolver::buildStructure (:263-366): gpu::buildHplStructure,
+   HschurSparseBlockMatrix::constructFromVertices, gpu::findHschureMulBlockIndices and
+   SparseLinearSolver::initialize (symbolic analysis).  Called implicitly if omitted. */
+int cuba_hip_build_structure(cuba_hip_solver* s);
+
+/* ---- per-iteration stages (same granularity as CudaBlockSolver's public methods) ---------------- */
+
+/* Replaces: CudaBlockSolver::computeErrors -> gpu::computeActiveErrors x2 (:368-382). Total robust chi2. */
+int cuba_hip_compute_errors(cuba_hip_solver* s, double* chi2);
+
+/* Replaces: CudaBlockSolver::buildSystem -> gpu::constructQuadraticForm x2 (:384-410).
+   Marks the current estimate as the linearisation point; the Jacobian products themselves are
+   (re)computed inside cuba_hip_max_diagonal / cuba_hip_schur, nothing is materialised per edge. */
+int cuba_hip_build_system(cuba_hip_solver* s);
+
+/* Replaces: CudaBlockSolver::maxDiagonal -> gpu::maxDiagonal x2 (:412-418). */
+int cuba_hip_max_diagonal(cuba_hip_solver* s, double* max_diag);
+
+/* Replaces: CudaBlockSolver::setLambda / restoreDiagonal -> gpu::addLambda / gpu::restoreDiagonal
+   (:420-430).  lambda is applied on the fly, so restore only forgets it. */
+int cuba_hip_set_lambda(cuba_hip_solver* s, double lambda);
+int cuba_hip_restore_diagonal(cuba_hip_solver* s);
+
+/* CudaBlockSolver::solve (:432-481) in three separately callable parts (so a landmark-partitioned
+   multi-GPU driver can all-reduce between them), and as one call:
+     schur           gpu::computeBschure + gpu::computeHschure                        (:443-444)
+     solve_reduced   gpu::convertHschureBSRToCSR + SparseLinearSolver::solve          (:452-453),
+                     here a block-Jacobi preconditioned block PCG on the BSR matrix
+     back_substitute gpu::schurComplementPost                                          (:463)
+   *ok = 0 reports a numerical failure (non-SPD pivot / PCG breakdown), the reference's
+   "factorize failed" path (src/cuda_linear_solver.cpp:406-410). */
+int cuba_hip_schur(cuba_hip_solver* s);
+int cuba_hip_solve_reduced(cuba_hip_solver* s, int* ok);
+int cuba_hip_back_substitute(cuba_hip_solver* s);
+int cuba_hip_solve(cuba_hip_solver* s, int* ok);
+
+/* Replaces: CudaBlockSolver::update -> gpu::updatePoses + gpu::updateLandmarks (:483-492). */
+int cuba_hip_update(cuba_hip_solver* s);
+
+/* Replaces: CudaBlockSolver::computeScale -> gpu::computeScale (:494-500). sum x (lambda x + b). */
+int cuba_hip_compute_scale(cuba_hip_solver* s, double lambda, double* scale);
+
+/* Replaces: CudaBlockSolver::push / pop (:502-510). */
+int cuba_hip_push(cuba_hip_solver* s);
+int cuba_hip_pop(cuba_hip_solver* s);
+
+/* ---- whole Levenberg-Marquardt run -------------------------------------------------------------- */
+
+/* Replaces: the loop of CudaBundleAdjustmentImpl::optimize (src/cuda_bundle_adjustment.cpp:793-857)
+   with identical control flow (tau = 1e-5, at most 10 trials per iteration, g2o's rho / lambda rules),
+   executed inside the library to avoid per-stage host round trips.
+   chi2_per_iter[niterations] receives BatchInfo::chi2 for each executed iteration, *n_done their count. */
+int cuba_hip_optimize(cuba_hip_solver* s, int niterations, double* chi2_per_iter, int* n_done);
+
+/* ---- results ------------------------------------------------------------------------------------ */
+
+/* Replaces: CudaBlockSolver::finalize downloads (:512-526). */
+int cuba_hip_get_solution(cuba_hip_solver* s, double* q, double* t, double* Xw);
+int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, const double* Xw);
+
+/* Replaces: CudaBlockSolver::getChiSqs -> gpu::computeChiSquares x2 (:528-543).
+   Non-robust omega*|r|^2 per edge, in the caller's edge order. */
+int cuba_hip_chi_squares(cuba_hip_solver* s, double* chi2_per_edge);
+
+/* Replaces: CudaBlockSolver::getTimeProfile (:545-562). Seconds per bucket. */
+int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITEMS]);
+
+/* Counters of the last optimize / solve: [0] PCG iterations (total), [1] LM trials (total),
+   [2] number of 6x6 blocks in upper-triangular Hsc, [3] number of Schur block products (nmul). */
+int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[4]);
+
+/* ---- introspection (parity tests) and multi-GPU plumbing ------------------------------------------ */
+
+/* Structure of the reduced system: upper-triangular BSR (replaces the accessors of
+   HschurSparseBlockMatrix, src/sparse_block_matrix.h:81-101). row_ptr[Pf+1], col_ind[nblk]. */
+int cuba_hip_get_hsc_structure(cuba_hip_solver* s, int32_t* row_ptr, int32_t* col_ind, int* nblk);
+
+/* Copy an internal device array to the host; out may be NULL to query *count only. */
+int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count);
+
+/* Device address + length (in doubles) of the contiguous buffer [Hsc values | bsc | bp] that a
+   landmark-partitioned multi-GPU driver must sum across ranks between cuba_hip_schur and
+   cuba_hip_solve_reduced (RCCL all-reduce over xGMI; no equivalent in the single-GPU reference). */
+int cuba_hip_reduction_buffer(cuba_hip_solver* s, void** device_ptr, size_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CUBA_HIP_H_ */
