@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Levenberg-Marquardt bundle adjustment on a KITTI-00-shaped graph.
+
+A "step" is one LM iteration (linearise + Schur + reduced solve + back-substitution + update +
+re-evaluation) over the whole graph; `value` = edges x steps / wall  (edge-iterations per second, the
+reading under which the reference's README numbers give 4.56 M/s on a GTX 1080 and 0.47 M/s for g2o).
+The stricter reading (edges / wall of a 10-iteration run) is reported next to it.
+
+N = 1 : BASELINE.json configs[1] -- ba_kitti_00 shape (1332 poses / 133383 landmarks / 561116 edges,
+        synthetic stand-in, seed 0), fp64, Huber kernels as in samples/sample_comparison_with_g2o.cpp:195-200.
+N > 1 : configs[3] -- one independent KITTI-00-sized graph per GPU (seeds 100+rank), no data-path
+        collective (weak scaling); launched by torchrun, one rank per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters")
+LM_RUN = 10               # iterations per LM run (the reference protocol: optimize(10))
+
+
+def algorithmic_bytes(fp, nblk):
+    """Compulsory bytes per launch of each hot kernel."""
+    E, Pf, Pt, Lf, Lt = fp.E, fp.Pf, fp.Pt, fp.Lf, fp.Lt
+    edge_in = 40 * E                     # pose idx 4 + landmark idx 4 + 3 x 8 measurement + 8 information
+    return {
+        "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
+        "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
+        "pcg_spmv": 288 * nblk + 4 * 48 * Pf,
+        "pcg_update": (288 + 6 * 48) * Pf,
+        "back_substitute": edge_in + (24 + 72 + 24) * Lf + (96 + 48) * Pt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--shape", default="kitti00")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import SHAPES, synth_named
+
+    rk = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
+    seed = SHAPES[args.shape]["seed"] if world == 1 else 100 + rank
+    fp = flatten(synth_named(args.shape, seed=seed))
+    solver = HipSolver(fp, rk, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    solver.build_structure()
+    q0, t0, X0 = solver.state()
+
+    def run_steps(k):
+        """k LM iterations as runs of LM_RUN iterations from the initial estimate. Returns chi2 of the last run."""
+        chi2, left = None, k
+        while left > 0:
+            n = min(LM_RUN, left)
+            solver.set_state(q0, t0, X0)
+            chi2 = solver.optimize(n)["chi2"]
+            if len(chi2) != n:
+                raise RuntimeError(f"LM stopped after {len(chi2)} of {n} iterations")
+            left -= n
+        return chi2
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    c0 = solver.counters()
+    fence()
+    t_start = time.perf_counter()
+    chi2 = run_steps(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    c1 = solver.counters()
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    pcg_iters = c1["pcg_iterations"] - c0["pcg_iterations"]
+    trials = c1["lm_trials"] - c0["lm_trials"]
+    E = fp.E
+    value = E * args.steps * world / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: per-kernel device time from HIP events on the solver's stream ------------
+        solver.set_state(q0, t0, X0)
+        kt = solver.time_kernels(reps=20)
+        nblk = c1["hsc_blocks"]
+        alg = algorithmic_bytes(fp, nblk)
+        launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
+                    "pcg_update": pcg_iters, "back_substitute": trials}
+        share = {k: kt[k] * launches[k] for k in kt}
+        dom = max(share, key=share.get)
+        kernels = {k: {"ms_per_launch": kt[k], "launches": launches[k], "alg_bytes": alg[k],
+                       "achieved_GBs": alg[k] / (kt[k] * 1e-3) / 1e9} for k in kt}
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "kernels": kernels}
+        out = {
+            "metric": "edges/sec (edge-iterations/s = E x LM iterations / wall) on KITTI-00-shaped graph, fp64, chi2 vs g2o-faithful oracle",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ba_{args.shape}-shaped synthetic stereo graph, {LM_RUN}-iteration LM runs, Huber",
+                       "poses": fp.Pt, "landmarks": fp.Lt, "edges": E, "graphs": world,
+                       "parallelism": "1 graph per GPU (no collective)" if world > 1 else "single GPU"},
+            "wall_ms_total": elapsed * 1e3,
+            "wall_ms_10iter": elapsed * 1e3 * LM_RUN / args.steps,
+            "edges_per_s_strict_10iter": E * world / (elapsed * LM_RUN / args.steps),
+            "pcg_iterations": pcg_iters, "lm_trials": trials, "hsc_blocks": nblk, "schur_products": c1["schur_products"],
+            "final_chi2": float(chi2[-1]),
+            "roofline": roof,
+        }
+        # ---- CPU baseline + parity leg (rank 0, N = 1 only): the oracle on the host cores ------------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.oracle import OracleSolver
+            n = min(LM_RUN, args.steps)
+            orc = OracleSolver(fp, rk)
+            orc.build_structure()
+            tc = time.perf_counter()
+            ref = orc.optimize(n)
+            tc = time.perf_counter() - tc
+            solver.set_state(q0, t0, X0)
+            got = solver.optimize(n)["chi2"]
+            m = min(len(got), len(ref["chi2"]))
+            out["cpu_baseline"] = {"value": E * len(ref["chi2"]) / tc, "unit": "edges/s", "cores": 1, "kind": "port",
+                                   "sample": f"same graph, {len(ref['chi2'])} LM iterations, oracle/ba_oracle.cpp single thread, "
+                                             f"{tc:.2f} s (structure analysis excluded, as for the GPU)"}
+            out["chi2_max_rel_diff_vs_oracle"] = float(np.max(np.abs(got[:m] - ref["chi2"][:m]) / ref["chi2"][:m]))
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

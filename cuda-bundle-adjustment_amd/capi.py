@@ -81,6 +81,7 @@ def load_library():
         "cuba_hip_get_counters": [H, C.POINTER(C.c_int64)],
         "cuba_hip_get_hsc_structure": [H, _ip, _ip, C.POINTER(C.c_int)],
         "cuba_hip_get_array": [H, C.c_int, _dp, C.POINTER(C.c_size_t)],
+        "cuba_hip_time_kernels": [H, C.c_int, _dp],
         "cuba_hip_reduction_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     }
     for name, args in sig.items():
@@ -239,6 +240,11 @@ class HipSolver:
         rp, ci = self.hsc_structure()
         v = self.array("hsc").reshape(len(ci), 6, 6).transpose(0, 2, 1).copy()
         return rp, ci, v
+
+    def time_kernels(self, reps=20):
+        out = np.zeros(5)
+        self._ck(self.lib.cuba_hip_time_kernels(self.h, int(reps), _d(out)))
+        return dict(zip(("residual_chi2", "linearize_schur", "pcg_spmv", "pcg_update", "back_substitute"), out.tolist()))
 
     def reduction_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

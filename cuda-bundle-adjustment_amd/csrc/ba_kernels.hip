@@ -924,12 +924,20 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 	if (blockIdx.x == 0 && threadIdx.x == 0) *sys.iters = k + 1;
 }
 
+void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_spmv_kernel, dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
+}
+
+void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
+}
+
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	const int gridA = (g.Pf + 3) / 4;
-	const int gridB = (g.Pf + 39) / 40;
-	hipLaunchKernelGGL(pcg_spmv_kernel, dim3(gridA), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
-	hipLaunchKernelGGL(pcg_update_kernel, dim3(gridB), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
+	launch_pcg_spmv(g, st, sys, k, maxIter, tol2, s);
+	launch_pcg_update(g, st, sys, k, maxIter, tol2, s);
 }
 
 }  // namespace cubahip

@@ -538,6 +538,41 @@ struct cuba_hip_solver
 		return v;
 	}
 
+	// Average device time per launch of the five hot kernels, measured with HIP events on this solver's
+	// stream (bench.py's roofline leg).  Leaves the increments / reduced system in an undefined state.
+	void timeKernels(int reps, double* msOut)
+	{
+		need();
+		hipEvent_t e0, e1;
+		HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+		auto timeit = [&](auto&& fn) {
+			fn();
+			HIP_TRY(hipEventRecord(e0, stream));
+			for (int i = 0; i < reps; i++) fn();
+			HIP_TRY(hipEventRecord(e1, stream));
+			HIP_TRY(hipEventSynchronize(e1));
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+			return (double)ms / reps;
+		};
+		const double lam = lambda > 0 ? lambda : 1.0;
+		msOut[0] = timeit([&] { launch_residual_chi2(g, d_slots.data(), nullptr, stream); });
+		d_red.zero(stream);
+		msOut[1] = timeit([&] { launch_linearize(g, st, sys, 1, lam, stream); });
+		// a consistent reduced system for the PCG kernels
+		d_red.zero(stream);
+		launch_linearize(g, st, sys, 1, lam, stream);
+		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
+		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
+		d_fail.zero(stream);
+		launch_pcg_setup(g, st, sys, lam, stream);
+		msOut[2] = timeit([&] { launch_pcg_spmv(g, st, sys, 0, 1 << 30, -1.0, stream); });
+		msOut[3] = timeit([&] { launch_pcg_update(g, st, sys, 0, 1 << 30, -1.0, stream); });
+		msOut[4] = timeit([&] { launch_back_substitute(g, st, sys, lam, stream); });
+		d_fail.zero(stream);
+		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	}
+
 	void chiSquares(double* out)
 	{
 		need();
@@ -768,6 +803,14 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
 		}
 		if (count) *count = n;
 		if (out && n) { HIP_TRY(hipMemcpyAsync(out, src, n * sizeof(double), hipMemcpyDeviceToHost, s->stream)); s->sync(); }
+	});
+}
+
+int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUBA_HIP_TIMED_KERNELS])
+{
+	return guarded(s, [&] {
+		if (reps <= 0 || !ms_per_launch) throw ArgError{ "bad arguments" };
+		s->timeKernels(reps, ms_per_launch);
 	});
 }
 

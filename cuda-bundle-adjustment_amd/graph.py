@@ -146,12 +146,16 @@ def flatten(g: Graph) -> FlatProblem:
         if P and int(g.pose_ids.min()) >= 0 and int(g.pose_ids.max()) < 4 * P + 1024:
             lut = np.full(int(g.pose_ids.max()) + 1, -1, dtype=np.int64)
             lut[g.pose_ids] = np.arange(P)
+            if vp.min() < 0 or vp.max() >= len(lut):
+                raise KeyError("edge references an unknown pose id")
             ep_row = lut[vp]
         else:
             ep_row = np.array([prow[int(i)] for i in vp], dtype=np.int64)
         if L and int(g.lm_ids.min()) >= 0 and int(g.lm_ids.max()) < 4 * (L + P) + 1024:
             lut = np.full(int(g.lm_ids.max()) + 1, -1, dtype=np.int64)
             lut[g.lm_ids] = np.arange(L)
+            if vl.min() < 0 or vl.max() >= len(lut):
+                raise KeyError("edge references an unknown landmark id")
             el_row = lut[vl]
         else:
             el_row = np.array([lrow[int(i)] for i in vl], dtype=np.int64)

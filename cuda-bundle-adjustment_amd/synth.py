@@ -103,12 +103,14 @@ def synth_ba(P, L, E, seed=0, cam=KITTI00_CAM, stereo_frac=0.85, outlier_frac=0.
     NW = 6 if (loop_closure and lap_len + 8 < P) else 0       # loop-closure window (frames of the other lap)
 
     cand_obs_p, cand_obs_l, cand_X, cand_n = [], [], [], []
-    n_have, e_have, batch_id = 0, 0, 0
+    n_have, e_have = 0, 0
     # geometric track-length model: n = 2 + Geom; visibility filtering removes some, so aim higher
     p_geo = min(0.95, 1.0 / max(mean_track * 1.35 - 1.0, 1.05))
-    while n_have < int(1.6 * L) + 64 or e_have < int(1.25 * E) + 64:
+
+    def gen_batch():
+        nonlocal n_have, e_have
         N = int(1.2 * L) + 256
-        a = rng.integers(0, P, N)
+        a = rng.integers(0, max(1, P - int(mean_track)), N) if P < 64 else rng.integers(0, P, N)
         n = np.minimum(2 + rng.geometric(p_geo, N) - 1, max_track)
         # point defined in the LAST frame of its track so that it stays in front of the camera
         last = np.minimum(a + n - 1, P - 1)
@@ -138,29 +140,41 @@ def synth_ba(P, L, E, seed=0, cam=KITTI00_CAM, stereo_frac=0.85, outlier_frac=0.
         new_index = np.cumsum(good) - 1 + n_have
         cand_obs_p.append(fr[li, ki]); cand_obs_l.append(new_index[li])
         cand_X.append(Xw[good]); cand_n.append(cnt[good])
-        n_have += int(good.sum()); e_have += int(cnt[good].sum()); batch_id += 1
-        if batch_id > 40:
-            raise RuntimeError("could not generate enough visible landmarks")
-    obs_p = np.concatenate(cand_obs_p); obs_l = np.concatenate(cand_obs_l)
-    X_all = np.concatenate(cand_X); n_all = np.concatenate(cand_n)
+        n_have += int(good.sum()); e_have += int(cnt[good].sum())
 
-    # ---- choose exactly L landmarks with exactly E observations ------------------------------
-    chosen = np.zeros(n_have, dtype=bool)
-    chosen[:L] = True
-    S = int(n_all[:L].sum())
-    if S < E:
-        unused = np.nonzero(~chosen)[0]
-        unused = unused[np.argsort(-n_all[unused], kind="stable")]
-        used = np.nonzero(chosen)[0]
-        used = used[np.argsort(n_all[used], kind="stable")]
-        m = min(len(unused), len(used))
-        gain = np.cumsum(n_all[unused[:m]] - n_all[used[:m]])
-        k = int(np.searchsorted(gain, E - S)) + 1
-        if k > m or gain[k - 1] < E - S:
-            raise RuntimeError("not enough long tracks to reach the requested edge count")
-        chosen[used[:k]] = False
-        chosen[unused[:k]] = True
-        S = int(n_all[chosen].sum())
+    def select(n_all):
+        """Choose exactly L landmarks whose tracks hold at least E observations (None if impossible yet)."""
+        chosen = np.zeros(len(n_all), dtype=bool)
+        chosen[:L] = True
+        S = int(n_all[:L].sum())
+        if S < E:
+            unused = np.nonzero(~chosen)[0]
+            unused = unused[np.argsort(-n_all[unused], kind="stable")]
+            used = np.nonzero(chosen)[0]
+            used = used[np.argsort(n_all[used], kind="stable")]
+            m = min(len(unused), len(used))
+            gain = np.cumsum(n_all[unused[:m]] - n_all[used[:m]])
+            k = int(np.searchsorted(gain, E - S)) + 1
+            if k > m or gain[k - 1] < E - S:
+                return None
+            chosen[used[:k]] = False
+            chosen[unused[:k]] = True
+        return chosen
+
+    chosen = None
+    for _ in range(60):
+        gen_batch()
+        if n_have < int(1.6 * L) + 64 or e_have < int(1.25 * E) + 64:
+            continue
+        n_all = np.concatenate(cand_n)
+        chosen = select(n_all)
+        if chosen is not None:
+            break
+    if chosen is None:
+        raise RuntimeError("could not generate enough visible landmark tracks for the requested (P, L, E)")
+    obs_p = np.concatenate(cand_obs_p); obs_l = np.concatenate(cand_obs_l)
+    X_all = np.concatenate(cand_X)
+    S = int(n_all[chosen].sum())
     keep_n = n_all.copy()
     surplus = S - E
     if surplus > 0:

@@ -176,6 +176,13 @@ int cuba_hip_get_hsc_structure(cuba_hip_solver* s, int32_t* row_ptr, int32_t* co
 /* Copy an internal device array to the host; out may be NULL to query *count only. */
 int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count);
 
+/* Measurement hook for bench.py: average device milliseconds per launch, taken with HIP events on the
+   handle's stream over `reps` back-to-back launches, of
+     [0] residual_chi2  [1] linearize+Schur  [2] pcg_spmv  [3] pcg_update  [4] back_substitute.
+   Clobbers the increments and the reduced system (not the estimates). */
+enum { CUBA_HIP_TIMED_KERNELS = 5 };
+int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUBA_HIP_TIMED_KERNELS]);
+
 /* Device address + length (in doubles) of the contiguous buffer [Hsc values | bsc | bp] that a
    landmark-partitioned multi-GPU driver must sum across ranks between cuba_hip_schur and
    cuba_hip_solve_reduced (RCCL all-reduce over xGMI; no equivalent in the single-GPU reference). */
