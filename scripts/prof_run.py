@@ -17,3 +17,6 @@ for r in range(runs + 1):
     h.set_state(q0, t0, X0)
     t = time.time(); res = h.optimize(10); dt = time.time() - t
     print("run", r, "%.1f ms" % (dt * 1e3), "chi2[-1]", res["chi2"][-1], h.counters())
+h.close()
+sys.stdout.flush()
+os._exit(0)   # skip interpreter teardown (rocprofv3 finalisation + atexit handlers hung once on this pool)

@@ -143,17 +143,18 @@ def test_lm_parity_pose_only_and_landmark_only(solvers, small_graph):
 def test_landmarks_with_more_than_64_observations(solvers):
     """Landmarks seen by > 64 poses leave the one-lane-per-edge wave path (big_* kernels)."""
     from scipy.spatial.transform import Rotation
-    g = synth_ba(100, 1500, 6000, seed=21)
+    g = synth_ba(300, 3000, 12000, seed=21)
     rng = np.random.default_rng(0)
     R = Rotation.from_quat(g.truth["q"]).as_matrix()
     cam = g.pose_cam[0]
     extra_X, vp, vl, meas, info = [], [], [], [], []
     for k in range(6):
         # a far point roughly ahead of the middle pose: visible (Z > 0) from most poses
-        c = -R[50].T @ g.truth["t"][50]
-        X = c + R[50].T @ np.array([rng.uniform(-20, 20), rng.uniform(-5, 5), rng.uniform(300, 500)])
+        mid = 60 + 30 * k
+        c = -R[mid].T @ g.truth["t"][mid]
+        X = c + R[mid].T @ np.array([rng.uniform(-20, 20), rng.uniform(-5, 5), rng.uniform(150, 250)])
         Xc = np.einsum("nij,j->ni", R, X) + g.truth["t"]
-        ok = np.nonzero(Xc[:, 2] > 50)[0]
+        ok = np.nonzero(Xc[:, 2] > 20)[0]
         if len(ok) <= 64:
             continue
         u = cam[0] * Xc[ok, 0] / Xc[ok, 2] + cam[2]; v = cam[1] * Xc[ok, 1] / Xc[ok, 2] + cam[3]
