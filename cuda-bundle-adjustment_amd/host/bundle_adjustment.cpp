@@ -1,0 +1,303 @@
+// bundle_adjustment.cpp -- host C++ layer: cuba::CudaBundleAdjustment implemented over the C ABI
+// (include/cuba_hip.h).  Plain C++17, no HIP headers: everything device-side happens behind the ABI.
+//
+// Behavioural counterpart of CudaBundleAdjustmentImpl and of the host half of CudaBlockSolver
+// (/root/reference/src/cuda_bundle_adjustment.cpp:115-261 initialize, :512-543 finalize/getChiSqs,
+// :677-903 graph containers + LM entry).  Differences, all deliberate:
+//   * edges are kept in insertion order (the reference iterates unordered_sets, so its edge order and
+//     hence its last-bit results change from run to run);
+//   * the device handle is created lazily in optimize(), so graph editing and initialize() work on a
+//     machine without a GPU;
+//   * failures raise std::runtime_error instead of being printed and ignored.
+
+#include "cuda_bundle_adjustment.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cuba_hip.h"
+
+namespace cuba
+{
+namespace
+{
+
+const char* const kProfileKeys[CUBA_HIP_PROFILE_ITEMS] = {
+	"0: Initialize Optimizer", "1: Build Structure", "2: Compute Error", "3: Build System",
+	"4: Schur Complement", "5: Symbolic Decomposition", "6: Numerical Decomposition", "7: Update Solution"
+};
+
+// insertion-ordered pointer set
+template <class T>
+class OrderedSet
+{
+public:
+	bool insert(T* p)
+	{
+		if (index_.count(p)) return false;
+		index_[p] = next_;
+		order_[next_++] = p;
+		return true;
+	}
+	bool erase(T* p)
+	{
+		auto it = index_.find(p);
+		if (it == index_.end()) return false;
+		order_.erase(it->second);
+		index_.erase(it);
+		return true;
+	}
+	bool contains(T* p) const { return index_.count(p) != 0; }
+	size_t size() const { return index_.size(); }
+	void clear() { index_.clear(); order_.clear(); next_ = 0; }
+	const std::map<uint64_t, T*>& ordered() const { return order_; }
+private:
+	std::unordered_map<T*, uint64_t> index_;
+	std::map<uint64_t, T*> order_;
+	uint64_t next_ = 0;
+};
+
+class HipBundleAdjustment final : public CudaBundleAdjustment
+{
+public:
+	~HipBundleAdjustment() override
+	{
+		if (solver_) cuba_hip_destroy(solver_);
+	}
+
+	// ---- graph editing (ref :681-764) -----------------------------------------------------------
+	void addPoseVertex(PoseVertex* v) override { poses_.insert({ v->id, v }); }
+	void addLandmarkVertex(LandmarkVertex* v) override { landmarks_.insert({ v->id, v }); }
+
+	void addMonocularEdge(MonoEdge* e) override
+	{
+		mono_.insert(e);
+		e->vertexP->edges.insert(e);
+		e->vertexL->edges.insert(e);
+	}
+
+	void addStereoEdge(StereoEdge* e) override
+	{
+		stereo_.insert(e);
+		e->vertexP->edges.insert(e);
+		e->vertexL->edges.insert(e);
+	}
+
+	PoseVertex* poseVertex(int id) const override { return poses_.at(id); }
+	LandmarkVertex* landmarkVertex(int id) const override { return landmarks_.at(id); }
+
+	void removePoseVertex(PoseVertex* v) override
+	{
+		auto it = poses_.find(v->id);
+		if (it == poses_.end()) return;
+		const std::vector<BaseEdge*> incident(it->second->edges.begin(), it->second->edges.end());
+		for (BaseEdge* e : incident) removeEdge(e);
+		poses_.erase(it);
+	}
+
+	void removeLandmarkVertex(LandmarkVertex* v) override
+	{
+		auto it = landmarks_.find(v->id);
+		if (it == landmarks_.end()) return;
+		const std::vector<BaseEdge*> incident(it->second->edges.begin(), it->second->edges.end());
+		for (BaseEdge* e : incident) removeEdge(e);
+		landmarks_.erase(it);
+	}
+
+	void removeEdge(BaseEdge* e) override
+	{
+		if (PoseVertex* p = e->poseVertex()) p->edges.erase(e);
+		if (LandmarkVertex* l = e->landmarkVertex()) l->edges.erase(e);
+		if (e->dim() == 2) mono_.erase(static_cast<MonoEdge*>(e));
+		else if (e->dim() == 3) stereo_.erase(static_cast<StereoEdge*>(e));
+	}
+
+	size_t nposes() const override { return poses_.size(); }
+	size_t nlandmarks() const override { return landmarks_.size(); }
+	size_t nedges() const override { return mono_.size() + stereo_.size(); }
+
+	void setRobustKernels(RobustKernelType kernelType, double delta, EdgeType edgeType) override
+	{
+		const int et = static_cast<int>(edgeType);
+		if (et < 0 || et >= 2) throw std::invalid_argument("setRobustKernels: bad edge type");
+		robustKind_[et] = static_cast<int>(kernelType);
+		robustDelta_[et] = delta;
+	}
+
+	// ---- initialize: graph -> solver-order flat arrays (ref CudaBlockSolver::initialize :115-261) ----
+	void initialize() override
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		activePoses_.clear(); activeLandmarks_.clear(); activeEdges_.clear();
+		q_.clear(); t_.clear(); cam_.clear(); Xw_.clear();
+		edgePose_.clear(); edgeLandmark_.clear(); edgeDim_.clear(); meas_.clear(); omega_.clear();
+
+		std::vector<PoseVertex*> fixedP;
+		std::vector<LandmarkVertex*> fixedL;
+		for (const auto& kv : poses_)           // id order; vertices without edges take no part
+		{
+			PoseVertex* v = kv.second;
+			if (v->edges.empty()) continue;
+			(v->fixed ? fixedP : activePoses_).push_back(v);
+		}
+		numFreePoses_ = static_cast<int>(activePoses_.size());
+		activePoses_.insert(activePoses_.end(), fixedP.begin(), fixedP.end());
+		for (const auto& kv : landmarks_)
+		{
+			LandmarkVertex* v = kv.second;
+			if (v->edges.empty()) continue;
+			(v->fixed ? fixedL : activeLandmarks_).push_back(v);
+		}
+		numFreeLandmarks_ = static_cast<int>(activeLandmarks_.size());
+		activeLandmarks_.insert(activeLandmarks_.end(), fixedL.begin(), fixedL.end());
+
+		for (size_t i = 0; i < activePoses_.size(); i++)
+		{
+			PoseVertex* v = activePoses_[i];
+			v->iP = static_cast<int>(i);
+			const double* qc = v->q.coeffs().data();       // (x, y, z, w)
+			q_.insert(q_.end(), qc, qc + 4);
+			t_.insert(t_.end(), v->t.data(), v->t.data() + 3);
+			const double c[5] = { v->camera.fx, v->camera.fy, v->camera.cx, v->camera.cy, v->camera.bf };
+			cam_.insert(cam_.end(), c, c + 5);
+		}
+		for (size_t i = 0; i < activeLandmarks_.size(); i++)
+		{
+			LandmarkVertex* v = activeLandmarks_[i];
+			v->iL = static_cast<int>(i);
+			Xw_.insert(Xw_.end(), v->Xw.data(), v->Xw.data() + 3);
+		}
+		auto addEdge = [&](BaseEdge* e, const double* m, int dim, double info) {
+			PoseVertex* p = e->poseVertex();
+			LandmarkVertex* l = e->landmarkVertex();
+			if (p->fixed && l->fixed) return;               // inactive edge (ref :209-221)
+			activeEdges_.push_back(e);
+			edgePose_.push_back(p->iP);
+			edgeLandmark_.push_back(l->iL);
+			edgeDim_.push_back(static_cast<uint8_t>(dim));
+			meas_.push_back(m[0]); meas_.push_back(m[1]); meas_.push_back(dim == 3 ? m[2] : 0.0);
+			omega_.push_back(info);
+		};
+		for (const auto& kv : mono_.ordered()) addEdge(kv.second, kv.second->measurement.data(), 2, kv.second->information);
+		for (const auto& kv : stereo_.ordered()) addEdge(kv.second, kv.second->measurement.data(), 3, kv.second->information);
+
+		stats_.clear();
+		graphDirty_ = true;
+		initialized_ = true;
+		initSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
+
+	// ---- optimize: the LM loop runs behind the ABI (ref :793-857) -----------------------------------
+	void optimize(int niterations) override
+	{
+		if (!initialized_) throw std::runtime_error("optimize() called before initialize()");
+		if (!solver_)
+		{
+			const char* dev = std::getenv("CUBA_HIP_DEVICE");
+			check(cuba_hip_create(dev ? std::atoi(dev) : 0, &solver_), "cuba_hip_create");
+			if (const char* p = std::getenv("CUBA_HIP_PROFILE")) check(cuba_hip_set_option(solver_, "profile", std::atof(p)), "set_option");
+			if (const char* p = std::getenv("CUBA_HIP_PCG_TOL")) check(cuba_hip_set_option(solver_, "pcg_tol", std::atof(p)), "set_option");
+		}
+		for (int et = 0; et < 2; et++) check(cuba_hip_set_robust_kernel(solver_, et, robustKind_[et], robustDelta_[et]), "set_robust_kernel");
+		if (graphDirty_)
+		{
+			check(cuba_hip_set_graph(solver_, static_cast<int>(activePoses_.size()), numFreePoses_,
+				static_cast<int>(activeLandmarks_.size()), numFreeLandmarks_, q_.data(), t_.data(), cam_.data(), Xw_.data(),
+				static_cast<int>(activeEdges_.size()), edgePose_.data(), edgeLandmark_.data(), edgeDim_.data(), meas_.data(), omega_.data()),
+				"cuba_hip_set_graph");
+			graphDirty_ = false;
+		}
+		std::vector<double> chi2(std::max(niterations, 1), 0.0);
+		int done = 0;
+		check(cuba_hip_optimize(solver_, niterations, chi2.data(), &done), "cuba_hip_optimize");
+		for (int i = 0; i < done; i++) stats_.push_back({ i, chi2[i] });
+
+		// finalize (ref :512-526): estimates back into the caller's vertices
+		check(cuba_hip_get_solution(solver_, q_.data(), t_.data(), Xw_.data()), "cuba_hip_get_solution");
+		for (size_t i = 0; i < activePoses_.size(); i++)
+		{
+			double* qc = activePoses_[i]->q.coeffs().data();
+			for (int k = 0; k < 4; k++) qc[k] = q_[4 * i + k];
+			for (int k = 0; k < 3; k++) activePoses_[i]->t.data()[k] = t_[3 * i + k];
+		}
+		for (size_t i = 0; i < activeLandmarks_.size(); i++)
+			for (int k = 0; k < 3; k++) activeLandmarks_[i]->Xw.data()[k] = Xw_[3 * i + k];
+
+		// per-edge chi2 (ref getChiSqs :528-543)
+		std::vector<double> perEdge(activeEdges_.size());
+		check(cuba_hip_chi_squares(solver_, perEdge.data()), "cuba_hip_chi_squares");
+		chiSqs_.clear();
+		for (size_t i = 0; i < activeEdges_.size(); i++) chiSqs_[activeEdges_[i]] = perEdge[i];
+
+		double prof[CUBA_HIP_PROFILE_ITEMS];
+		check(cuba_hip_get_profile(solver_, prof), "cuba_hip_get_profile");
+		prof[0] += initSeconds_;
+		initSeconds_ = 0;
+		timeProfile_.clear();
+		for (int i = 0; i < CUBA_HIP_PROFILE_ITEMS; i++) timeProfile_[kProfileKeys[i]] = prof[i];
+	}
+
+	void clear() override
+	{
+		poses_.clear(); landmarks_.clear(); mono_.clear(); stereo_.clear(); stats_.clear();
+		initialized_ = false;
+	}
+
+	const BatchStatistics& batchStatistics() const override { return stats_; }
+	const TimeProfile& timeProfile() const override { return timeProfile_; }
+
+	double chiSquared(const BaseEdge* e) const override
+	{
+		auto it = chiSqs_.find(e);
+		return it == chiSqs_.end() ? 0.0 : it->second;
+	}
+
+private:
+	void check(int status, const char* what) const
+	{
+		if (status == CUBA_HIP_OK) return;
+		std::string msg = std::string(what) + " failed (status " + std::to_string(status) + ")";
+		if (solver_) { msg += ": "; msg += cuba_hip_last_error(solver_); }
+		else if (status == CUBA_HIP_ERR_NO_DEVICE) msg += ": no HIP device visible";
+		throw std::runtime_error(msg);
+	}
+
+	std::map<int, PoseVertex*> poses_;
+	std::map<int, LandmarkVertex*> landmarks_;
+	OrderedSet<MonoEdge> mono_;
+	OrderedSet<StereoEdge> stereo_;
+	int robustKind_[2] = { 0, 0 };
+	double robustDelta_[2] = { 0, 0 };
+
+	// flattened problem (solver order)
+	std::vector<PoseVertex*> activePoses_;
+	std::vector<LandmarkVertex*> activeLandmarks_;
+	std::vector<BaseEdge*> activeEdges_;
+	int numFreePoses_ = 0, numFreeLandmarks_ = 0;
+	std::vector<double> q_, t_, cam_, Xw_, meas_, omega_;
+	std::vector<int32_t> edgePose_, edgeLandmark_;
+	std::vector<uint8_t> edgeDim_;
+	bool initialized_ = false, graphDirty_ = false;
+	double initSeconds_ = 0;
+
+	cuba_hip_solver* solver_ = nullptr;
+	BatchStatistics stats_;
+	TimeProfile timeProfile_;
+	std::unordered_map<const BaseEdge*, double> chiSqs_;
+};
+
+}  // namespace
+
+CudaBundleAdjustment::Ptr CudaBundleAdjustment::create() { return std::make_unique<HipBundleAdjustment>(); }
+
+CudaBundleAdjustment::~CudaBundleAdjustment() = default;
+
+}  // namespace cuba

@@ -19,4 +19,3 @@ for r in range(runs + 1):
     print("run", r, "%.1f ms" % (dt * 1e3), "chi2[-1]", res["chi2"][-1], h.counters())
 h.close()
 sys.stdout.flush()
-os._exit(0)   # skip interpreter teardown (rocprofv3 finalisation + atexit handlers hung once on this pool)
