@@ -26,15 +26,18 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MI
 LM_RUN = 10               # iterations per LM run (the reference protocol: optimize(10))
 
 
-def algorithmic_bytes(fp, nblk):
-    """Compulsory bytes per launch of each hot kernel."""
+def algorithmic_bytes(fp, nblk, nc):
+    """Compulsory bytes per launch of each hot kernel. nc = coarse aggregates."""
     E, Pf, Pt, Lf, Lt = fp.E, fp.Pf, fp.Pt, fp.Lf, fp.Lt
+    Nc = 6 * nc
     edge_in = 40 * E                     # pose idx 4 + landmark idx 4 + 3 x 8 measurement + 8 information
     return {
         "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
         "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
         "pcg_spmv": 288 * nblk + 4 * 48 * Pf,
-        "pcg_update": (288 + 6 * 48) * Pf,
+        "pcg_update": (288 + 6 * 48) * Pf if nc == 0 else 5 * 48 * Pf + 8 * Nc,
+        "pcg_precond": 8 * Nc * Nc + 8 * Nc + (288 + 2 * 48) * Pf,
+        "coarse_setup": 288 * nblk + 3 * 8 * Nc * Nc,          # read Hsc once, write Ac, read+write it once more for the inverse
         "back_substitute": edge_in + (24 + 72 + 24) * Lf + (96 + 48) * Pt,
     }
 
@@ -114,9 +117,11 @@ def main():
         solver.set_state(q0, t0, X0)
         kt = solver.time_kernels(reps=20)
         nblk = c1["hsc_blocks"]
-        alg = algorithmic_bytes(fp, nblk)
+        nc = 0 if kt["pcg_precond"] == 0 else (fp.Pf + max(16, (fp.Pf + 255) // 256) - 1) // max(16, (fp.Pf + 255) // 256)
+        alg = algorithmic_bytes(fp, nblk, nc)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
-                    "pcg_update": pcg_iters, "back_substitute": trials}
+                    "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials, "coarse_setup": trials}
+        kt = {k: v for k, v in kt.items() if v > 0}
         share = {k: kt[k] * launches[k] for k in kt}
         dom = max(share, key=share.get)
         kernels = {k: {"ms_per_launch": kt[k], "launches": launches[k], "alg_bytes": alg[k],

@@ -242,9 +242,10 @@ class HipSolver:
         return rp, ci, v
 
     def time_kernels(self, reps=20):
-        out = np.zeros(5)
+        out = np.zeros(7)
         self._ck(self.lib.cuba_hip_time_kernels(self.h, int(reps), _d(out)))
-        return dict(zip(("residual_chi2", "linearize_schur", "pcg_spmv", "pcg_update", "back_substitute"), out.tolist()))
+        return dict(zip(("residual_chi2", "linearize_schur", "pcg_spmv", "pcg_update", "back_substitute", "pcg_precond",
+                         "coarse_setup"), out.tolist()))
 
     def reduction_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 #pragma unroll
 			for (int c = 0; c < 6; c++) z += Ai[c * 6 + r] * rr[c];
 			sys.r[6 * (size_t)i + r] = rr[r];
-			sys.z[6 * (size_t)i + r] = z;
+			sys.z[6 * (size_t)i + r] = z;   // overwritten by pcg2_precond_kernel when the coarse level is on
 			sys.xp[6 * (size_t)i + r] = 0;
 			sys.p0[6 * (size_t)i + r] = 0;
 			sys.p1[6 * (size_t)i + r] = 0;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 		}
 	}
 	rz = wave_sum(rz);
-	if ((threadIdx.x & 63) == 0) atomic_add(&sys.rz[(blockIdx.x * 4 + (threadIdx.x >> 6)) % NSLOT], rz);
+	if (sys.agg == 0 && (threadIdx.x & 63) == 0) atomic_add(&sys.rz[(blockIdx.x * 4 + (threadIdx.x >> 6)) % NSLOT], rz);
 	if (i == 0) *sys.iters = 0;
 }
 
@@ -922,6 +922,242 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 	dot = wave_sum(dot);
 	if (lane == 0) atomic_add(&sys.rz[(size_t)(k + 1) * NSLOT + ((blockIdx.x * 4 + wv) % NSLOT)], dot);
 	if (blockIdx.x == 0 && threadIdx.x == 0) *sys.iters = k + 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Two-level preconditioner  M^-1 = blockdiag(A)^-1 + P (P^T A P)^-1 P^T.
+// P is piecewise constant over aggregates of `agg` consecutive free poses (6 coarse dof per aggregate):
+// keyframe chains are stiff along the trajectory, and these are exactly the slowly converging drift
+// modes of block-Jacobi CG (1887 -> 226 iterations on the KITTI-00-shaped system at lambda_9).
+// The coarse matrix is dense and small (6*nc <= ~1500), so its explicit inverse is formed on the device by
+// a blocked Gauss-Jordan sweep (SPD => no pivoting) and applied as a dense mat-vec inside the PCG.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar* Ac)
+{
+	extern __shared__ __attribute__((aligned(16))) Scalar rowbuf[];   // 6 x Nc, column-major
+	const int I = blockIdx.x;
+	const int Nc = 6 * sys.nc;
+	for (int t = threadIdx.x; t < 6 * Nc; t += 256) rowbuf[t] = 0;
+	__syncthreads();
+	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+	const int a0 = st.adj_ptr[i0], a1 = st.adj_ptr[i1];
+	for (int w = threadIdx.x; w < (a1 - a0) * 36; w += 256)
+	{
+		const int a = a0 + w / 36, el = w % 36;
+		const int r = el % 6, c = el / 6;
+		const int bi = st.adj_blk[a];
+		const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
+		const Scalar v = (bi < 0) ? B[r * 6 + c] : B[c * 6 + r];
+		const int J = st.adj_col[a] / sys.agg;
+		__hip_atomic_fetch_add(&rowbuf[(J * 6 + c) * 6 + r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < 6 * Nc; t += 256)
+	{
+		const int col = t / 6, r = t % 6;
+		Ac[(size_t)col * Nc + I * 6 + r] = rowbuf[t];
+	}
+}
+
+constexpr int GJ_B = 24;      // pivot block width of the Gauss-Jordan sweep
+constexpr int GJ_T = 32;      // output tile edge
+
+// One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk): dst = GJ_step(src). After the last step dst = A^-1.
+__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk)
+{
+	__shared__ Scalar D[GJ_B][GJ_B + 1];
+	__shared__ Scalar Apj[GJ_B][GJ_T + 1];
+	__shared__ Scalar R[GJ_B][GJ_T + 1];
+	__shared__ Scalar F[GJ_T][GJ_B + 1];
+	const int tid = threadIdx.x;
+	const int i0 = blockIdx.y * GJ_T, j0 = blockIdx.x * GJ_T;
+	for (int t = tid; t < GJ_B * GJ_B; t += 256)
+	{
+		const int r = t % GJ_B, c = t / GJ_B;
+		D[r][c] = (r < bk && c < bk) ? src[(size_t)(p0 + c) * n + p0 + r] : (r == c ? Scalar(1) : Scalar(0));
+	}
+	for (int t = tid; t < GJ_B * GJ_T; t += 256)
+	{
+		const int k = t % GJ_B, c = t / GJ_B;      // Apj[k][c] = A[p0+k, j0+c]
+		Apj[k][c] = (k < bk && j0 + c < n) ? src[(size_t)(j0 + c) * n + p0 + k] : Scalar(0);
+		const int r = t % GJ_T, kk = t / GJ_T;    // F[r][kk] = A[i0+r, p0+kk]
+		F[r][kk] = (kk < bk && i0 + r < n) ? src[(size_t)(p0 + kk) * n + i0 + r] : Scalar(0);
+	}
+	__syncthreads();
+	// in-place scalar Gauss-Jordan inverse of the pivot block (every workgroup repeats it: bk^3 flops)
+	for (int p = 0; p < bk; p++)
+	{
+		const Scalar d = 1 / D[p][p];
+		__syncthreads();
+		if (tid < bk && tid != p) D[p][tid] *= d;
+		__syncthreads();
+		for (int t = tid; t < bk * bk; t += 256)
+		{
+			const int i = t % bk, j = t / bk;
+			if (i != p && j != p) D[i][j] -= D[i][p] * D[p][j];
+		}
+		__syncthreads();
+		if (tid < bk && tid != p) D[tid][p] = -D[tid][p] * d;
+		if (tid == 0) D[p][p] = d;
+		__syncthreads();
+	}
+	// R = D * Apj
+	for (int t = tid; t < GJ_B * GJ_T; t += 256)
+	{
+		const int k = t % GJ_B, c = t / GJ_B;
+		Scalar s = 0;
+		if (k < bk)
+			for (int m = 0; m < bk; m++) s += D[k][m] * Apj[m][c];
+		R[k][c] = s;
+	}
+	__syncthreads();
+	for (int t = tid; t < GJ_T * GJ_T; t += 256)
+	{
+		const int r = t % GJ_T, c = t / GJ_T;
+		const int gi = i0 + r, gj = j0 + c;
+		if (gi >= n || gj >= n) continue;
+		const bool rp = gi >= p0 && gi < p0 + bk, cp = gj >= p0 && gj < p0 + bk;
+		Scalar v;
+		if (rp && cp) v = D[gi - p0][gj - p0];
+		else if (rp) v = R[gi - p0][c];
+		else if (cp)
+		{
+			Scalar s = 0;
+			for (int k = 0; k < bk; k++) s += F[r][k] * D[k][gj - p0];
+			v = -s;
+		}
+		else
+		{
+			Scalar s = src[(size_t)gj * n + gi];
+			for (int k = 0; k < bk; k++) s -= F[r][k] * R[k][c];
+			v = s;
+		}
+		dst[(size_t)gj * n + gi] = v;
+	}
+}
+
+// Assemble P^T A P from the (already damped) reduced matrix and invert it. Leaves sys.acinv pointing at the result.
+void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s)
+{
+	const int Nc = 6 * sys.nc;
+	hipLaunchKernelGGL(coarse_assemble_kernel, dim3(sys.nc), dim3(256), sizeof(Scalar) * 6 * Nc, s, g, st, sys, work0);
+	Scalar* src = work0; Scalar* dst = work1;
+	const int tiles = (Nc + GJ_T - 1) / GJ_T;
+	for (int p0 = 0; p0 < Nc; p0 += GJ_B)
+	{
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles), dim3(256), 0, s, src, dst, Nc, p0, min(GJ_B, Nc - p0));
+		Scalar* tmp = src; src = dst; dst = tmp;
+	}
+	sys.acinv = src;
+}
+
+// B1(k): [x += alpha p; r -= alpha q;]  rc = P^T r        (one 128-thread workgroup per aggregate)
+__global__ __launch_bounds__(128) void pcg2_restrict_kernel(DeviceGraph g, DeviceSystem sys, int k, int maxIter, Scalar tol2, int doUpdate)
+{
+	__shared__ Scalar red[128];
+	const int lane = threadIdx.x & 63;
+	Scalar alpha = 0;
+	if (doUpdate)
+	{
+		Scalar rzk;
+		if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
+		const Scalar pqk = sum_slots(sys.pq + (size_t)k * NSLOT, lane);
+		if (!(pqk > 0))
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
+			return;
+		}
+		alpha = rzk / pqk;
+	}
+	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;
+	const int I = blockIdx.x;
+	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+	const int comp = threadIdx.x % 6;
+	Scalar acc = 0;
+	if (threadIdx.x < 126)
+		for (int i = i0 + threadIdx.x / 6; i < i1; i += 21)
+		{
+			const size_t idx = 6 * (size_t)i + comp;
+			Scalar r = sys.r[idx];
+			if (doUpdate)
+			{
+				sys.xp[idx] += alpha * p[idx];
+				r -= alpha * sys.ap[idx];
+				sys.r[idx] = r;
+			}
+			acc += r;
+		}
+	red[threadIdx.x] = acc;
+	__syncthreads();
+	if (threadIdx.x < 6)
+	{
+		Scalar s = 0;
+		for (int t = threadIdx.x; t < 126; t += 6) s += red[t];
+		sys.rc[6 * (size_t)I + threadIdx.x] = s;
+	}
+	if (doUpdate && blockIdx.x == 0 && threadIdx.x == 0) *sys.iters = k + 1;
+}
+
+// B3(k): z = Minv r + P (Ac^-1 rc);  rz[kOut] += r.z      (one 128-thread workgroup per aggregate)
+__global__ __launch_bounds__(128) void pcg2_precond_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2)
+{
+	__shared__ Scalar part[128][6];
+	__shared__ Scalar yc[6];
+	__shared__ Scalar wsum[2];
+	const int lane = threadIdx.x & 63;
+	if (k >= 0)
+	{
+		Scalar rzk;
+		if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
+		const Scalar pqk = sum_slots(sys.pq + (size_t)k * NSLOT, lane);
+		if (!(pqk > 0)) return;
+	}
+	const int I = blockIdx.x;
+	const int Nc = 6 * sys.nc;
+	// yc = Ac^-1[6I..6I+6, :] rc   (the inverse is symmetric: read columns 6I..6I+5, contiguous in memory)
+	Scalar acc[6] = { 0, 0, 0, 0, 0, 0 };
+	for (int j = threadIdx.x; j < Nc; j += 128)
+	{
+		const Scalar rj = sys.rc[j];
+#pragma unroll
+		for (int c = 0; c < 6; c++) acc[c] += sys.acinv[(size_t)(6 * I + c) * Nc + j] * rj;
+	}
+#pragma unroll
+	for (int c = 0; c < 6; c++) part[threadIdx.x][c] = acc[c];
+	__syncthreads();
+	if (threadIdx.x < 6)
+	{
+		Scalar s = 0;
+		for (int t = 0; t < 128; t++) s += part[t][threadIdx.x];
+		yc[threadIdx.x] = s;
+	}
+	__syncthreads();
+	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+	const int comp = threadIdx.x % 6;
+	Scalar dot = 0;
+	if (threadIdx.x < 126)
+		for (int i = i0 + threadIdx.x / 6; i < i1; i += 21)
+		{
+			Scalar z = yc[comp];
+#pragma unroll
+			for (int c = 0; c < 6; c++) z += sys.minv[36 * (size_t)i + c * 6 + comp] * sys.r[6 * (size_t)i + c];
+			sys.z[6 * (size_t)i + comp] = z;
+			dot += sys.r[6 * (size_t)i + comp] * z;
+		}
+	dot = wave_sum(dot);
+	if (lane == 0) wsum[threadIdx.x >> 6] = dot;
+	__syncthreads();
+	if (threadIdx.x == 0) atomic_add(&sys.rz[(size_t)kOut * NSLOT + (blockIdx.x % NSLOT)], wsum[0] + wsum[1]);
+}
+
+void launch_pcg2_restrict(const DeviceGraph& g, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg2_restrict_kernel, dim3(sys.nc), dim3(128), 0, s, g, sys, k, maxIter, tol2, doUpdate);
+}
+
+void launch_pcg2_precond(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg2_precond_kernel, dim3(sys.nc), dim3(128), 0, s, g, sys, k, kOut, maxIter, tol2);
 }
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)

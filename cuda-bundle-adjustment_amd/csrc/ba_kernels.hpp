@@ -66,6 +66,11 @@ struct DeviceSystem
 	Scalar *minv = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *ap = nullptr;
 	Scalar *rz = nullptr, *pq = nullptr;   // [(maxIter+2)*NSLOT] each
 	int* iters = nullptr;      // device iteration counter
+	// two-level preconditioner: aggregates of `agg` consecutive free poses, 6 coarse dof each
+	int agg = 0;               // 0 = block-Jacobi only
+	int nc = 0;                // number of aggregates (coarse dimension = 6*nc)
+	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
+	Scalar* rc = nullptr;      // [6nc] restricted residual
 };
 
 // residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
@@ -94,6 +99,10 @@ void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipS
 void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
+// two-level (block-Jacobi + aggregate coarse correction) variant: 3 kernels per iteration
+void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s);
+void launch_pcg2_restrict(const DeviceGraph& g, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
+void launch_pcg2_precond(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
 }  // namespace cubahip

@@ -86,6 +86,7 @@ struct cuba_hip_solver
 	double pcgTol = 1e-10;
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 32;
+	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
 	bool profile = false;
 
 	// host copy of the problem (solver order) and of the sort permutation
@@ -106,6 +107,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters;
+	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc;
 	std::vector<int> h_rowptr, h_colind;
 	Scalar* h_pinned = nullptr;   // 4*NSLOT doubles + small ints
 
@@ -340,6 +342,12 @@ struct cuba_hip_solver
 		d_minv.resize((size_t)36 * Pf);
 		d_r.resize((size_t)6 * Pf); d_z.resize((size_t)6 * Pf); d_p0.resize((size_t)6 * Pf); d_p1.resize((size_t)6 * Pf); d_ap.resize((size_t)6 * Pf);
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
+		// coarse level of the preconditioner: aggregates of consecutive free poses, coarse dimension <= 1536
+		int agg = pcgAggregate;
+		if (agg < 0) agg = std::max(16, (Pf + 255) / 256);
+		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
+		if (nc < 2) { agg = 0; nc = 0; }
+		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
 		d_rz.resize((size_t)(mi + 2) * NSLOT); d_pq.resize((size_t)(mi + 2) * NSLOT);
@@ -357,6 +365,7 @@ struct cuba_hip_solver
 		sys.maxdiag = d_maxdiag.data(); sys.fail = d_fail.data();
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
 		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data();
+		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
 		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;   // pattern of Hsc doubles as the "symbolic" phase of the reduced solver
@@ -417,13 +426,29 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
 		launch_pcg_setup(g, st, sys, lambda, stream);
+		const bool twoLevel = sys.agg > 0;
+		if (twoLevel)
+		{
+			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
+			launch_pcg2_restrict(g, sys, 0, maxIter, tol2, 0, stream);
+			launch_pcg2_precond(g, sys, -1, 0, maxIter, tol2, stream);
+		}
 		const int chunk = std::max(1, pcgCheckEvery);
 		int* hInts = (int*)(h_pinned + 2 * NSLOT);
 		bool converged = false;
 		for (int k0 = 0; k0 < maxIter && !converged; k0 += chunk)
 		{
 			const int k1 = std::min(maxIter, k0 + chunk);
-			for (int k = k0; k < k1; k++) launch_pcg_iteration(g, st, sys, k, maxIter, tol2, stream);
+			for (int k = k0; k < k1; k++)
+			{
+				if (twoLevel)
+				{
+					launch_pcg_spmv(g, st, sys, k, maxIter, tol2, stream);
+					launch_pcg2_restrict(g, sys, k, maxIter, tol2, 1, stream);
+					launch_pcg2_precond(g, sys, k, k + 1, maxIter, tol2, stream);
+				}
+				else launch_pcg_iteration(g, st, sys, k, maxIter, tol2, stream);
+			}
 			HIP_TRY(hipMemcpyAsync(h_pinned, d_rz.data(), sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(h_pinned + NSLOT, d_rz.data() + (size_t)k1 * NSLOT, sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts, d_fail.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -566,8 +591,24 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
 		launch_pcg_setup(g, st, sys, lam, stream);
+		if (sys.agg > 0)
+		{
+			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
+			launch_pcg2_restrict(g, sys, 0, 1 << 30, -1.0, 0, stream);
+			launch_pcg2_precond(g, sys, -1, 0, 1 << 30, -1.0, stream);
+		}
 		msOut[2] = timeit([&] { launch_pcg_spmv(g, st, sys, 0, 1 << 30, -1.0, stream); });
-		msOut[3] = timeit([&] { launch_pcg_update(g, st, sys, 0, 1 << 30, -1.0, stream); });
+		if (sys.agg > 0)
+		{
+			msOut[3] = timeit([&] { launch_pcg2_restrict(g, sys, 0, 1 << 30, -1.0, 1, stream); });
+			msOut[5] = timeit([&] { launch_pcg2_precond(g, sys, 0, 1, 1 << 30, -1.0, stream); });
+			msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream); });
+		}
+		else
+		{
+			msOut[3] = timeit([&] { launch_pcg_update(g, st, sys, 0, 1 << 30, -1.0, stream); });
+			msOut[5] = 0; msOut[6] = 0;
+		}
 		msOut[4] = timeit([&] { launch_back_substitute(g, st, sys, lam, stream); });
 		d_fail.zero(stream);
 		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -664,6 +705,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		if (k == "pcg_tol") s->pcgTol = value;
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
+		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
 	});

@@ -76,7 +76,8 @@ const char* cuba_hip_version(void);
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
 /* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-10), "pcg_max_iter"
-   (default 20*6*Pf capped at 100000), "pcg_check_every" (default 32), "profile" (0/1: per-stage
+   (default 4*6*Pf capped at 32768), "pcg_check_every" (default 32), "pcg_aggregate" (poses per coarse
+   aggregate of the two-level preconditioner; -1 = automatic (16), 0 = block-Jacobi only), "profile" (0/1: per-stage
    synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */
 int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value);
 
@@ -178,9 +179,11 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
 
 /* Measurement hook for bench.py: average device milliseconds per launch, taken with HIP events on the
    handle's stream over `reps` back-to-back launches, of
-     [0] residual_chi2  [1] linearize+Schur  [2] pcg_spmv  [3] pcg_update  [4] back_substitute.
+     [0] residual_chi2  [1] linearize+Schur  [2] pcg_spmv  [3] pcg_update (+restrict)  [4] back_substitute
+     [5] pcg_precond (two-level preconditioner apply; 0 if disabled)
+     [6] coarse_setup (assemble + invert the coarse matrix, once per solve; 0 if disabled).
    Clobbers the increments and the reduced system (not the estimates). */
-enum { CUBA_HIP_TIMED_KERNELS = 5 };
+enum { CUBA_HIP_TIMED_KERNELS = 7 };
 int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUBA_HIP_TIMED_KERNELS]);
 
 /* Device address + length (in doubles) of the contiguous buffer [Hsc values | bsc | bp] that a

@@ -183,6 +183,22 @@ def test_landmarks_with_more_than_64_observations(solvers):
     compare_lm(HipSolver, OracleSolver, fp, RK_HUBER, 5)
 
 
+def test_preconditioner_modes_agree(solvers, small_fp):
+    """Block-Jacobi PCG and the two-level (aggregate coarse correction) PCG solve the same system."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
+    o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
+    lam = 1e-7 * o.max_diagonal()
+    o.set_lambda(lam); assert o.solve()
+    its = {}
+    for agg in (0, 16, 5):
+        h = HipSolver(fp, RK_HUBER, pcg_aggregate=agg)
+        h.set_lambda(lam); assert h.solve()
+        assert rel(h.array("xp"), o.array("xp")) < 1e-6 and rel(h.array("xl"), o.array("xl")) < 1e-6
+        its[agg] = h.counters()["pcg_iterations"]
+    assert its[16] < its[0] and its[5] < its[0], its       # the coarse level must pay off on a keyframe chain
+
+
 def test_golden_trajectories_on_gpu(solvers):
     HipSolver, _ = solvers
     with open(os.path.join(os.path.dirname(__file__), "golden", "lm_trajectories.json")) as f:
