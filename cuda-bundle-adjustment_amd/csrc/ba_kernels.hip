@@ -524,6 +524,363 @@ void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const Dev
 	}
 }
 
+// ===================================================================================================
+// Destination-major Schur assembly (default).  No atomics, no per-landmark pair loops:
+//   1. lm_pass_kernel     lane = edge, wave = landmarks: Hll/bl reduced in LDS, (Hll+lambda I)^-1, and a
+//                         64-byte linearisation record per edge {Xc, w', r, landmark/stereo tag};
+//   2. pose_pass_kernel   wave = free pose: every edge of the pose contributes Hpp_e - W_e Hpl_e^T, bp_e,
+//                         bp_e - Hpl_e Hll^-1 bl to registers, one wave reduction, plain stores;
+//   3. block_pass_kernel  16 lanes = one off-diagonal block (a,b): the products of all landmarks seen by
+//                         both poses, T = JP_a^T [w_a w_b JL_a Hll^-1 JL_b^T] JP_b, rebuilt from the two
+//                         records (no Hpl tile is ever stored), reduced over the 16 lanes, one plain store.
+// Every output has exactly one writer and a fixed summation order => results are reproducible bit for bit.
+// ===================================================================================================
+constexpr int REC = 8;   // doubles per edge record
+
+__device__ __forceinline__ void rec_jacobians(const Scalar* rec, const Rot3& R, const Scalar cam[5], EdgeLin& L, Scalar& wr, int& il, Scalar Xc[3])
+{
+	Xc[0] = rec[0]; Xc[1] = rec[1]; Xc[2] = rec[2];
+	wr = rec[3];
+	L.r[0] = rec[4]; L.r[1] = rec[5]; L.r[2] = rec[6];
+	const long long tag = (long long)rec[7];
+	il = (int)(tag >> 1);
+	edge_jacobians(Xc, R, cam, (tag & 1) != 0, L);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
+{
+	__shared__ Scalar lds_all[(LIN_BLOCK / WAVE) * WAVE * 9];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int wave = blockIdx.x * (LIN_BLOCK / WAVE) + wv;
+	if (wave >= st.nWaves) return;
+	Scalar* lds = lds_all + wv * WAVE * 9;
+	const int lm0 = st.wave_lm[2 * wave], lm1 = st.wave_lm[2 * wave + 1];
+	const int e0 = g.lm_ptr[lm0], e1 = g.lm_ptr[lm1];
+	const int e = e0 + lane;
+	const bool valid = e < e1;
+	int il = lm0, seg0 = 0, seg1 = 0;
+	Scalar h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	if (valid)
+	{
+		const int pe = g.e_pose[e];
+		const bool stereo = (pe & STEREO_BIT) != 0;
+		const int ip = pe & ~STEREO_BIT;
+		il = g.e_lm[e];
+		Scalar q[4], t[3], cam[5], Xw[3], meas[3], Xc[3];
+		EdgeLin L;
+		load_pose(g, ip, q, t, cam);
+#pragma unroll
+		for (int i = 0; i < 3; i++) Xw[i] = g.Xw[3 * (size_t)il + i];
+		meas[0] = g.e_mu[e]; meas[1] = g.e_mv[e]; meas[2] = g.e_mr[e];
+		const Scalar w = g.e_w[e];
+		const Scalar ss = edge_residual(q, t, cam, Xw, meas, stereo, L.r, Xc);
+		const int kind = stereo ? g.rk[1].kind : g.rk[0].kind;
+		const Scalar delta = stereo ? g.rk[1].delta : g.rk[0].delta;
+		const Scalar wr = w * robust_weight(kind, delta, w * ss);
+		Scalar* rec = st.e_rec + REC * (size_t)e;
+		rec[0] = Xc[0]; rec[1] = Xc[1]; rec[2] = Xc[2]; rec[3] = wr;
+		rec[4] = L.r[0]; rec[5] = L.r[1]; rec[6] = L.r[2]; rec[7] = (Scalar)(2 * (long long)il + (stereo ? 1 : 0));
+		if (il < g.Lf)
+		{
+			const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
+			edge_jacobians(Xc, R, cam, stereo, L);
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+			{
+#pragma unroll
+				for (int j = i; j < 3; j++)
+					h[sym3_idx(i, j)] = wr * (L.JL[0][i] * L.JL[0][j] + L.JL[1][i] * L.JL[1][j] + L.JL[2][i] * L.JL[2][j]);
+				h[6 + i] = wr * (L.JL[0][i] * L.r[0] + L.JL[1][i] * L.r[1] + L.JL[2][i] * L.r[2]);
+			}
+			seg0 = g.lm_ptr[il] - e0;
+			seg1 = g.lm_ptr[il + 1] - e0;
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 9; k++) lds[lane * 9 + k] = h[k];
+	wave_lds_sync();
+	const bool head = valid && il < g.Lf && lane == seg0;
+	Scalar m = 0;
+	if (head)
+	{
+		Scalar H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		for (int j = seg0; j < seg1; j++)
+#pragma unroll
+			for (int k = 0; k < 9; k++) H[k] += lds[j * 9 + k];
+		Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+		if (MODE == 0)
+		{
+#pragma unroll
+			for (int k = 0; k < 9; k++) ls[k] = H[k];
+			m = fmax(H[0], fmax(H[3], H[5]));
+		}
+		else
+		{
+			Scalar inv[6];
+			H[0] += lambda; H[3] += lambda; H[5] += lambda;
+			sym3_inverse(H, inv);
+#pragma unroll
+			for (int k = 0; k < 6; k++) ls[k] = inv[k];
+#pragma unroll
+			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
+		}
+	}
+	if (MODE == 0)
+	{
+		m = wave_max(m);
+		if (lane == 0) atomic_max_nonneg(sys.maxdiag, m);
+	}
+}
+
+// landmarks with more than 64 observations: one workgroup each
+template <int MODE>
+__global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
+{
+	__shared__ Scalar red[4][9];
+	const int il = st.big_lm[blockIdx.x];
+	const int e0 = g.lm_ptr[il], e1 = g.lm_ptr[il + 1];
+	Scalar acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (int e = e0 + threadIdx.x; e < e1; e += 256)
+	{
+		LaneEdge le;
+		linearize_edge(g, e, le);
+		// linearize_edge does not return Xc: recompute it for the record
+		Scalar q[4], t[3], cam[5], Xw[3], Xc[3];
+		load_pose(g, le.ip, q, t, cam);
+#pragma unroll
+		for (int i = 0; i < 3; i++) Xw[i] = g.Xw[3 * (size_t)il + i];
+		quat_rotate(q, Xw, Xc);
+		Scalar* rec = st.e_rec + REC * (size_t)e;
+		rec[0] = Xc[0] + t[0]; rec[1] = Xc[1] + t[1]; rec[2] = Xc[2] + t[2]; rec[3] = le.wr;
+		rec[4] = le.lin.r[0]; rec[5] = le.lin.r[1]; rec[6] = le.lin.r[2]; rec[7] = (Scalar)(2 * (long long)il + (le.stereo ? 1 : 0));
+		if (il < g.Lf)
+		{
+			const EdgeLin& L = le.lin;
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+			{
+#pragma unroll
+				for (int j = i; j < 3; j++)
+					acc[sym3_idx(i, j)] += le.wr * (L.JL[0][i] * L.JL[0][j] + L.JL[1][i] * L.JL[1][j] + L.JL[2][i] * L.JL[2][j]);
+				acc[6 + i] += le.wr * (L.JL[0][i] * L.r[0] + L.JL[1][i] * L.r[1] + L.JL[2][i] * L.r[2]);
+			}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 9; k++) acc[k] = wave_sum(acc[k]);
+	if ((threadIdx.x & 63) == 0)
+#pragma unroll
+		for (int k = 0; k < 9; k++) red[threadIdx.x >> 6][k] = acc[k];
+	__syncthreads();
+	if (threadIdx.x == 0 && il < g.Lf)
+	{
+		Scalar H[9];
+#pragma unroll
+		for (int k = 0; k < 9; k++) H[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+		Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+		if (MODE == 0)
+		{
+#pragma unroll
+			for (int k = 0; k < 9; k++) ls[k] = H[k];
+			atomic_max_nonneg(sys.maxdiag, fmax(H[0], fmax(H[3], H[5])));
+		}
+		else
+		{
+			Scalar inv[6];
+			H[0] += lambda; H[3] += lambda; H[5] += lambda;
+			sym3_inverse(H, inv);
+#pragma unroll
+			for (int k = 0; k < 6; k++) ls[k] = inv[k];
+#pragma unroll
+			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
+		}
+	}
+}
+
+// wave = free pose: diagonal block (upper triangle), bp, bsc
+template <int MODE>
+__global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+{
+	const int lane = threadIdx.x & 63;
+	const int ip = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (ip >= g.Pf) return;
+	Scalar q[4], t[3], cam[5];
+	load_pose(g, ip, q, t, cam);
+	const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
+	Scalar acc[33];
+#pragma unroll
+	for (int k = 0; k < 33; k++) acc[k] = 0;
+	const int p1 = st.pe_ptr[ip + 1];
+	for (int p = st.pe_ptr[ip] + lane; p < p1; p += 64)
+	{
+		const int e = st.pe_edge[p];
+		EdgeLin L; Scalar wr, Xc[3]; int il;
+		rec_jacobians(st.e_rec + REC * (size_t)e, R, cam, L, wr, il, Xc);
+		Scalar hpl[6][3], W[6][3], ibl[3] = { 0, 0, 0 };
+		const bool lmFree = MODE == 1 && il < g.Lf;
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+#pragma unroll
+			for (int k = 0; k < 3; k++)
+				hpl[c][k] = wr * (L.JP[0][c] * L.JL[0][k] + L.JP[1][c] * L.JL[1][k] + L.JP[2][c] * L.JL[2][k]);
+		if (lmFree)
+		{
+			const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+			Scalar inv[6], bl[3];
+#pragma unroll
+			for (int k = 0; k < 6; k++) inv[k] = ls[k];
+#pragma unroll
+			for (int k = 0; k < 3; k++) bl[k] = ls[6 + k];
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+				ibl[i] = inv[sym3_idx(i, 0)] * bl[0] + inv[sym3_idx(i, 1)] * bl[1] + inv[sym3_idx(i, 2)] * bl[2];
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+#pragma unroll
+				for (int k = 0; k < 3; k++)
+					W[r][k] = hpl[r][0] * inv[sym3_idx(0, k)] + hpl[r][1] * inv[sym3_idx(1, k)] + hpl[r][2] * inv[sym3_idx(2, k)];
+		}
+		else
+		{
+#pragma unroll
+			for (int r = 0; r < 6; r++) { W[r][0] = 0; W[r][1] = 0; W[r][2] = 0; }
+		}
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+		{
+#pragma unroll
+			for (int r = 0; r <= c; r++)
+				acc[c * (c + 1) / 2 + r] += wr * (L.JP[0][r] * L.JP[0][c] + L.JP[1][r] * L.JP[1][c] + L.JP[2][r] * L.JP[2][c])
+					- (W[r][0] * hpl[c][0] + W[r][1] * hpl[c][1] + W[r][2] * hpl[c][2]);
+			const Scalar b = wr * (L.JP[0][c] * L.r[0] + L.JP[1][c] * L.r[1] + L.JP[2][c] * L.r[2]);
+			acc[21 + c] += b;
+			acc[27 + c] += b - (hpl[c][0] * ibl[0] + hpl[c][1] * ibl[1] + hpl[c][2] * ibl[2]);
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 33; k++) acc[k] = wave_sum(acc[k]);
+	if (lane == 0)
+	{
+		Scalar* blk = sys.hsc + 36 * (size_t)st.hsc_rowptr[ip];
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+		{
+#pragma unroll
+			for (int r = 0; r <= c; r++) blk[c * 6 + r] = acc[c * (c + 1) / 2 + r];
+			sys.bp[6 * (size_t)ip + c] = acc[21 + c];
+			if (MODE == 1) sys.bsc[6 * (size_t)ip + c] = acc[27 + c];
+		}
+	}
+}
+
+// 16 lanes = one block (a,b) of Hsc with a != b (or a == b for the rare duplicate-observation products)
+constexpr int BP_GROUP = 16;
+
+__global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+{
+	const int gl = threadIdx.x & (BP_GROUP - 1);
+	const int grp = (blockIdx.x * 256 + threadIdx.x) / BP_GROUP;
+	const bool on = grp < st.nOd;
+	const int blk = on ? st.od_blocks[grp] : 0;
+	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
+	Scalar qa[4], ta[3], cama[5], qb[4], tb[3], camb[5];
+	load_pose(g, a, qa, ta, cama);
+	load_pose(g, b, qb, tb, camb);
+	const Rot3 Ra = quat_to_rot(qa[0], qa[1], qa[2], qa[3]);
+	const Rot3 Rb = quat_to_rot(qb[0], qb[1], qb[2], qb[3]);
+	Scalar T[6][6];
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+#pragma unroll
+		for (int c = 0; c < 6; c++) T[r][c] = 0;
+	const int p1 = on ? st.prod_ptr[blk + 1] : 0;
+	for (int p = (on ? st.prod_ptr[blk] : 0) + gl; p < p1; p += BP_GROUP)
+	{
+		EdgeLin La, Lb; Scalar wa, wb, Xa[3], Xb[3]; int il, il2;
+		rec_jacobians(st.e_rec + REC * (size_t)st.prod_ea[p], Ra, cama, La, wa, il, Xa);
+		rec_jacobians(st.e_rec + REC * (size_t)st.prod_eb[p], Rb, camb, Lb, wb, il2, Xb);
+		const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+		Scalar inv[6];
+#pragma unroll
+		for (int k = 0; k < 6; k++) inv[k] = ls[k];
+		// S = wa wb JL_a inv JL_b^T  (measurement x measurement)
+		Scalar M1[3][3], S[3][3];
+#pragma unroll
+		for (int m = 0; m < 3; m++)
+#pragma unroll
+			for (int k = 0; k < 3; k++)
+				M1[m][k] = La.JL[m][0] * inv[sym3_idx(0, k)] + La.JL[m][1] * inv[sym3_idx(1, k)] + La.JL[m][2] * inv[sym3_idx(2, k)];
+		const Scalar ww = wa * wb;
+#pragma unroll
+		for (int m = 0; m < 3; m++)
+#pragma unroll
+			for (int n = 0; n < 3; n++)
+				S[m][n] = ww * (M1[m][0] * Lb.JL[n][0] + M1[m][1] * Lb.JL[n][1] + M1[m][2] * Lb.JL[n][2]);
+		// T += JP_a^T (S JP_b)
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+		{
+			const Scalar u0 = S[0][0] * Lb.JP[0][c] + S[0][1] * Lb.JP[1][c] + S[0][2] * Lb.JP[2][c];
+			const Scalar u1 = S[1][0] * Lb.JP[0][c] + S[1][1] * Lb.JP[1][c] + S[1][2] * Lb.JP[2][c];
+			const Scalar u2 = S[2][0] * Lb.JP[0][c] + S[2][1] * Lb.JP[1][c] + S[2][2] * Lb.JP[2][c];
+#pragma unroll
+			for (int r = 0; r < 6; r++) T[r][c] += La.JP[0][r] * u0 + La.JP[1][r] * u1 + La.JP[2][r] * u2;
+		}
+	}
+	// reduce over the 16 lanes of the group
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+		{
+			Scalar v = T[r][c];
+			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+			T[r][c] = v;
+		}
+	if (!on) return;
+	Scalar* dst = sys.hsc + 36 * (size_t)blk;
+	if (a != b)
+	{
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -T[r][c];
+	}
+	else if (gl == 0)
+	{
+		// duplicate observations of one pose by one landmark: symmetric update of the diagonal block
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+#pragma unroll
+			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= T[r][c] + T[c][r];
+	}
+}
+
+void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
+{
+	if (st.nWaves > 0)
+	{
+		const int grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
+		if (mode == 0) hipLaunchKernelGGL(lm_pass_kernel<0>, dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
+		else hipLaunchKernelGGL(lm_pass_kernel<1>, dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
+	}
+	if (st.nBig > 0)
+	{
+		if (mode == 0) hipLaunchKernelGGL(big_lm_pass_kernel<0>, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+		else hipLaunchKernelGGL(big_lm_pass_kernel<1>, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+	}
+	if (g.Pf > 0)
+	{
+		if (mode == 0) hipLaunchKernelGGL(pose_pass_kernel<0>, dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
+		else hipLaunchKernelGGL(pose_pass_kernel<1>, dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
+	}
+	if (mode == 1 && st.nOd > 0)
+		hipLaunchKernelGGL(block_pass_kernel, dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // max diagonal of Hpp (diagonal blocks of hsc after an assemble pass).  Ref: maxDiagonalKernel :877-904.
 // ---------------------------------------------------------------------------------------------------

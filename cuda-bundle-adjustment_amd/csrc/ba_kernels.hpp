@@ -49,6 +49,14 @@ struct DeviceStructure
 	long long* lm_pair_base = nullptr; // [Lf] offset of a landmark's pairs in pair_blk
 	int* lm_nfree = nullptr;           // [Lf] number of edges of the landmark whose pose is free
 	int *adj_ptr = nullptr, *adj_blk = nullptr, *adj_col = nullptr;  // adj_blk bit 31 = use transposed
+	// destination-major (atomic-free) Schur assembly
+	int* hsc_blkrow = nullptr;         // [nblk] block row of every block
+	int nOd = 0;                       // blocks that receive at least one off-diagonal (or duplicate-pose) product
+	int* od_blocks = nullptr;          // [nOd] their ids, largest product count first
+	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
+	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)
+	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
+	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo}
 };
 
 struct DeviceSystem
@@ -79,6 +87,10 @@ void launch_residual_chi2(const DeviceGraph& g, Scalar* slots, Scalar* per_edge,
 
 // mode 0: assemble only (Hpp -> diagonal blocks of hsc, bp, Hll/bl -> lm_sys, max diagonal of Hll)
 // mode 1: full linearise + Schur reduction with damping lambda (hsc, bsc, bp, inv(Hll+lambda)/bl -> lm_sys)
+// launch_linearize: landmark-major kernel with fp64 atomics on the pose side (first design, kept for A/B runs)
+// launch_linearize_dm: destination-major, atomic-free and bitwise reproducible (default):
+//   landmark pass (Hll/bl, inverse, per-edge record) -> pose pass (diagonal blocks, bp, bsc) -> block pass (off-diagonal blocks)
+void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s);
 void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s);
 
 // max over the diagonal of the diagonal blocks of hsc (Hpp after an assemble pass) folded into sys.maxdiag

@@ -87,6 +87,7 @@ struct cuba_hip_solver
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 32;
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
+	bool schurAtomic = false;    // true: first-generation landmark-major Schur kernel with fp64 atomics (A/B runs)
 	bool profile = false;
 
 	// host copy of the problem (solver order) and of the sort permutation
@@ -108,6 +109,8 @@ struct cuba_hip_solver
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters;
 	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc;
+	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
+	DevBuf<Scalar> d_erec;
 	std::vector<int> h_rowptr, h_colind;
 	Scalar* h_pinned = nullptr;   // 4*NSLOT doubles + small ints
 
@@ -307,6 +310,39 @@ struct cuba_hip_solver
 			for (int i = 0; i < Pf; i++)
 				for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) { adjBlk[cur[i]] = k; adjCol[cur[i]] = h_colind[k]; cur[i]++; }
 		}
+		// destination-major product lists: for every block the (edge of row pose, edge of column pose) pairs of all
+		// landmarks seen by both poses, in landmark order (fixed summation order => reproducible results)
+		std::vector<int> blkRow(nblk), prodPtr(nblk + 1, 0), prodEa((size_t)npairs), prodEb((size_t)npairs), odBlocks;
+		for (int i = 0; i < Pf; i++)
+			for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) blkRow[k] = i;
+		for (long long i = 0; i < npairs; i++) prodPtr[(pairBlk[i] & 0x3fffffff) + 1]++;
+		for (int k = 0; k < nblk; k++) prodPtr[k + 1] += prodPtr[k];
+		{
+			std::vector<int> cur(prodPtr.begin(), prodPtr.end() - 1);
+			for (int l = 0; l < Lf; l++)
+			{
+				const int b = h_lmptr[l], n = nfree[l];
+				long long idx = pairBase[l];
+				for (int a = 0; a < n; a++)
+					for (int c = a + 1; c < n; c++, idx++)
+					{
+						const int k = pairBlk[idx] & 0x3fffffff;
+						prodEa[cur[k]] = b + a; prodEb[cur[k]] = b + c; cur[k]++;
+					}
+			}
+			for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k);
+			std::stable_sort(odBlocks.begin(), odBlocks.end(), [&](int x, int y) {
+				return prodPtr[x + 1] - prodPtr[x] > prodPtr[y + 1] - prodPtr[y]; });
+		}
+		// per free pose: its edges (sorted-edge ids, ascending)
+		std::vector<int> pePtr(Pf + 1, 0), peEdge;
+		for (int i = 0; i < E; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
+		for (int i = 0; i < Pf; i++) pePtr[i + 1] += pePtr[i];
+		peEdge.resize(pePtr[Pf]);
+		{
+			std::vector<int> cur(pePtr.begin(), pePtr.end() - 1);
+			for (int i = 0; i < E; i++) if (h_epose[i] < Pf) peEdge[cur[h_epose[i]]++] = i;
+		}
 		// wave work list: whole landmarks, at most 64 edges per wave; larger landmarks get a workgroup each
 		std::vector<int> waveLm, bigLm;
 		std::vector<long long> bigOfs;
@@ -336,6 +372,9 @@ struct cuba_hip_solver
 		d_rowptr.upload(h_rowptr, stream); d_colind.upload(h_colind, stream);
 		d_pairBlk.upload(pairBlk, stream); d_lmPairBase.upload(pairBase, stream); d_lmNfree.upload(nfree, stream);
 		d_adjPtr.upload(adjPtr, stream); d_adjBlk.upload(adjBlk, stream); d_adjCol.upload(adjCol, stream);
+		d_blkrow.upload(blkRow, stream); d_odBlocks.upload(odBlocks, stream); d_prodPtr.upload(prodPtr, stream);
+		d_prodEa.upload(prodEa, stream); d_prodEb.upload(prodEb, stream); d_pePtr.upload(pePtr, stream); d_peEdge.upload(peEdge, stream);
+		d_erec.resize((size_t)8 * E);
 
 		d_red.resize((size_t)36 * nblk + (size_t)12 * Pf);
 		d_lmSys.resize((size_t)9 * Lf); d_xp.resize((size_t)6 * Pf); d_xl.resize((size_t)3 * Lf);
@@ -359,6 +398,9 @@ struct cuba_hip_solver
 		st.nblk = nblk; st.hsc_rowptr = d_rowptr.data(); st.hsc_colind = d_colind.data();
 		st.pair_blk = d_pairBlk.data(); st.lm_pair_base = d_lmPairBase.data(); st.lm_nfree = d_lmNfree.data();
 		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
+		st.hsc_blkrow = d_blkrow.data(); st.nOd = (int)odBlocks.size(); st.od_blocks = d_odBlocks.data();
+		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
+		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
 		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = d_slots.data();
@@ -391,13 +433,19 @@ struct cuba_hip_solver
 		return readSlots(0);
 	}
 
+	void linearize(int mode, double lam)
+	{
+		if (schurAtomic) launch_linearize(g, st, sys, mode, lam, stream);
+		else launch_linearize_dm(g, st, sys, mode, lam, stream);
+	}
+
 	double maxDiagonal()
 	{
 		need();
 		StageTimer tm(this, 3);
 		d_red.zero(stream);
 		d_maxdiag.zero(stream);
-		launch_linearize(g, st, sys, 0, 0.0, stream);
+		linearize(0, 0.0);
 		launch_pose_maxdiag(g, st, sys, stream);
 		unsigned long long bits = 0;
 		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8, hipMemcpyDeviceToHost, stream));
@@ -412,7 +460,7 @@ struct cuba_hip_solver
 		need();
 		StageTimer tm(this, 4);
 		d_red.zero(stream);
-		launch_linearize(g, st, sys, 1, lambda, stream);
+		linearize(1, lambda);
 	}
 
 	bool solveReduced()
@@ -583,10 +631,10 @@ struct cuba_hip_solver
 		const double lam = lambda > 0 ? lambda : 1.0;
 		msOut[0] = timeit([&] { launch_residual_chi2(g, d_slots.data(), nullptr, stream); });
 		d_red.zero(stream);
-		msOut[1] = timeit([&] { launch_linearize(g, st, sys, 1, lam, stream); });
+		msOut[1] = timeit([&] { linearize(1, lam); });
 		// a consistent reduced system for the PCG kernels
 		d_red.zero(stream);
-		launch_linearize(g, st, sys, 1, lam, stream);
+		linearize(1, lam);
 		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
 		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
@@ -706,6 +754,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
+		else if (k == "schur_atomic") s->schurAtomic = value != 0;
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
 	});
