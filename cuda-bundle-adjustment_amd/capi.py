@@ -22,7 +22,7 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _u8p = C.POINTER(C.c_uint8)
 
-ARRAY_IDS = dict(bp=0, bsc=1, xp=2, xl=3, lm_sys=4, hsc=5)
+ARRAY_IDS = dict(bp=0, bsc=1, xp=2, xl=3, lm_sys=4, hsc=5, state=6)
 PROFILE_KEYS = (  # same strings as CudaBlockSolver::getTimeProfile (src/cuda_bundle_adjustment.cpp:545-562)
     "0: Initialize Optimizer", "1: Build Structure", "2: Compute Error", "3: Build System",
     "4: Schur Complement", "5: Symbolic Decomposition", "6: Numerical Decomposition", "7: Update Solution")
@@ -82,6 +82,11 @@ def load_library():
         "cuba_hip_get_hsc_structure": [H, _ip, _ip, C.POINTER(C.c_int)],
         "cuba_hip_get_array": [H, C.c_int, _dp, C.POINTER(C.c_size_t)],
         "cuba_hip_time_kernels": [H, C.c_int, _dp],
+        "cuba_hip_set_partition": [H, C.c_int, C.c_int],
+        "cuba_hip_assemble": [H],
+        "cuba_hip_max_diagonal_parts": [H, _dp, _dp],
+        "cuba_hip_compute_scale_parts": [H, C.c_double, _dp, _dp],
+        "cuba_hip_device_pointer": [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "cuba_hip_reduction_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     }
     for name, args in sig.items():
@@ -246,6 +251,27 @@ class HipSolver:
         self._ck(self.lib.cuba_hip_time_kernels(self.h, int(reps), _d(out)))
         return dict(zip(("residual_chi2", "linearize_schur", "pcg_spmv", "pcg_update", "back_substitute", "pcg_precond",
                          "coarse_setup"), out.tolist()))
+
+    # ---- landmark-partitioned multi-GPU hooks ---------------------------------------------------
+    def set_partition(self, lm_begin, lm_end):
+        self._ck(self.lib.cuba_hip_set_partition(self.h, int(lm_begin), int(lm_end)))
+
+    def assemble(self): self._ck(self.lib.cuba_hip_assemble(self.h))
+
+    def max_diagonal_parts(self):
+        a, b = C.c_double(), C.c_double()
+        self._ck(self.lib.cuba_hip_max_diagonal_parts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def compute_scale_parts(self, lam):
+        a, b = C.c_double(), C.c_double()
+        self._ck(self.lib.cuba_hip_compute_scale_parts(self.h, float(lam), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def device_pointer(self, name):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.cuba_hip_device_pointer(self.h, ARRAY_IDS[name], C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def reduction_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

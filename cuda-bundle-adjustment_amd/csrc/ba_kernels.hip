@@ -112,7 +112,7 @@ __device__ __forceinline__ void linearize_edge(const DeviceGraph& g, int e, Lane
 __global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scalar* slots, Scalar* per_edge)
 {
 	Scalar acc = 0;
-	for (int e = blockIdx.x * 256 + threadIdx.x; e < g.E; e += gridDim.x * 256)
+	for (int e = g.e_begin + blockIdx.x * 256 + threadIdx.x; e < g.e_end; e += gridDim.x * 256)
 	{
 		const int pe = g.e_pose[e];
 		const bool stereo = (pe & STEREO_BIT) != 0;
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scala
 
 void launch_residual_chi2(const DeviceGraph& g, Scalar* slots, Scalar* per_edge, hipStream_t st)
 {
-	if (g.E <= 0) return;
-	const int grid = min((g.E + 255) / 256, 2048);
+	const int n = g.e_end - g.e_begin;
+	if (n <= 0) return;
+	const int grid = min((n + 255) / 256, 2048);
 	hipLaunchKernelGGL(residual_chi2_kernel, dim3(grid), dim3(256), 0, st, g, slots, per_edge);
 }
 
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	if (MODE == 0)
 	{
 		m = wave_max(m);
-		if (lane == 0) atomic_max_nonneg(sys.maxdiag, m);
+		if (lane == 0) atomic_max_nonneg(sys.maxdiag + (wave & 63), m);
 	}
 }
 
@@ -1341,21 +1342,32 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 		F[r][kk] = (kk < bk && i0 + r < n) ? src[(size_t)(p0 + kk) * n + i0 + r] : Scalar(0);
 	}
 	__syncthreads();
-	// in-place scalar Gauss-Jordan inverse of the pivot block (every workgroup repeats it: bk^3 flops)
+	// in-place scalar Gauss-Jordan inverse of the pivot block (every workgroup repeats it: bk^3 flops);
+	// all elements are updated at once from values read before the barrier: two barriers per pivot
 	for (int p = 0; p < bk; p++)
 	{
-		const Scalar d = 1 / D[p][p];
-		__syncthreads();
-		if (tid < bk && tid != p) D[p][tid] *= d;
-		__syncthreads();
-		for (int t = tid; t < bk * bk; t += 256)
+		Scalar nv[3];
+#pragma unroll
+		for (int u = 0; u < 3; u++)
 		{
-			const int i = t % bk, j = t / bk;
-			if (i != p && j != p) D[i][j] -= D[i][p] * D[p][j];
+			const int t = tid + 256 * u;
+			const int i = t % GJ_B, j = t / GJ_B;
+			nv[u] = 0;
+			if (t < GJ_B * GJ_B && i < bk && j < bk)
+			{
+				const Scalar d = 1 / D[p][p];
+				const Scalar mip = D[i][p], mpj = D[p][j];
+				nv[u] = (i == p) ? (j == p ? d : mpj * d) : (j == p ? -mip * d : D[i][j] - mip * mpj * d);
+			}
 		}
 		__syncthreads();
-		if (tid < bk && tid != p) D[tid][p] = -D[tid][p] * d;
-		if (tid == 0) D[p][p] = d;
+#pragma unroll
+		for (int u = 0; u < 3; u++)
+		{
+			const int t = tid + 256 * u;
+			const int i = t % GJ_B, j = t / GJ_B;
+			if (t < GJ_B * GJ_B && i < bk && j < bk) D[i][j] = nv[u];
+		}
 		__syncthreads();
 	}
 	// R = D * Apj

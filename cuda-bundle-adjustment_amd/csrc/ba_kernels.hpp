@@ -28,6 +28,7 @@ constexpr int STEREO_BIT = 0x40000000;
 struct DeviceGraph
 {
 	int Pt = 0, Pf = 0, Lt = 0, Lf = 0, E = 0;
+	int e_begin = 0, e_end = 0;        // sorted-edge range this handle evaluates (whole graph unless landmark-partitioned)
 	Scalar *q = nullptr, *t = nullptr, *cam = nullptr, *Xw = nullptr;
 	int *e_pose = nullptr, *e_lm = nullptr;
 	Scalar *e_mu = nullptr, *e_mv = nullptr, *e_mr = nullptr, *e_w = nullptr;

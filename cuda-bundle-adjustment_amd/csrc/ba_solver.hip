@@ -93,6 +93,7 @@ struct cuba_hip_solver
 	// host copy of the problem (solver order) and of the sort permutation
 	int Pt = 0, Pf = 0, Lt = 0, Lf = 0, E = 0;
 	bool haveGraph = false, haveStructure = false;
+	int partLo = 0, partHi = -1; // landmark range [partLo, partHi) this handle evaluates (-1 = all): multi-GPU partition
 	std::vector<int> perm;       // sorted position -> caller edge index
 	std::vector<int> h_lmptr, h_epose;   // sorted, e_pose without the stereo bit
 	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
@@ -201,7 +202,7 @@ struct cuba_hip_solver
 		d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream);
 		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
 		d_perEdge.resize(E);
-		d_slots.resize(4 * NSLOT); d_maxdiag.resize(1); d_fail.resize(1); d_iters.resize(1);
+		d_slots.resize(4 * NSLOT); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1);
 		d_fail.zero(stream); d_iters.zero(stream);
 		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
 		sync();   // host staging vectors go out of scope
@@ -213,6 +214,8 @@ struct cuba_hip_solver
 		g.e_pose = d_epose.data(); g.e_lm = d_elm.data(); g.lm_ptr = d_lmptr.data();
 		g.e_mu = d_mu.data(); g.e_mv = d_mv.data(); g.e_mr = d_mr.data(); g.e_w = d_w.data();
 		g.rk[0] = rk[0]; g.rk[1] = rk[1];
+		g.e_begin = 0; g.e_end = E;
+		partLo = 0; partHi = -1;
 		haveGraph = true;
 		lambda = 0;
 		for (double& v : prof) v = 0;
@@ -310,16 +313,21 @@ struct cuba_hip_solver
 			for (int i = 0; i < Pf; i++)
 				for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) { adjBlk[cur[i]] = k; adjCol[cur[i]] = h_colind[k]; cur[i]++; }
 		}
+		// landmark partition (multi-GPU): the PATTERN above is global, everything below covers [lo, hi) only
+		const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
+		g.e_begin = h_lmptr[lo]; g.e_end = h_lmptr[hi];
 		// destination-major product lists: for every block the (edge of row pose, edge of column pose) pairs of all
 		// landmarks seen by both poses, in landmark order (fixed summation order => reproducible results)
 		std::vector<int> blkRow(nblk), prodPtr(nblk + 1, 0), prodEa((size_t)npairs), prodEb((size_t)npairs), odBlocks;
 		for (int i = 0; i < Pf; i++)
 			for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) blkRow[k] = i;
-		for (long long i = 0; i < npairs; i++) prodPtr[(pairBlk[i] & 0x3fffffff) + 1]++;
+		for (int l = std::min(lo, Lf); l < std::min(hi, Lf); l++)
+			for (long long i = pairBase[l], iend = pairBase[l] + (long long)nfree[l] * (nfree[l] - 1) / 2; i < iend; i++)
+				prodPtr[(pairBlk[i] & 0x3fffffff) + 1]++;
 		for (int k = 0; k < nblk; k++) prodPtr[k + 1] += prodPtr[k];
 		{
 			std::vector<int> cur(prodPtr.begin(), prodPtr.end() - 1);
-			for (int l = 0; l < Lf; l++)
+			for (int l = std::min(lo, Lf); l < std::min(hi, Lf); l++)
 			{
 				const int b = h_lmptr[l], n = nfree[l];
 				long long idx = pairBase[l];
@@ -336,12 +344,12 @@ struct cuba_hip_solver
 		}
 		// per free pose: its edges (sorted-edge ids, ascending)
 		std::vector<int> pePtr(Pf + 1, 0), peEdge;
-		for (int i = 0; i < E; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
+		for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
 		for (int i = 0; i < Pf; i++) pePtr[i + 1] += pePtr[i];
 		peEdge.resize(pePtr[Pf]);
 		{
 			std::vector<int> cur(pePtr.begin(), pePtr.end() - 1);
-			for (int i = 0; i < E; i++) if (h_epose[i] < Pf) peEdge[cur[h_epose[i]]++] = i;
+			for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) peEdge[cur[h_epose[i]]++] = i;
 		}
 		// wave work list: whole landmarks, at most 64 edges per wave; larger landmarks get a workgroup each
 		std::vector<int> waveLm, bigLm;
@@ -350,7 +358,7 @@ struct cuba_hip_solver
 		{
 			int start = -1, cnt = 0;
 			auto flush = [&](int end) { if (start >= 0 && cnt > 0) { waveLm.push_back(start); waveLm.push_back(end); } start = -1; cnt = 0; };
-			for (int l = 0; l < Lt; l++)
+			for (int l = lo; l < hi; l++)
 			{
 				const int n = h_lmptr[l + 1] - h_lmptr[l];
 				if (n > WAVE)
@@ -364,7 +372,7 @@ struct cuba_hip_solver
 				if (start < 0) start = l;
 				cnt += n;
 			}
-			flush(Lt);
+			flush(hi);
 		}
 
 		d_waveLm.upload(waveLm, stream); d_bigLm.upload(bigLm, stream); d_bigOfs.upload(bigOfs, stream);
@@ -439,6 +447,47 @@ struct cuba_hip_solver
 		else launch_linearize_dm(g, st, sys, mode, lam, stream);
 	}
 
+	// assemble only: Hpp -> diagonal blocks, bp, raw Hll/bl, landmark part of the max diagonal
+	void assemble()
+	{
+		need();
+		StageTimer tm(this, 3);
+		d_red.zero(stream);
+		d_maxdiag.zero(stream);
+		linearize(0, 0.0);
+	}
+
+	// max diagonal of the (possibly externally reduced) Hpp and of the local Hll
+	void maxDiagonalParts(double* posePart, double* lmPart)
+	{
+		need();
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
+		sync();
+		double v = 0;
+		for (int i = 0; i < 64; i++) v = std::max(v, h_pinned[i]);
+		*lmPart = v;
+		d_maxdiag.zero(stream);
+		launch_pose_maxdiag(g, st, sys, stream);
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
+		sync();
+		v = 0;
+		for (int i = 0; i < 64; i++) v = std::max(v, h_pinned[i]);
+		*posePart = v;
+	}
+
+	void scaleParts(double lam, double* posePart, double* lmPart)
+	{
+		need();
+		HIP_TRY(hipMemsetAsync(d_slots.data() + 2 * NSLOT, 0, sizeof(Scalar) * 2 * NSLOT, stream));
+		launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
+		launch_landmark_scale(g, sys, lam, d_slots.data() + 2 * NSLOT, stream);
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data() + 2 * NSLOT, sizeof(Scalar) * 2 * NSLOT, hipMemcpyDeviceToHost, stream));
+		sync();
+		double a = 0, b = 0;
+		for (int i = 0; i < NSLOT; i++) { b += h_pinned[i]; a += h_pinned[NSLOT + i]; }
+		*posePart = a; *lmPart = b;
+	}
+
 	double maxDiagonal()
 	{
 		need();
@@ -447,11 +496,10 @@ struct cuba_hip_solver
 		d_maxdiag.zero(stream);
 		linearize(0, 0.0);
 		launch_pose_maxdiag(g, st, sys, stream);
-		unsigned long long bits = 0;
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
-		std::memcpy(&bits, h_pinned, 8);
-		double v; std::memcpy(&v, &bits, 8);
+		double v = 0;   // bit patterns of non-negative doubles are doubles again
+		for (int i = 0; i < 64; i++) v = std::max(v, h_pinned[i]);
 		return v;
 	}
 
@@ -902,6 +950,49 @@ int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUB
 	return guarded(s, [&] {
 		if (reps <= 0 || !ms_per_launch) throw ArgError{ "bad arguments" };
 		s->timeKernels(reps, ms_per_launch);
+	});
+}
+
+int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_end)
+{
+	return guarded(s, [&] {
+		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		if (landmark_begin < 0 || landmark_end > s->Lt || landmark_begin > landmark_end) throw ArgError{ "bad landmark range" };
+		s->partLo = landmark_begin; s->partHi = landmark_end;
+		s->haveStructure = false;
+	});
+}
+
+int cuba_hip_assemble(cuba_hip_solver* s) { return guarded(s, [&] { s->assemble(); }); }
+
+int cuba_hip_max_diagonal_parts(cuba_hip_solver* s, double* pose_part, double* landmark_part)
+{
+	return guarded(s, [&] { if (!pose_part || !landmark_part) throw ArgError{ "null output" }; s->maxDiagonalParts(pose_part, landmark_part); });
+}
+
+int cuba_hip_compute_scale_parts(cuba_hip_solver* s, double lambda, double* pose_part, double* landmark_part)
+{
+	return guarded(s, [&] { if (!pose_part || !landmark_part) throw ArgError{ "null output" }; s->scaleParts(lambda, pose_part, landmark_part); });
+}
+
+int cuba_hip_device_pointer(cuba_hip_solver* s, int which, void** device_ptr, size_t* count)
+{
+	return guarded(s, [&] {
+		s->need();
+		Scalar* p = nullptr; size_t n = 0;
+		switch (which)
+		{
+		case CUBA_HIP_ARRAY_BP: p = s->sys.bp; n = (size_t)6 * s->Pf; break;
+		case CUBA_HIP_ARRAY_BSC: p = s->sys.bsc; n = (size_t)6 * s->Pf; break;
+		case CUBA_HIP_ARRAY_XP: p = s->sys.xp; n = (size_t)6 * s->Pf; break;
+		case CUBA_HIP_ARRAY_XL: p = s->sys.xl; n = (size_t)3 * s->Lf; break;
+		case CUBA_HIP_ARRAY_LM_SYS: p = s->sys.lm_sys; n = (size_t)9 * s->Lf; break;
+		case CUBA_HIP_ARRAY_HSC: p = s->sys.hsc; n = (size_t)36 * s->st.nblk; break;
+		case CUBA_HIP_ARRAY_STATE: p = s->d_state.data(); n = s->d_state.size(); break;
+		default: throw ArgError{ "unknown array id" };
+		}
+		if (device_ptr) *device_ptr = p;
+		if (count) *count = n;
 	});
 }
 

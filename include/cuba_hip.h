@@ -60,8 +60,9 @@ enum
 	CUBA_HIP_ARRAY_LM_SYS = 4,  /* 9*Lf   per landmark: 6 unique entries (00,01,02,11,12,22) of Hll
 	                                       (after cuba_hip_max_diagonal) or of inv(Hll+lambda I)
 	                                       (after cuba_hip_schur), then bl (3)                   */
-	CUBA_HIP_ARRAY_HSC = 5      /* 36*nblk upper-triangular BSR values of Hsc (col-major 6x6);
+	CUBA_HIP_ARRAY_HSC = 5,     /* 36*nblk upper-triangular BSR values of Hsc (col-major 6x6);
 	                                       after cuba_hip_max_diagonal the diagonal blocks hold Hpp */
+	CUBA_HIP_ARRAY_STATE = 6    /* 7*Pt+3*Lt  [q | t | Xw] estimates (cuba_hip_device_pointer only)          */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -186,6 +187,22 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
    Clobbers the increments and the reduced system (not the estimates). */
 enum { CUBA_HIP_TIMED_KERNELS = 7 };
 int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUBA_HIP_TIMED_KERNELS]);
+
+/* ---- landmark-partitioned multi-GPU operation (no counterpart in the single-GPU reference) ----------------
+   Every rank uploads the WHOLE graph (so all ranks share one Hsc pattern and one pose ordering) and then
+   restricts itself to the landmarks [landmark_begin, landmark_end) of the solver order: residuals, Schur
+   contributions, back-substitution and landmark updates are evaluated for those landmarks only.
+   Per trial the driver sums cuba_hip_reduction_buffer() over the ranks between cuba_hip_schur and
+   cuba_hip_solve_reduced; chi2 and the landmark parts of max-diagonal / scale are reduced as scalars. */
+int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_end);
+/* First half of cuba_hip_max_diagonal: accumulate Hpp (diagonal blocks of the reduction buffer), bp, Hll. */
+int cuba_hip_assemble(cuba_hip_solver* s);
+/* Second half: max diag of the (externally summed) Hpp and of this rank's Hll. */
+int cuba_hip_max_diagonal_parts(cuba_hip_solver* s, double* pose_part, double* landmark_part);
+/* sum x (lambda x + b) split into the replicated pose part and this rank's landmark part. */
+int cuba_hip_compute_scale_parts(cuba_hip_solver* s, double lambda, double* pose_part, double* landmark_part);
+/* Device address of an internal array (ids as for cuba_hip_get_array) for zero-copy collectives. */
+int cuba_hip_device_pointer(cuba_hip_solver* s, int which, void** device_ptr, size_t* count);
 
 /* Device address + length (in doubles) of the contiguous buffer [Hsc values | bsc | bp] that a
    landmark-partitioned multi-GPU driver must sum across ranks between cuba_hip_schur and

@@ -888,6 +888,16 @@ void orc_set_lambda(void* h, double lam) { ((Problem*)h)->setLambda(lam); }
 void orc_restore_diagonal(void* h) { ((Problem*)h)->restoreDiagonal(); }
 int orc_solve(void* h) { return ((Problem*)h)->solve() ? 1 : 0; }
 void orc_schur(void* h) { ((Problem*)h)->schur(); }
+// split solve (for the landmark-partitioned multi-process driver test): reduced system only / back-substitution only
+int orc_solve_reduced(void* h)
+{
+	Problem* p = (Problem*)h;
+	if (p->Pf == 0) return 1;
+	if (!p->chol.factorize(p->hscRowPtr.data(), p->hscColInd.data(), p->hscVal.data())) return 0;
+	p->chol.solve(p->bsc.data(), p->xp.data());
+	return 1;
+}
+void orc_back_substitute(void* h) { ((Problem*)h)->backSubstitute(); }
 void orc_update(void* h) { ((Problem*)h)->update(); }
 double orc_compute_scale(void* h, double lam) { return ((Problem*)h)->computeScale(lam); }
 void orc_push(void* h) { ((Problem*)h)->push(); }
@@ -930,6 +940,21 @@ long orc_get_array(void* h, int which, double* out)
 	default: return -1;
 	}
 	if (out) std::memcpy(out, v->data(), v->size() * 8);
+	return (long)v->size();
+}
+
+// overwrite an internal array (same ids as orc_get_array, plus 11 = Hsc values) -- used to inject all-reduced sums
+long orc_set_array(void* h, int which, const double* in)
+{
+	Problem* p = (Problem*)h;
+	std::vector<double>* v = nullptr;
+	switch (which)
+	{
+	case 0: v = &p->Hpp; break; case 1: v = &p->bp; break; case 2: v = &p->Hll; break; case 3: v = &p->bl; break;
+	case 5: v = &p->bsc; break; case 6: v = &p->xp; break; case 7: v = &p->xl; break; case 11: v = &p->hscVal; break;
+	default: return -1;
+	}
+	std::memcpy(v->data(), in, v->size() * 8);
 	return (long)v->size();
 }
 

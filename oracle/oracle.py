@@ -42,6 +42,12 @@ def _load():
         getattr(lib, name).restype = None
     lib.orc_solve.argtypes = [C.c_void_p]
     lib.orc_solve.restype = C.c_int
+    lib.orc_solve_reduced.argtypes = [C.c_void_p]
+    lib.orc_solve_reduced.restype = C.c_int
+    lib.orc_back_substitute.argtypes = [C.c_void_p]
+    lib.orc_back_substitute.restype = None
+    lib.orc_set_array.argtypes = [C.c_void_p, C.c_int, _dp]
+    lib.orc_set_array.restype = C.c_long
     lib.orc_optimize.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     lib.orc_optimize.restype = C.c_int
     lib.orc_chi_squares.argtypes = [C.c_void_p, _dp]
@@ -176,6 +182,22 @@ class OracleSolver:
     def restore_diagonal(self): lib().orc_restore_diagonal(self.h)
     def solve(self): return bool(lib().orc_solve(self.h))
     def schur(self): lib().orc_schur(self.h)
+    def solve_reduced(self): return bool(lib().orc_solve_reduced(self.h))
+    def back_substitute(self): lib().orc_back_substitute(self.h)
+
+    def set_array(self, name, values):
+        ids = dict(self.ARR, hsc=11)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        n = lib().orc_set_array(self.h, ids[name], _d(v))
+        assert n == v.size, (name, n, v.size)
+
+    def hsc_values_raw(self):
+        """Hsc values exactly as stored (col-major 6x6 blocks, flattened)."""
+        nb = lib().orc_hsc_nblocks(self.h)
+        rp, ci = np.zeros(self.fp.Pf + 1, dtype=np.int32), np.zeros(nb, dtype=np.int32)
+        v = np.zeros(nb * 36)
+        lib().orc_get_hsc(self.h, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), _d(v))
+        return rp, ci, v
     def update(self): lib().orc_update(self.h)
     def compute_scale(self, lam): return lib().orc_compute_scale(self.h, float(lam))
     def push(self): lib().orc_push(self.h)
