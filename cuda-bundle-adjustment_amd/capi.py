@@ -50,6 +50,14 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise CubaHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    if os.environ.get("CUBA_HIP_NO_TORCH") != "1":
+        # PyTorch wheels bundle their own libamdhip64; whichever HIP runtime is loaded first serves the whole
+        # process.  Loading torch's first keeps torch.cuda (streams, torch.distributed/RCCL) usable next to this
+        # library; the C ABI itself does not depend on torch.
+        try:
+            import torch  # noqa: F401
+        except Exception:      # pragma: no cover
+            pass
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     sig = {
