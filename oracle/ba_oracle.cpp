@@ -5,13 +5,18 @@
 // __graft_entry__.smoke(), and bench.py's cpu_baseline leg).  Nothing under
 // cuda-bundle-adjustment_amd/ may include, link or call this file.
 //
-// PARITY UNPINNED: the reference ships no unit tests / golden vectors for this path; its only known
-// answers (README.md:141-150,176-191 chi2 tables) need samples/ba_input.7z, which is absent from the
-// checkout.  The reduced-system solve of the reference is NVIDIA cuSOLVER sparse Cholesky
-// (src/cuda_linear_solver.cpp:147-232, closed source); it is restated here as an exact sparse block
-// Cholesky (min-degree ordering) -- any exact SPD solve is equivalent up to rounding.  Independent
-// pins live in tests/: finite-difference Jacobians, mpmath exp-map, dense full-system solves, and
-// oracle/_ref (the reference's own kernels compiled through a name shim, GPU box only).
+// PARITY PIN: the reference ships no unit tests / golden vectors for this path, and its only known answers
+// (README.md:141-150,176-191 chi2 tables) need samples/ba_input.7z, which is absent from the checkout.  The pin
+// is therefore "outputs of the reference itself run here": oracle/_ref = the reference's own device layer
+// (src/cuda_block_solver.cu compiled in place through a CUDA->HIP name shim, oracle/ref_build/) runs one LM
+// trial on the MI355X and tests/test_ref_kernels.py requires this file to reproduce every stage output
+// (chi2, Hpp/bp/Hll/bl, max diagonal, bsc, Hsc, Hll^-1, xl, scale, updated estimates, per-edge chi2).
+// Two parts of the path remain UNPINNED against the reference because they cannot run here:
+//   * the reduced-system solve -- NVIDIA cuSOLVER sparse Cholesky (src/cuda_linear_solver.cpp:147-232, closed
+//     source), restated as an exact sparse block Cholesky with min-degree ordering (any exact SPD solve is
+//     equivalent up to rounding; pinned against numpy dense solves instead);
+//   * the host LM controller (src/cuda_bundle_adjustment.cpp:793-857, needs Eigen) -- restated line by line.
+// Further independent pins in tests/: finite-difference Jacobians, mpmath exp-map, dense full-system solves.
 //
 // Every function cites the reference lines (under /root/reference/) it follows.
 // Conventions: pose = unit quaternion (x,y,z,w) + t, world->camera;
