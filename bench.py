@@ -35,7 +35,8 @@ def algorithmic_bytes(fp, nblk, nc):
         "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
         "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
         "pcg_spmv": 288 * nblk + 4 * 48 * Pf,
-        "pcg_update": (288 + 6 * 48) * Pf if nc == 0 else 5 * 48 * Pf + 8 * Nc,
+        # two-level: fused update + restrict + preconditioner (one read of r, q, p, x, Minv, one of the coarse inverse)
+        "pcg_update": (288 + 6 * 48) * Pf if nc == 0 else (288 + 7 * 48) * Pf + 8 * Nc * Nc,
         "pcg_precond": 8 * Nc * Nc + 8 * Nc + (288 + 2 * 48) * Pf,
         "coarse_setup": 288 * nblk + 3 * 8 * Nc * Nc,          # read Hsc once, write Ac, read+write it once more for the inverse
         "back_substitute": edge_in + (24 + 72 + 24) * Lf + (96 + 48) * Pt,
@@ -127,7 +128,7 @@ def main():
         solver.set_state(q0, t0, X0)
         kt = solver.time_kernels(reps=20)
         nblk = c1["hsc_blocks"]
-        nc = 0 if kt["pcg_precond"] == 0 else (fp.Pf + max(16, (fp.Pf + 255) // 256) - 1) // max(16, (fp.Pf + 255) // 256)
+        nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + max(16, (fp.Pf + 255) // 256) - 1) // max(16, (fp.Pf + 255) // 256)
         alg = algorithmic_bytes(fp, nblk, nc)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
                     "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials, "coarse_setup": trials}

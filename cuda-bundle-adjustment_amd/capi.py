@@ -7,9 +7,11 @@ constructor raises.  The method names mirror CudaBlockSolver's stage methods
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -112,6 +114,17 @@ def _d(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
 
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # destroy device objects (streams, graphs, buffers) while the HIP runtime is still alive: handles that
+    # survive until interpreter teardown would be destroyed after the runtime's own static destructors
+    for s in list(_live):
+        s.close()
+
+
 class HipSolver:
     """One bundle-adjustment problem on one GPU, driven through the C ABI."""
 
@@ -127,6 +140,7 @@ class HipSolver:
         for k, v in options.items():
             self.set_option(k, v)
         self.fp = None
+        _live.add(self)
         for et, (kind, delta) in enumerate(robust):
             self.set_robust_kernel(et, kind, delta)
         if fp is not None:

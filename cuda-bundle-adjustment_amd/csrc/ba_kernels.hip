@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 #pragma unroll
 			for (int c = 0; c < 6; c++) z += Ai[c * 6 + r] * rr[c];
 			sys.r[6 * (size_t)i + r] = rr[r];
-			sys.z[6 * (size_t)i + r] = z;   // overwritten by pcg2_precond_kernel when the coarse level is on
+			sys.z[6 * (size_t)i + r] = z;   // overwritten by pcg2_fused_kernel when the coarse level is on
 			sys.xp[6 * (size_t)i + r] = 0;
 			sys.p0[6 * (size_t)i + r] = 0;
 			sys.p1[6 * (size_t)i + r] = 0;
@@ -1186,6 +1186,7 @@ __device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int m
 __global__ __launch_bounds__(256) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	k += *sys.kbase;
 	Scalar rzk;
 	if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
 	Scalar beta = 0;
@@ -1242,6 +1243,7 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(DeviceGraph g, DeviceStru
 __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	k += *sys.kbase;
 	Scalar rzk;
 	if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
 	const Scalar pqk = sum_slots(sys.pq + (size_t)k * NSLOT, lane);
@@ -1420,11 +1422,24 @@ void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, Device
 	sys.acinv = src;
 }
 
-// B1(k): [x += alpha p; r -= alpha q;]  rc = P^T r        (one 128-thread workgroup per aggregate)
-__global__ __launch_bounds__(128) void pcg2_restrict_kernel(DeviceGraph g, DeviceSystem sys, int k, int maxIter, Scalar tol2, int doUpdate)
+// Fused B(k) of the two-level PCG: [x += alpha p; r -= alpha q;]  rc = P^T r;  z = Minv r + P (Ac^-1 rc);
+// rz[kOut] += r.z.  One 512-thread workgroup per aggregate.  Every workgroup rebuilds the WHOLE restricted
+// residual rc (6*nc values) from r and q = A p itself -- 2 x 6Pf doubles from L2 per workgroup -- which is
+// cheaper than a kernel boundary (~1.5 us) plus a second launch; only the owner of an aggregate stores x, r, z.
+constexpr int PCG2_T = 512;
+
+__global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
-	__shared__ Scalar red[128];
-	const int lane = threadIdx.x & 63;
+	extern __shared__ __attribute__((aligned(16))) Scalar sm[];   // rcL[Nc] | part[8][6] | yc[6] | wsum[8] | rown[6*agg]
+	const int Nc = 6 * sys.nc;
+	Scalar* rcL = sm;
+	Scalar* part = sm + Nc;
+	Scalar* yc = part + 48;
+	Scalar* wsum = yc + 6;
+	Scalar* rown = wsum + 8;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int kb = *sys.kbase;
+	k += kb; kOut += kb;
 	Scalar alpha = 0;
 	if (doUpdate)
 	{
@@ -1439,94 +1454,106 @@ __global__ __launch_bounds__(128) void pcg2_restrict_kernel(DeviceGraph g, Devic
 		alpha = rzk / pqk;
 	}
 	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;
+	// the residual is double-buffered: other workgroups still read r_k of this aggregate while its owner stores r_{k+1}
+	const Scalar* rin = (k & 1) ? sys.r2 : sys.r;
+	Scalar* rout = (k & 1) ? sys.r : sys.r2;
 	const int I = blockIdx.x;
-	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
-	const int comp = threadIdx.x % 6;
-	Scalar acc = 0;
-	if (threadIdx.x < 126)
-		for (int i = i0 + threadIdx.x / 6; i < i1; i += 21)
-		{
-			const size_t idx = 6 * (size_t)i + comp;
-			Scalar r = sys.r[idx];
-			if (doUpdate)
-			{
-				sys.xp[idx] += alpha * p[idx];
-				r -= alpha * sys.ap[idx];
-				sys.r[idx] = r;
-			}
-			acc += r;
-		}
-	red[threadIdx.x] = acc;
+	// ---- restricted residual of the whole vector (coalesced sweep, LDS atomics per aggregate component) --------
+	for (int j = threadIdx.x; j < Nc; j += PCG2_T) rcL[j] = 0;
 	__syncthreads();
-	if (threadIdx.x < 6)
+	const int n6 = 6 * g.Pf;
+	const int own0 = 6 * I * sys.agg, own1 = min(n6, own0 + 6 * sys.agg);
+	constexpr int SWEEP = 8;   // independent loads in flight per thread
+	for (int base = 0; base < n6; base += SWEEP * PCG2_T)
 	{
-		Scalar s = 0;
-		for (int t = threadIdx.x; t < 126; t += 6) s += red[t];
-		sys.rc[6 * (size_t)I + threadIdx.x] = s;
+		Scalar rv[SWEEP], qv[SWEEP];
+#pragma unroll
+		for (int m = 0; m < SWEEP; m++)
+		{
+			const int idx = base + m * PCG2_T + threadIdx.x;
+			rv[m] = idx < n6 ? rin[idx] : Scalar(0);
+			qv[m] = (doUpdate && idx < n6) ? sys.ap[idx] : Scalar(0);
+		}
+#pragma unroll
+		for (int m = 0; m < SWEEP; m++)
+		{
+			const int idx = base + m * PCG2_T + threadIdx.x;
+			if (idx < n6)
+			{
+				const Scalar r = rv[m] - alpha * qv[m];
+				const int pose = idx / 6;
+				if (idx >= own0 && idx < own1)
+				{
+					rown[idx - own0] = r;
+					if (doUpdate)
+					{
+						rout[idx] = r;
+						sys.xp[idx] += alpha * p[idx];
+					}
+				}
+				__hip_atomic_fetch_add(&rcL[(pose / sys.agg) * 6 + (idx - 6 * pose)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
 	}
-	if (doUpdate && blockIdx.x == 0 && threadIdx.x == 0) *sys.iters = k + 1;
-}
-
-// B3(k): z = Minv r + P (Ac^-1 rc);  rz[kOut] += r.z      (one 128-thread workgroup per aggregate)
-__global__ __launch_bounds__(128) void pcg2_precond_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2)
-{
-	__shared__ Scalar part[128][6];
-	__shared__ Scalar yc[6];
-	__shared__ Scalar wsum[2];
-	const int lane = threadIdx.x & 63;
-	if (k >= 0)
-	{
-		Scalar rzk;
-		if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
-		const Scalar pqk = sum_slots(sys.pq + (size_t)k * NSLOT, lane);
-		if (!(pqk > 0)) return;
-	}
-	const int I = blockIdx.x;
-	const int Nc = 6 * sys.nc;
-	// yc = Ac^-1[6I..6I+6, :] rc   (the inverse is symmetric: read columns 6I..6I+5, contiguous in memory)
+	__syncthreads();
+	// ---- yc = Ac^-1[6I..6I+5, :] rc  (symmetric inverse: columns 6I..6I+5 are contiguous) ------------------
 	Scalar acc[6] = { 0, 0, 0, 0, 0, 0 };
-	for (int j = threadIdx.x; j < Nc; j += 128)
+	for (int j = threadIdx.x; j < Nc; j += PCG2_T)
 	{
-		const Scalar rj = sys.rc[j];
+		const Scalar rj = rcL[j];
 #pragma unroll
 		for (int c = 0; c < 6; c++) acc[c] += sys.acinv[(size_t)(6 * I + c) * Nc + j] * rj;
 	}
 #pragma unroll
-	for (int c = 0; c < 6; c++) part[threadIdx.x][c] = acc[c];
+	for (int c = 0; c < 6; c++)
+	{
+		acc[c] = wave_sum(acc[c]);
+		if (lane == 0) part[wv * 6 + c] = acc[c];
+	}
 	__syncthreads();
 	if (threadIdx.x < 6)
 	{
-		Scalar s = 0;
-		for (int t = 0; t < 128; t++) s += part[t][threadIdx.x];
-		yc[threadIdx.x] = s;
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < PCG2_T / 64; w++) s2 += part[w * 6 + threadIdx.x];
+		yc[threadIdx.x] = s2;
 	}
 	__syncthreads();
+	// ---- z = Minv r + yc for the poses of this aggregate; r.z --------------------------------------------------
 	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
-	const int comp = threadIdx.x % 6;
 	Scalar dot = 0;
-	if (threadIdx.x < 126)
-		for (int i = i0 + threadIdx.x / 6; i < i1; i += 21)
-		{
-			Scalar z = yc[comp];
+	for (int w = threadIdx.x; w < (i1 - i0) * 6; w += PCG2_T)
+	{
+		const int i = i0 + w / 6, comp = w % 6;
+		Scalar rr[6];
 #pragma unroll
-			for (int c = 0; c < 6; c++) z += sys.minv[36 * (size_t)i + c * 6 + comp] * sys.r[6 * (size_t)i + c];
-			sys.z[6 * (size_t)i + comp] = z;
-			dot += sys.r[6 * (size_t)i + comp] * z;
+		for (int c = 0; c < 6; c++)
+		{
+			rr[c] = rown[6 * (i - i0) + c];
 		}
+		Scalar z = yc[comp];
+#pragma unroll
+		for (int c = 0; c < 6; c++) z += sys.minv[36 * (size_t)i + c * 6 + comp] * rr[c];
+		sys.z[6 * (size_t)i + comp] = z;
+		dot += rr[comp] * z;
+	}
 	dot = wave_sum(dot);
-	if (lane == 0) wsum[threadIdx.x >> 6] = dot;
+	if (lane == 0) wsum[wv] = dot;
 	__syncthreads();
-	if (threadIdx.x == 0) atomic_add(&sys.rz[(size_t)kOut * NSLOT + (blockIdx.x % NSLOT)], wsum[0] + wsum[1]);
+	if (threadIdx.x == 0)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < PCG2_T / 64; w++) s2 += wsum[w];
+		atomic_add(&sys.rz[(size_t)kOut * NSLOT + (blockIdx.x % NSLOT)], s2);
+		if (doUpdate && blockIdx.x == 0) *sys.iters = k + 1;
+	}
 }
 
-void launch_pcg2_restrict(const DeviceGraph& g, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
+void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg2_restrict_kernel, dim3(sys.nc), dim3(128), 0, s, g, sys, k, maxIter, tol2, doUpdate);
-}
-
-void launch_pcg2_precond(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, hipStream_t s)
-{
-	hipLaunchKernelGGL(pcg2_precond_kernel, dim3(sys.nc), dim3(128), 0, s, g, sys, k, kOut, maxIter, tol2);
+	const size_t lds = sizeof(Scalar) * (6 * (size_t)sys.nc + 48 + 6 + 8 + 6 * (size_t)sys.agg);
+	hipLaunchKernelGGL(pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -1537,6 +1564,13 @@ void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const Devi
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
 	hipLaunchKernelGGL(pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
+}
+
+__global__ void pcg_advance_kernel(int* kbase, int n) { *kbase += n; }
+
+void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys.kbase, n);
 }
 
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)

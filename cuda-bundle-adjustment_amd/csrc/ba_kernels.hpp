@@ -75,11 +75,14 @@ struct DeviceSystem
 	Scalar *minv = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *ap = nullptr;
 	Scalar *rz = nullptr, *pq = nullptr;   // [(maxIter+2)*NSLOT] each
 	int* iters = nullptr;      // device iteration counter
+	int* kbase = nullptr;      // iteration offset added to the k / kOut kernel arguments (lets one captured hipGraph
+	                           // of `chunk` iterations be replayed: the graph's last node advances it by `chunk`)
 	// two-level preconditioner: aggregates of `agg` consecutive free poses, 6 coarse dof each
 	int agg = 0;               // 0 = block-Jacobi only
 	int nc = 0;                // number of aggregates (coarse dimension = 6*nc)
 	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
 	Scalar* rc = nullptr;      // [6nc] restricted residual
+	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
 };
 
 // residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
@@ -114,8 +117,8 @@ void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const Devi
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 // two-level (block-Jacobi + aggregate coarse correction) variant: 3 kernels per iteration
 void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s);
-void launch_pcg2_restrict(const DeviceGraph& g, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
-void launch_pcg2_precond(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, hipStream_t s);
+void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
+void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
 }  // namespace cubahip

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -108,8 +109,8 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
 	DevBuf<Scalar> d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
-	DevBuf<int> d_fail, d_iters;
-	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc;
+	DevBuf<int> d_fail, d_iters, d_kbase;
+	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2;
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	std::vector<int> h_rowptr, h_colind;
@@ -119,6 +120,55 @@ struct cuba_hip_solver
 	DeviceStructure st;
 	DeviceSystem sys;
 
+	// one captured hipGraph = `pcgGraphChunk` PCG iterations (kernel arguments are chunk-local, the device-side
+	// kbase counter supplies the offset): replaying it costs one host call instead of 2-3 launches per iteration
+	hipGraphExec_t pcgGraphExec = nullptr;
+	int pcgGraphChunk = 0;
+	bool useGraph = true;
+	hipStream_t captureStream = nullptr;   // private stream used only to record graphs (the work stream may be the
+	                                       // legacy default stream, which cannot be captured)
+	hipStream_t capStream()
+	{
+		if (!captureStream) HIP_TRY(hipStreamCreateWithFlags(&captureStream, hipStreamNonBlocking));
+		return captureStream;
+	}
+
+	void dropPcgGraph()
+	{
+		if (pcgGraphExec) { (void)hipGraphExecDestroy(pcgGraphExec); pcgGraphExec = nullptr; }
+	}
+
+	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
+	{
+		if (sys.agg > 0)
+		{
+			launch_pcg_spmv(g, st, sys, k, maxIter, tol2, s);
+			launch_pcg2_fused(g, sys, k, k + 1, maxIter, tol2, 1, s);
+		}
+		else launch_pcg_iteration(g, st, sys, k, maxIter, tol2, s);
+	}
+
+	void buildPcgGraph(int chunk, int maxIter, Scalar tol2)
+	{
+		dropPcgGraph();
+		hipGraph_t graph = nullptr;
+		hipStream_t cs = capStream();
+		HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+		for (int k = 0; k < chunk; k++) enqueuePcgIteration(k, maxIter, tol2, cs);
+		launch_pcg_advance(sys, chunk, cs);
+		HIP_TRY(hipStreamEndCapture(cs, &graph));
+		if (std::getenv("CUBA_HIP_DEBUG"))
+		{
+			size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn);
+			std::fprintf(stderr, "[cuba_hip] PCG graph: %zu nodes for a chunk of %d iterations\n", nn, chunk);
+		}
+		HIP_TRY(hipGraphInstantiate(&pcgGraphExec, graph, nullptr, nullptr, 0));
+		(void)hipGraphDestroy(graph);
+		pcgGraphChunk = chunk;
+		pcgGraphTol2 = tol2; pcgGraphMaxIter = maxIter; pcgGraphAcinv = sys.acinv;
+	}
+	Scalar pcgGraphTol2 = 0; int pcgGraphMaxIter = 0; const Scalar* pcgGraphAcinv = nullptr;
+
 	double lambda = 0;
 	int maxIterAlloc = 0;
 	long long nmul = 0;
@@ -127,6 +177,8 @@ struct cuba_hip_solver
 
 	~cuba_hip_solver()
 	{
+		dropPcgGraph();
+		if (captureStream) (void)hipStreamDestroy(captureStream);
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
 	}
@@ -202,8 +254,8 @@ struct cuba_hip_solver
 		d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream);
 		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
 		d_perEdge.resize(E);
-		d_slots.resize(4 * NSLOT); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1);
-		d_fail.zero(stream); d_iters.zero(stream);
+		d_slots.resize(4 * NSLOT); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1);
+		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream);
 		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
 		sync();   // host staging vectors go out of scope
 
@@ -394,7 +446,7 @@ struct cuba_hip_solver
 		if (agg < 0) agg = std::max(16, (Pf + 255) / 256);
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		if (nc < 2) { agg = 0; nc = 0; }
-		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc);
+		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc); d_r2.resize((size_t)6 * Pf);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
 		d_rz.resize((size_t)(mi + 2) * NSLOT); d_pq.resize((size_t)(mi + 2) * NSLOT);
@@ -414,8 +466,9 @@ struct cuba_hip_solver
 		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = d_slots.data();
 		sys.maxdiag = d_maxdiag.data(); sys.fail = d_fail.data();
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
-		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data();
-		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data();
+		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data();
+		dropPcgGraph();
+		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
 		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;   // pattern of Hsc doubles as the "symbolic" phase of the reduced solver
@@ -521,30 +574,24 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
 		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
+		d_kbase.zero(stream);
 		launch_pcg_setup(g, st, sys, lambda, stream);
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
 			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
-			launch_pcg2_restrict(g, sys, 0, maxIter, tol2, 0, stream);
-			launch_pcg2_precond(g, sys, -1, 0, maxIter, tol2, stream);
+			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
 		const int chunk = std::max(1, pcgCheckEvery);
 		int* hInts = (int*)(h_pinned + 2 * NSLOT);
 		bool converged = false;
+		if (useGraph && (!pcgGraphExec || pcgGraphChunk != chunk || pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter || pcgGraphAcinv != sys.acinv))
+			buildPcgGraph(chunk, maxIter, tol2);
 		for (int k0 = 0; k0 < maxIter && !converged; k0 += chunk)
 		{
 			const int k1 = std::min(maxIter, k0 + chunk);
-			for (int k = k0; k < k1; k++)
-			{
-				if (twoLevel)
-				{
-					launch_pcg_spmv(g, st, sys, k, maxIter, tol2, stream);
-					launch_pcg2_restrict(g, sys, k, maxIter, tol2, 1, stream);
-					launch_pcg2_precond(g, sys, k, k + 1, maxIter, tol2, stream);
-				}
-				else launch_pcg_iteration(g, st, sys, k, maxIter, tol2, stream);
-			}
+			if (useGraph) HIP_TRY(hipGraphLaunch(pcgGraphExec, stream));
+			else for (int k = k0; k < k1; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 			HIP_TRY(hipMemcpyAsync(h_pinned, d_rz.data(), sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(h_pinned + NSLOT, d_rz.data() + (size_t)k1 * NSLOT, sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts, d_fail.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -666,14 +713,28 @@ struct cuba_hip_solver
 		need();
 		hipEvent_t e0, e1;
 		HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+		// `reps` launches are captured into one hipGraph so that the events bracket device time, not the host's
+		// launch cadence (plain launches of these few-microsecond kernels are host-bound)
+		hipStream_t work = stream;
 		auto timeit = [&](auto&& fn) {
 			fn();
-			HIP_TRY(hipEventRecord(e0, stream));
+			hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+			hipStream_t cs = capStream();
+			HIP_TRY(hipStreamSynchronize(work));
+			HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+			stream = cs;                    // the launch helpers below enqueue on `stream`
 			for (int i = 0; i < reps; i++) fn();
+			stream = work;
+			HIP_TRY(hipStreamEndCapture(cs, &graph));
+			HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+			HIP_TRY(hipGraphLaunch(exec, stream));
+			HIP_TRY(hipEventRecord(e0, stream));
+			HIP_TRY(hipGraphLaunch(exec, stream));
 			HIP_TRY(hipEventRecord(e1, stream));
 			HIP_TRY(hipEventSynchronize(e1));
 			float ms = 0;
 			HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+			(void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
 			return (double)ms / reps;
 		};
 		const double lam = lambda > 0 ? lambda : 1.0;
@@ -686,18 +747,18 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
 		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
+		d_kbase.zero(stream);
 		launch_pcg_setup(g, st, sys, lam, stream);
 		if (sys.agg > 0)
 		{
 			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
-			launch_pcg2_restrict(g, sys, 0, 1 << 30, -1.0, 0, stream);
-			launch_pcg2_precond(g, sys, -1, 0, 1 << 30, -1.0, stream);
+			launch_pcg2_fused(g, sys, 0, 0, 1 << 30, -1.0, 0, stream);
 		}
 		msOut[2] = timeit([&] { launch_pcg_spmv(g, st, sys, 0, 1 << 30, -1.0, stream); });
 		if (sys.agg > 0)
 		{
-			msOut[3] = timeit([&] { launch_pcg2_restrict(g, sys, 0, 1 << 30, -1.0, 1, stream); });
-			msOut[5] = timeit([&] { launch_pcg2_precond(g, sys, 0, 1, 1 << 30, -1.0, stream); });
+			msOut[3] = timeit([&] { launch_pcg2_fused(g, sys, 0, 1, 1 << 30, -1.0, 1, stream); });
+			msOut[5] = 0;   // merged into [3] (update + restrict + two-level preconditioner in one kernel)
 			msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream); });
 		}
 		else
@@ -803,6 +864,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "schur_atomic") s->schurAtomic = value != 0;
+		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
 	});

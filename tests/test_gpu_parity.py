@@ -292,4 +292,4 @@ def test_kitti00_shape_properties(solvers):
     res2 = h.optimize(10)["chi2"]
     assert rel(res2, res) < 1e-8
     kt = h.time_kernels(5)
-    assert all(v > 0 for v in kt.values())
+    assert all(v > 0 for k, v in kt.items() if k != "pcg_precond")   # merged into pcg_update in the two-level path
