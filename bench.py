@@ -128,7 +128,7 @@ def main():
         solver.set_state(q0, t0, X0)
         kt = solver.time_kernels(reps=20)
         nblk = c1["hsc_blocks"]
-        nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + max(16, (fp.Pf + 255) // 256) - 1) // max(16, (fp.Pf + 255) // 256)
+        nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + max(16, (fp.Pf + 127) // 128) - 1) // max(16, (fp.Pf + 127) // 128)
         alg = algorithmic_bytes(fp, nblk, nc)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
                     "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials, "coarse_setup": trials}

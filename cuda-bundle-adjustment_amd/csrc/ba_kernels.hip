@@ -1183,54 +1183,82 @@ __device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int m
 }
 
 // A(k): p_k = z_k + beta p_{k-1} (recomputed on the fly for the neighbour rows), q = A p_k, pq[k] += p.q
+// Latency structure: everything that does not need the reduction scalars is issued first -- A p_k is formed as
+// A z_k + beta A p_{k-1} from two accumulators, so beta (and the stop test) are only needed after the last FMA and
+// their loads (slots written by atomics of the previous kernel => memory-side latency) overlap the matrix sweep.
+// k's parity equals the parity of the chunk-local argument (chunks are even), so the p ping-pong needs no load either.
+__device__ __forceinline__ void spmv_entry(const DeviceStructure& st, const DeviceSystem& sys, const Scalar* pold, int a, int rr,
+	Scalar& accz, Scalar& accp)
+{
+	const int bi = st.adj_blk[a];
+	const int j = st.adj_col[a];
+	const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
+	const int sr = bi < 0 ? 6 : 1, sc = bi < 0 ? 1 : 6;   // transposed read of the stored upper block for the lower half
+	Scalar av[6], zv[6], pv[6];
+#pragma unroll
+	for (int c = 0; c < 6; c++)
+	{
+		av[c] = B[rr * sr + c * sc];
+		zv[c] = sys.z[6 * (size_t)j + c];
+		pv[c] = pold[6 * (size_t)j + c];
+	}
+#pragma unroll
+	for (int c = 0; c < 6; c++) { accz += av[c] * zv[c]; accp += av[c] * pv[c]; }
+}
+
 __global__ __launch_bounds__(256) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	k += *sys.kbase;
-	Scalar rzk;
-	if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
-	Scalar beta = 0;
-	if (k > 0) beta = rzk / sum_slots(sys.rz + (size_t)(k - 1) * NSLOT, lane);
 	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
 	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
 	const int row = blockIdx.x * 4 + wv;
-	Scalar dot = 0;
+	// scalar loads, consumed at the very end
+	k += *sys.kbase;
+	const int failed = *sys.fail;
+	const Scalar s_k = lane < NSLOT ? sys.rz[(size_t)k * NSLOT + lane] : Scalar(0);
+	const Scalar s_0 = lane < NSLOT ? sys.rz[lane] : Scalar(0);
+	const Scalar s_m = (lane < NSLOT && k > 0) ? sys.rz[(size_t)(k - 1) * NSLOT + lane] : Scalar(0);
+
+	Scalar accz = 0, accp = 0, zi = 0, pi_old = 0;
 	if (row < g.Pf)
 	{
 		const int slot = lane / 6, rr = lane % 6;
-		Scalar acc = 0;
 		if (lane < 60)
 		{
 			const int a1 = st.adj_ptr[row + 1];
-			for (int a = st.adj_ptr[row] + slot; a < a1; a += 10)
+			int a = st.adj_ptr[row] + slot;
+			for (; a + 10 < a1; a += 20)     // two entries per trip: their 36 loads are independent and overlap
 			{
-				const int bi = st.adj_blk[a];
-				const int j = st.adj_col[a];
-				const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
-				const bool tr = bi < 0;
-#pragma unroll
-				for (int c = 0; c < 6; c++)
-				{
-					const Scalar pj = sys.z[6 * (size_t)j + c] + beta * pold[6 * (size_t)j + c];
-					const Scalar av = tr ? B[rr * 6 + c] : B[c * 6 + rr];
-					acc += av * pj;
-				}
+				spmv_entry(st, sys, pold, a, rr, accz, accp);
+				spmv_entry(st, sys, pold, a + 10, rr, accz, accp);
 			}
+			if (a < a1) spmv_entry(st, sys, pold, a, rr, accz, accp);
 		}
-		// fold the 10 slots onto lanes 0..5
-		acc += __shfl_down(acc, 30);
-		Scalar tot = acc;
-		tot += __shfl_down(acc, 6);
-		tot += __shfl_down(acc, 12);
-		tot += __shfl_down(acc, 18);
-		tot += __shfl_down(acc, 24);
 		if (lane < 6)
 		{
-			const Scalar pi = sys.z[6 * (size_t)row + lane] + beta * pold[6 * (size_t)row + lane];
-			pnew[6 * (size_t)row + lane] = pi;
-			sys.ap[6 * (size_t)row + lane] = tot;
-			dot = pi * tot;
+			zi = sys.z[6 * (size_t)row + lane];
+			pi_old = pold[6 * (size_t)row + lane];
 		}
+	}
+	// fold the 10 slots onto lanes 0..5
+	accz += __shfl_down(accz, 30); accp += __shfl_down(accp, 30);
+	Scalar tz = accz, tp = accp;
+	tz += __shfl_down(accz, 6);  tp += __shfl_down(accp, 6);
+	tz += __shfl_down(accz, 12); tp += __shfl_down(accp, 12);
+	tz += __shfl_down(accz, 18); tp += __shfl_down(accp, 18);
+	tz += __shfl_down(accz, 24); tp += __shfl_down(accp, 24);
+
+	const Scalar rzk = wave_sum(s_k), rz0 = wave_sum(s_0), rzm = wave_sum(s_m);
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk)) return;
+	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
+	Scalar dot = 0;
+	if (row < g.Pf && lane < 6)
+	{
+		const Scalar pi = zi + beta * pi_old;
+		const Scalar q = tz + beta * tp;
+		pnew[6 * (size_t)row + lane] = pi;
+		sys.ap[6 * (size_t)row + lane] = q;
+		dot = pi * q;
 	}
 	dot = wave_sum(dot);
 	__shared__ Scalar part[4];
@@ -1430,36 +1458,30 @@ constexpr int PCG2_T = 512;
 
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
-	extern __shared__ __attribute__((aligned(16))) Scalar sm[];   // rcL[Nc] | part[8][6] | yc[6] | wsum[8] | rown[6*agg]
+	extern __shared__ __attribute__((aligned(16))) Scalar sm[];   // sR[Nc] | sQ[Nc] | part[8][6] | yc[6] | wsum[8] | rown | qown
 	const int Nc = 6 * sys.nc;
-	Scalar* rcL = sm;
-	Scalar* part = sm + Nc;
+	Scalar* sR = sm;
+	Scalar* sQ = sR + Nc;
+	Scalar* part = sQ + Nc;
 	Scalar* yc = part + 48;
 	Scalar* wsum = yc + 6;
 	Scalar* rown = wsum + 8;
+	Scalar* qown = rown + 6 * sys.agg;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int kb = *sys.kbase;
-	k += kb; kOut += kb;
-	Scalar alpha = 0;
-	if (doUpdate)
-	{
-		Scalar rzk;
-		if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
-		const Scalar pqk = sum_slots(sys.pq + (size_t)k * NSLOT, lane);
-		if (!(pqk > 0))
-		{
-			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
-			return;
-		}
-		alpha = rzk / pqk;
-	}
 	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;
 	// the residual is double-buffered: other workgroups still read r_k of this aggregate while its owner stores r_{k+1}
 	const Scalar* rin = (k & 1) ? sys.r2 : sys.r;
 	Scalar* rout = (k & 1) ? sys.r : sys.r2;
 	const int I = blockIdx.x;
-	// ---- restricted residual of the whole vector (coalesced sweep, LDS atomics per aggregate component) --------
-	for (int j = threadIdx.x; j < Nc; j += PCG2_T) rcL[j] = 0;
+	// reduction scalars: loaded now, consumed after the sweep (alpha enters linearly: rc = P^T r - alpha P^T q)
+	const int kb = *sys.kbase;
+	k += kb; kOut += kb;
+	const int failed = *sys.fail;
+	const Scalar s_k = (doUpdate && lane < NSLOT) ? sys.rz[(size_t)k * NSLOT + lane] : Scalar(0);
+	const Scalar s_0 = (doUpdate && lane < NSLOT) ? sys.rz[lane] : Scalar(0);
+	const Scalar s_q = (doUpdate && lane < NSLOT) ? sys.pq[(size_t)k * NSLOT + lane] : Scalar(0);
+
+	for (int j = threadIdx.x; j < 2 * Nc; j += PCG2_T) sR[j] = 0;
 	__syncthreads();
 	const int n6 = 6 * g.Pf;
 	const int own0 = 6 * I * sys.agg, own1 = min(n6, own0 + 6 * sys.agg);
@@ -1480,29 +1502,58 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			const int idx = base + m * PCG2_T + threadIdx.x;
 			if (idx < n6)
 			{
-				const Scalar r = rv[m] - alpha * qv[m];
 				const int pose = idx / 6;
-				if (idx >= own0 && idx < own1)
-				{
-					rown[idx - own0] = r;
-					if (doUpdate)
-					{
-						rout[idx] = r;
-						sys.xp[idx] += alpha * p[idx];
-					}
-				}
-				__hip_atomic_fetch_add(&rcL[(pose / sys.agg) * 6 + (idx - 6 * pose)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const int slot = (pose / sys.agg) * 6 + (idx - 6 * pose);
+				if (idx >= own0 && idx < own1) { rown[idx - own0] = rv[m]; qown[idx - own0] = qv[m]; }
+				__hip_atomic_fetch_add(&sR[slot], rv[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (doUpdate) __hip_atomic_fetch_add(&sQ[slot], qv[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		}
 	}
+	// the part of the coarse inverse this workgroup needs (symmetric: columns 6I..6I+5 are contiguous), also early
+	Scalar ainv[6] = { 0, 0, 0, 0, 0, 0 };
+	if (threadIdx.x < Nc)
+#pragma unroll
+		for (int c = 0; c < 6; c++) ainv[c] = sys.acinv[(size_t)(6 * I + c) * Nc + threadIdx.x];
+	Scalar alpha = 0;
+	if (doUpdate)
+	{
+		const Scalar rzk = wave_sum(s_k), rz0 = wave_sum(s_0), pqk = wave_sum(s_q);
+		if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk)) return;
+		if (!(pqk > 0))
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
+			return;
+		}
+		alpha = rzk / pqk;
+	}
 	__syncthreads();
-	// ---- yc = Ac^-1[6I..6I+5, :] rc  (symmetric inverse: columns 6I..6I+5 are contiguous) ------------------
+	// ---- own rows: r_{k+1}, x_{k+1} ---------------------------------------------------------------------------
+	for (int w = threadIdx.x; w < own1 - own0; w += PCG2_T)
+	{
+		const Scalar r = rown[w] - alpha * qown[w];
+		rown[w] = r;
+		if (doUpdate)
+		{
+			rout[own0 + w] = r;
+			sys.xp[own0 + w] += alpha * p[own0 + w];
+		}
+	}
+	// ---- yc = Ac^-1[6I..6I+5, :] (P^T r - alpha P^T q) ------------------------------------------------------------
 	Scalar acc[6] = { 0, 0, 0, 0, 0, 0 };
 	for (int j = threadIdx.x; j < Nc; j += PCG2_T)
 	{
-		const Scalar rj = rcL[j];
+		const Scalar rj = sR[j] - alpha * sQ[j];
+		if (j == threadIdx.x)
+		{
 #pragma unroll
-		for (int c = 0; c < 6; c++) acc[c] += sys.acinv[(size_t)(6 * I + c) * Nc + j] * rj;
+			for (int c = 0; c < 6; c++) acc[c] += ainv[c] * rj;
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < 6; c++) acc[c] += sys.acinv[(size_t)(6 * I + c) * Nc + j] * rj;
+		}
 	}
 #pragma unroll
 	for (int c = 0; c < 6; c++)
@@ -1525,17 +1576,11 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	for (int w = threadIdx.x; w < (i1 - i0) * 6; w += PCG2_T)
 	{
 		const int i = i0 + w / 6, comp = w % 6;
-		Scalar rr[6];
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-		{
-			rr[c] = rown[6 * (i - i0) + c];
-		}
 		Scalar z = yc[comp];
 #pragma unroll
-		for (int c = 0; c < 6; c++) z += sys.minv[36 * (size_t)i + c * 6 + comp] * rr[c];
+		for (int c = 0; c < 6; c++) z += sys.minv[36 * (size_t)i + c * 6 + comp] * rown[6 * (i - i0) + c];
 		sys.z[6 * (size_t)i + comp] = z;
-		dot += rr[comp] * z;
+		dot += rown[6 * (i - i0) + comp] * z;
 	}
 	dot = wave_sum(dot);
 	if (lane == 0) wsum[wv] = dot;
@@ -1552,7 +1597,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
 {
-	const size_t lds = sizeof(Scalar) * (6 * (size_t)sys.nc + 48 + 6 + 8 + 6 * (size_t)sys.agg);
+	const size_t lds = sizeof(Scalar) * (12 * (size_t)sys.nc + 48 + 6 + 8 + 12 * (size_t)sys.agg);
 	hipLaunchKernelGGL(pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 

@@ -84,7 +84,7 @@ struct cuba_hip_solver
 	std::string lastError;
 
 	// options
-	double pcgTol = 1e-10;
+	double pcgTol = 1e-8;        // relative M^-1-norm residual; the objective is second-order in the solve error
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 32;
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
@@ -441,9 +441,9 @@ struct cuba_hip_solver
 		d_minv.resize((size_t)36 * Pf);
 		d_r.resize((size_t)6 * Pf); d_z.resize((size_t)6 * Pf); d_p0.resize((size_t)6 * Pf); d_p1.resize((size_t)6 * Pf); d_ap.resize((size_t)6 * Pf);
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
-		// coarse level of the preconditioner: aggregates of consecutive free poses, coarse dimension <= 1536
+		// coarse level of the preconditioner: aggregates of consecutive free poses
 		int agg = pcgAggregate;
-		if (agg < 0) agg = std::max(16, (Pf + 255) / 256);
+		if (agg < 0) agg = std::max(16, (Pf + 127) / 128);   // coarse dimension <= 768: the O(Nc^3) inverse stays below ~0.3 ms
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		if (nc < 2) { agg = 0; nc = 0; }
 		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc); d_r2.resize((size_t)6 * Pf);
@@ -582,7 +582,7 @@ struct cuba_hip_solver
 			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
-		const int chunk = std::max(1, pcgCheckEvery);
+		const int chunk = 2 * ((std::max(1, pcgCheckEvery) + 1) / 2);   // even: the kernels take k's parity from the chunk-local index
 		int* hInts = (int*)(h_pinned + 2 * NSLOT);
 		bool converged = false;
 		if (useGraph && (!pcgGraphExec || pcgGraphChunk != chunk || pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter || pcgGraphAcinv != sys.acinv))

@@ -76,7 +76,7 @@ const char* cuba_hip_version(void);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-10), "pcg_max_iter"
+/* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-8), "pcg_max_iter"
    (default 4*6*Pf capped at 32768), "pcg_check_every" (default 32), "pcg_aggregate" (poses per coarse
    aggregate of the two-level preconditioner; -1 = automatic (16), 0 = block-Jacobi only), "pcg_graph" (default 1: replay the PCG iterations as a captured hipGraph), "schur_atomic"
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "profile" (0/1: per-stage

@@ -73,7 +73,7 @@ def test_oracle_and_hip_match_reference_kernels(name, fp, rk):
     assert rel(ref["chi_per_edge"], o.chi_squares()) < 1e-9
 
     # ---- HIP path vs reference kernels ---------------------------------------------------------------------
-    h = HipSolver(fp, rk)
+    h = HipSolver(fp, rk, pcg_tol=1e-11)
     assert h.compute_errors() == pytest.approx(ref["chi2"], rel=1e-12)
     assert h.max_diagonal() == pytest.approx(ref["maxdiag"], rel=1e-12)
     lm = h.array("lm_sys").reshape(-1, 9)
