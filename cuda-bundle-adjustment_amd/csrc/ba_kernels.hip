@@ -64,6 +64,29 @@ __device__ __forceinline__ Scalar sum_slots(const Scalar* s, int lane)
 	return wave_sum(v);
 }
 
+// lane-strided partial sum of n per-workgroup partials (finish with wave_sum)
+__device__ __forceinline__ Scalar load_parts(const Scalar* p, int n, int lane)
+{
+	// four independent loads per trip (a runtime-trip loop is not unrolled by the compiler and would pay one memory
+	// round trip per element); the summation order is fixed, so the result is reproducible
+	Scalar v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+	int i = lane;
+	for (; i + 192 < n; i += 256)
+	{
+		const Scalar a = p[i], b = p[i + 64], c = p[i + 128], d = p[i + 192];
+		v0 += a; v1 += b; v2 += c; v3 += d;
+	}
+	const Scalar e0 = i < n ? p[i] : Scalar(0);
+	const Scalar e1 = i + 64 < n ? p[i + 64] : Scalar(0);
+	const Scalar e2 = i + 128 < n ? p[i + 128] : Scalar(0);
+	return ((v0 + e0) + (v1 + e1)) + ((v2 + e2) + v3);
+}
+
+__device__ __forceinline__ const Scalar* rz_slot(const DeviceSystem& sys, int k) { return sys.rz + (size_t)(k == 0 ? 0 : 1 + (k & 3)) * sys.rzStride; }
+__device__ __forceinline__ Scalar* rz_slot_w(const DeviceSystem& sys, int k) { return sys.rz + (size_t)(k == 0 ? 0 : 1 + (k & 3)) * sys.rzStride; }
+__device__ __forceinline__ int rz_count(const DeviceSystem& sys, int k) { return k == 0 ? sys.nrz0 : sys.nrz; }
+__device__ __forceinline__ Scalar* pq_slot(const DeviceSystem& sys, int k) { return sys.pq + (size_t)(k & 3) * sys.pqStride; }
+
 // Everything a lane knows about its edge after loading + linearising it.
 struct LaneEdge
 {
@@ -1166,8 +1189,11 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 		}
 	}
 	rz = wave_sum(rz);
-	if (sys.agg == 0 && (threadIdx.x & 63) == 0) atomic_add(&sys.rz[(blockIdx.x * 4 + (threadIdx.x >> 6)) % NSLOT], rz);
-	if (i == 0) *sys.iters = 0;
+	__shared__ Scalar part[4];
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rz;
+	__syncthreads();
+	if (sys.agg == 0 && threadIdx.x == 0) sys.rz[blockIdx.x] = part[0] + part[1] + part[2] + part[3];   // slot 0
+	if (i == 0) { *sys.iters = 0; *sys.done = 0; }
 }
 
 void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
@@ -1177,9 +1203,12 @@ void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const Dev
 
 __device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int lane, Scalar& rzk)
 {
-	rzk = sum_slots(sys.rz + (size_t)k * NSLOT, lane);
-	const Scalar rz0 = sum_slots(sys.rz, lane);
-	return k < maxIter && *sys.fail == 0 && rzk > tol2 * rz0 && rzk == rzk;
+	if (*sys.done) return false;
+	rzk = wave_sum(load_parts(rz_slot(sys, k), rz_count(sys, k), lane));
+	const Scalar rz0 = wave_sum(load_parts(sys.rz, sys.nrz0, lane));
+	const bool on = k < maxIter && *sys.fail == 0 && rzk > tol2 * rz0 && rzk == rzk;
+	if (!on && blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+	return on;
 }
 
 // A(k): p_k = z_k + beta p_{k-1} (recomputed on the fly for the neighbour rows), q = A p_k, pq[k] += p.q
@@ -1206,18 +1235,20 @@ __device__ __forceinline__ void spmv_entry(const DeviceStructure& st, const Devi
 	for (int c = 0; c < 6; c++) { accz += av[c] * zv[c]; accp += av[c] * pv[c]; }
 }
 
-__global__ __launch_bounds__(256) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+constexpr int SPMV_ROWS = 4;    // block rows (= waves) per workgroup: one p.Ap partial per 16 rows keeps the partial list short
+
+__global__ __launch_bounds__(64 * SPMV_ROWS) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
 	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
-	const int row = blockIdx.x * 4 + wv;
+	const int row = blockIdx.x * SPMV_ROWS + wv;
 	// scalar loads, consumed at the very end
 	k += *sys.kbase;
-	const int failed = *sys.fail;
-	const Scalar s_k = lane < NSLOT ? sys.rz[(size_t)k * NSLOT + lane] : Scalar(0);
-	const Scalar s_0 = lane < NSLOT ? sys.rz[lane] : Scalar(0);
-	const Scalar s_m = (lane < NSLOT && k > 0) ? sys.rz[(size_t)(k - 1) * NSLOT + lane] : Scalar(0);
+	const int failed = *sys.fail | *sys.done;   // consumed after the sweep, like the other scalars
+	const Scalar s_k = load_parts(rz_slot(sys, k), rz_count(sys, k), lane);
+	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
+	const Scalar s_m = k > 0 ? load_parts(rz_slot(sys, k - 1), rz_count(sys, k - 1), lane) : Scalar(0);
 
 	Scalar accz = 0, accp = 0, zi = 0, pi_old = 0;
 	if (row < g.Pf)
@@ -1249,7 +1280,11 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(DeviceGraph g, DeviceStru
 	tz += __shfl_down(accz, 24); tp += __shfl_down(accp, 24);
 
 	const Scalar rzk = wave_sum(s_k), rz0 = wave_sum(s_0), rzm = wave_sum(s_m);
-	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk)) return;
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+		return;
+	}
 	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
 	Scalar dot = 0;
 	if (row < g.Pf && lane < 6)
@@ -1261,10 +1296,16 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(DeviceGraph g, DeviceStru
 		dot = pi * q;
 	}
 	dot = wave_sum(dot);
-	__shared__ Scalar part[4];
+	__shared__ Scalar part[SPMV_ROWS];
 	if (lane == 0) part[wv] = dot;
 	__syncthreads();
-	if (threadIdx.x == 0) atomic_add(&sys.pq[(size_t)k * NSLOT + (blockIdx.x % NSLOT)], part[0] + part[1] + part[2] + part[3]);
+	if (threadIdx.x == 0)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < SPMV_ROWS; w++) s2 += part[w];
+		pq_slot(sys, k)[blockIdx.x] = s2;
+	}
 }
 
 // B(k): alpha = rz[k]/pq[k]; x += alpha p; r -= alpha q; z = Minv r; rz[k+1] += r.z
@@ -1274,7 +1315,7 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 	k += *sys.kbase;
 	Scalar rzk;
 	if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
-	const Scalar pqk = sum_slots(sys.pq + (size_t)k * NSLOT, lane);
+	const Scalar pqk = wave_sum(load_parts(pq_slot(sys, k), sys.npq, lane));
 	if (!(pqk > 0))
 	{
 		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;   // not positive definite along p
@@ -1308,7 +1349,10 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 		dot = rnew * z;
 	}
 	dot = wave_sum(dot);
-	if (lane == 0) atomic_add(&sys.rz[(size_t)(k + 1) * NSLOT + ((blockIdx.x * 4 + wv) % NSLOT)], dot);
+	__shared__ Scalar part[4];
+	if (lane == 0) part[wv] = dot;
+	__syncthreads();
+	if (threadIdx.x == 0) rz_slot_w(sys, k + 1)[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 	if (blockIdx.x == 0 && threadIdx.x == 0) *sys.iters = k + 1;
 }
 
@@ -1476,10 +1520,10 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	// reduction scalars: loaded now, consumed after the sweep (alpha enters linearly: rc = P^T r - alpha P^T q)
 	const int kb = *sys.kbase;
 	k += kb; kOut += kb;
-	const int failed = *sys.fail;
-	const Scalar s_k = (doUpdate && lane < NSLOT) ? sys.rz[(size_t)k * NSLOT + lane] : Scalar(0);
-	const Scalar s_0 = (doUpdate && lane < NSLOT) ? sys.rz[lane] : Scalar(0);
-	const Scalar s_q = (doUpdate && lane < NSLOT) ? sys.pq[(size_t)k * NSLOT + lane] : Scalar(0);
+	const int failed = *sys.fail | (doUpdate ? *sys.done : 0);
+	const Scalar s_k = doUpdate ? load_parts(rz_slot(sys, k), rz_count(sys, k), lane) : Scalar(0);
+	const Scalar s_0 = doUpdate ? load_parts(sys.rz, sys.nrz0, lane) : Scalar(0);
+	const Scalar s_q = doUpdate ? load_parts(pq_slot(sys, k), sys.npq, lane) : Scalar(0);
 
 	for (int j = threadIdx.x; j < 2 * Nc; j += PCG2_T) sR[j] = 0;
 	__syncthreads();
@@ -1519,7 +1563,11 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	if (doUpdate)
 	{
 		const Scalar rzk = wave_sum(s_k), rz0 = wave_sum(s_0), pqk = wave_sum(s_q);
-		if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk)) return;
+		if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+			return;
+		}
 		if (!(pqk > 0))
 		{
 			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
@@ -1590,7 +1638,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		Scalar s2 = 0;
 #pragma unroll
 		for (int w = 0; w < PCG2_T / 64; w++) s2 += wsum[w];
-		atomic_add(&sys.rz[(size_t)kOut * NSLOT + (blockIdx.x % NSLOT)], s2);
+		rz_slot_w(sys, kOut)[blockIdx.x] = s2;
 		if (doUpdate && blockIdx.x == 0) *sys.iters = k + 1;
 	}
 }
@@ -1603,7 +1651,7 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_spmv_kernel, dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
+	hipLaunchKernelGGL(pcg_spmv_kernel, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(64 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
 }
 
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)

@@ -73,7 +73,12 @@ struct DeviceSystem
 	int* fail = nullptr;       // numeric failure flag
 	// PCG work
 	Scalar *minv = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *ap = nullptr;
-	Scalar *rz = nullptr, *pq = nullptr;   // [(maxIter+2)*NSLOT] each
+	// CG scalars as per-workgroup partial sums in small rings (no atomics => fixed summation order, nothing to zero):
+	//   rz: slot 0 = r0.z0 (kept for the stop test), slot 1+(k&3) = r_k.z_k for k >= 1;  pq: slot k&3 = p_k.A p_k
+	Scalar *rz = nullptr, *pq = nullptr;
+	int rzStride = 0, pqStride = 0;        // entries per ring slot
+	int nrz0 = 0, nrz = 0, npq = 0;        // number of partials actually written into slot 0 / the other rz slots / pq slots
+	int* done = nullptr;                   // set once the stop test fails: later queued launches return at once
 	int* iters = nullptr;      // device iteration counter
 	int* kbase = nullptr;      // iteration offset added to the k / kOut kernel arguments (lets one captured hipGraph
 	                           // of `chunk` iterations be replayed: the graph's last node advances it by `chunk`)

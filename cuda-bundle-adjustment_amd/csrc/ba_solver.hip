@@ -109,7 +109,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
 	DevBuf<Scalar> d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
-	DevBuf<int> d_fail, d_iters, d_kbase;
+	DevBuf<int> d_fail, d_iters, d_kbase, d_done;
 	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2;
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
@@ -254,8 +254,8 @@ struct cuba_hip_solver
 		d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream);
 		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
 		d_perEdge.resize(E);
-		d_slots.resize(4 * NSLOT); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1);
-		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream);
+		d_slots.resize(4 * NSLOT); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1);
+		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream);
 		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
 		sync();   // host staging vectors go out of scope
 
@@ -449,7 +449,9 @@ struct cuba_hip_solver
 		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc); d_r2.resize((size_t)6 * Pf);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
-		d_rz.resize((size_t)(mi + 2) * NSLOT); d_pq.resize((size_t)(mi + 2) * NSLOT);
+		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + 3) / 4;   // SPMV_ROWS
+		const int rzStride = std::max(1, std::max(std::max(gridSetup, gridUpd), nc)), pqStride = std::max(1, gridSpmv);
+		d_rz.resize((size_t)5 * rzStride); d_pq.resize((size_t)4 * pqStride);
 		sync();
 
 		st = DeviceStructure();
@@ -468,6 +470,8 @@ struct cuba_hip_solver
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
 		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data();
 		dropPcgGraph();
+		sys.rzStride = rzStride; sys.pqStride = pqStride; sys.npq = gridSpmv;
+		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -571,11 +575,9 @@ struct cuba_hip_solver
 		if (Pf == 0) return true;
 		const int maxIter = maxIterAlloc;
 		const Scalar tol2 = pcgTol * pcgTol;
-		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
-		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
 		d_kbase.zero(stream);
-		launch_pcg_setup(g, st, sys, lambda, stream);
+		launch_pcg_setup(g, st, sys, lambda, stream);   // also clears the device-side `done` flag
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
@@ -592,16 +594,12 @@ struct cuba_hip_solver
 			const int k1 = std::min(maxIter, k0 + chunk);
 			if (useGraph) HIP_TRY(hipGraphLaunch(pcgGraphExec, stream));
 			else for (int k = k0; k < k1; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
-			HIP_TRY(hipMemcpyAsync(h_pinned, d_rz.data(), sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipMemcpyAsync(h_pinned + NSLOT, d_rz.data() + (size_t)k1 * NSLOT, sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts, d_fail.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts + 1, d_iters.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(hInts + 2, d_done.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			sync();
-			double rz0 = 0, rzk = 0;
-			for (int i = 0; i < NSLOT; i++) { rz0 += h_pinned[i]; rzk += h_pinned[NSLOT + i]; }
 			if (hInts[0] != 0) { cntPcgIters += hInts[1]; return false; }
-			// a finished solve leaves rz[k1] untouched (= 0) once the kernels turned into no-ops
-			if (!(rzk > tol2 * rz0) || hInts[1] < k1) converged = true;
+			if (hInts[2] != 0 || hInts[1] < k1) converged = true;   // the device-side stop test fired
 		}
 		cntPcgIters += hInts[1];
 		return true;   // hitting max_iter returns the best iterate, like an inexact LM step
@@ -744,8 +742,6 @@ struct cuba_hip_solver
 		// a consistent reduced system for the PCG kernels
 		d_red.zero(stream);
 		linearize(1, lam);
-		HIP_TRY(hipMemsetAsync(d_rz.data(), 0, d_rz.size() * sizeof(Scalar), stream));
-		HIP_TRY(hipMemsetAsync(d_pq.data(), 0, d_pq.size() * sizeof(Scalar), stream));
 		d_fail.zero(stream);
 		d_kbase.zero(stream);
 		launch_pcg_setup(g, st, sys, lam, stream);
