@@ -87,6 +87,35 @@ __device__ __forceinline__ Scalar* rz_slot_w(const DeviceSystem& sys, int k) { r
 __device__ __forceinline__ int rz_count(const DeviceSystem& sys, int k) { return k == 0 ? sys.nrz0 : sys.nrz; }
 __device__ __forceinline__ Scalar* pq_slot(const DeviceSystem& sys, int k) { return sys.pq + (size_t)(k & 3) * sys.pqStride; }
 
+// Deterministic second stage of every global sum (chi2, gain-ratio denominator): one workgroup adds the
+// per-workgroup partials in a fixed order and writes the total to out[0] (out[1..NSLOT) = 0, so hosts that add up a
+// slot group keep working).  No atomics anywhere => results are reproducible bit for bit.
+__global__ __launch_bounds__(1024) void reduce_parts_kernel(const Scalar* __restrict__ parts, int n, Scalar* out)
+{
+	__shared__ Scalar sh[1024];
+	Scalar v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+	int i = threadIdx.x;
+	for (; i + 3072 < n; i += 4096)
+	{
+		const Scalar a = parts[i], b = parts[i + 1024], c = parts[i + 2048], d = parts[i + 3072];
+		v0 += a; v1 += b; v2 += c; v3 += d;
+	}
+	for (; i < n; i += 1024) v0 += parts[i];
+	sh[threadIdx.x] = (v0 + v1) + (v2 + v3);
+	__syncthreads();
+	for (int stride = 512; stride > 0; stride >>= 1)
+	{
+		if (threadIdx.x < stride) sh[threadIdx.x] += sh[threadIdx.x + stride];
+		__syncthreads();
+	}
+	if (threadIdx.x < NSLOT) out[threadIdx.x] = threadIdx.x == 0 ? sh[0] : Scalar(0);
+}
+
+static void launch_reduce_parts(const Scalar* parts, int n, Scalar* out, hipStream_t s)
+{
+	hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(1024), 0, s, parts, n, out);
+}
+
 // Everything a lane knows about its edge after loading + linearising it.
 struct LaneEdge
 {
@@ -132,7 +161,7 @@ __device__ __forceinline__ void linearize_edge(const DeviceGraph& g, int e, Lane
 // Replaces computeActiveErrorsKernel / computeChiSquaresKernel (cuda_block_solver.cu:733-786, 841-875):
 // no errors/Xcs are stored -- later kernels recompute them from 40 B/edge instead of re-reading 48 B/edge.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scalar* slots, Scalar* per_edge)
+__global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scalar* parts, Scalar* per_edge)
 {
 	Scalar acc = 0;
 	for (int e = g.e_begin + blockIdx.x * 256 + threadIdx.x; e < g.e_end; e += gridDim.x * 256)
@@ -156,15 +185,15 @@ __global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scala
 	__shared__ Scalar part[4];
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	if (threadIdx.x == 0) atomic_add(&slots[blockIdx.x % NSLOT], part[0] + part[1] + part[2] + part[3]);
+	if (threadIdx.x == 0) parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-void launch_residual_chi2(const DeviceGraph& g, Scalar* slots, Scalar* per_edge, hipStream_t st)
+void launch_residual_chi2(const DeviceGraph& g, Scalar* parts, Scalar* slots, Scalar* per_edge, hipStream_t st)
 {
 	const int n = g.e_end - g.e_begin;
-	if (n <= 0) return;
-	const int grid = min((n + 255) / 256, 2048);
-	hipLaunchKernelGGL(residual_chi2_kernel, dim3(grid), dim3(256), 0, st, g, slots, per_edge);
+	const int grid = n > 0 ? min((n + 255) / 256, 2048) : 0;
+	if (grid > 0) hipLaunchKernelGGL(residual_chi2_kernel, dim3(grid), dim3(256), 0, st, g, parts, per_edge);
+	launch_reduce_parts(parts, grid, slots, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1015,7 +1044,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void back_substitute_kernel(DeviceGraph 
 		sc = finish_landmark(sys, il, cs, lambda);
 	}
 	sc = wave_sum(sc);
-	if (lane == 0) atomic_add(&sys.slots[NSLOT + (wave % NSLOT)], sc);
+	if (lane == 0) sys.parts[wave] = sc;     // one partial per wave, summed by reduce_parts_kernel
 }
 
 __global__ __launch_bounds__(256) void big_back_substitute_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
@@ -1048,8 +1077,7 @@ __global__ __launch_bounds__(256) void big_back_substitute_kernel(DeviceGraph g,
 		Scalar cs[3];
 #pragma unroll
 		for (int k = 0; k < 3; k++) cs[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-		const Scalar sc = finish_landmark(sys, il, cs, lambda);
-		atomic_add(&sys.slots[NSLOT + (blockIdx.x % NSLOT)], sc);
+		sys.parts[st.nWaves + blockIdx.x] = finish_landmark(sys, il, cs, lambda);
 	}
 }
 
@@ -1063,10 +1091,11 @@ void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, con
 	}
 	if (st.nBig > 0)
 		hipLaunchKernelGGL(big_back_substitute_kernel, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+	launch_reduce_parts(sys.parts, st.nWaves + st.nBig, sys.slots + NSLOT, s);
 }
 
 // sum x (lambda x + b), pose part and (stage API only) landmark part.  Ref: computeScaleKernel :1070-1091.
-__global__ __launch_bounds__(256) void pose_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* slots)
+__global__ __launch_bounds__(256) void pose_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* parts)
 {
 	Scalar acc = 0;
 	for (int i = blockIdx.x * 256 + threadIdx.x; i < g.Pf * 6; i += gridDim.x * 256)
@@ -1075,10 +1104,10 @@ __global__ __launch_bounds__(256) void pose_scale_kernel(DeviceGraph g, DeviceSy
 		acc += x * (lambda * x + sys.bp[i]);
 	}
 	acc = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0) atomic_add(&slots[(blockIdx.x * 4 + (threadIdx.x >> 6)) % NSLOT], acc);
+	if ((threadIdx.x & 63) == 0) parts[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
 }
 
-__global__ __launch_bounds__(256) void landmark_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* slots)
+__global__ __launch_bounds__(256) void landmark_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* parts)
 {
 	Scalar acc = 0;
 	for (int i = blockIdx.x * 256 + threadIdx.x; i < g.Lf * 3; i += gridDim.x * 256)
@@ -1087,21 +1116,21 @@ __global__ __launch_bounds__(256) void landmark_scale_kernel(DeviceGraph g, Devi
 		acc += x * (lambda * x + sys.lm_sys[9 * (size_t)(i / 3) + 6 + (i % 3)]);
 	}
 	acc = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0) atomic_add(&slots[(blockIdx.x * 4 + (threadIdx.x >> 6)) % NSLOT], acc);
+	if ((threadIdx.x & 63) == 0) parts[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
 }
 
 void launch_pose_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s)
 {
-	if (g.Pf <= 0) return;
-	const int grid = min((g.Pf * 6 + 255) / 256, 256);
-	hipLaunchKernelGGL(pose_scale_kernel, dim3(grid), dim3(256), 0, s, g, sys, lambda, slots);
+	const int grid = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
+	if (grid > 0) hipLaunchKernelGGL(pose_scale_kernel, dim3(grid), dim3(256), 0, s, g, sys, lambda, sys.parts);
+	launch_reduce_parts(sys.parts, grid * 4, slots, s);
 }
 
 void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s)
 {
-	if (g.Lf <= 0) return;
-	const int grid = min((g.Lf * 3 + 255) / 256, 1024);
-	hipLaunchKernelGGL(landmark_scale_kernel, dim3(grid), dim3(256), 0, s, g, sys, lambda, slots);
+	const int grid = g.Lf > 0 ? min((g.Lf * 3 + 255) / 256, 1024) : 0;
+	if (grid > 0) hipLaunchKernelGGL(landmark_scale_kernel, dim3(grid), dim3(256), 0, s, g, sys, lambda, sys.parts);
+	launch_reduce_parts(sys.parts, grid * 4, slots, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1364,31 +1393,33 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 // The coarse matrix is dense and small (6*nc <= ~1500), so its explicit inverse is formed on the device by
 // a blocked Gauss-Jordan sweep (SPD => no pivoting) and applied as a dense mat-vec inside the PCG.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar* Ac)
+// one 64-lane wave per non-empty coarse block (I,J): lanes 0..35 own one element each and add the fine blocks of the
+// list in a fixed order (no atomics => the coarse matrix, its inverse and hence the whole CG are reproducible)
+__global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st, DeviceSystem sys, Scalar* Ac)
 {
-	extern __shared__ __attribute__((aligned(16))) Scalar rowbuf[];   // 6 x Nc, column-major
-	const int I = blockIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int cb = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (cb >= st.nCb || lane >= 36) return;
+	const int r = lane % 6, c = lane / 6;
 	const int Nc = 6 * sys.nc;
-	for (int t = threadIdx.x; t < 6 * Nc; t += 256) rowbuf[t] = 0;
-	__syncthreads();
-	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
-	const int a0 = st.adj_ptr[i0], a1 = st.adj_ptr[i1];
-	for (int w = threadIdx.x; w < (a1 - a0) * 36; w += 256)
+	Scalar acc = 0;
+	const int p1 = st.cb_ptr[cb + 1];
+	int p = st.cb_ptr[cb];
+	for (; p + 3 < p1; p += 4)
 	{
-		const int a = a0 + w / 36, el = w % 36;
-		const int r = el % 6, c = el / 6;
-		const int bi = st.adj_blk[a];
-		const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
-		const Scalar v = (bi < 0) ? B[r * 6 + c] : B[c * 6 + r];
-		const int J = st.adj_col[a] / sys.agg;
-		__hip_atomic_fetch_add(&rowbuf[(J * 6 + c) * 6 + r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const int b0 = st.cb_blk[p], b1 = st.cb_blk[p + 1], b2 = st.cb_blk[p + 2], b3 = st.cb_blk[p + 3];
+		const Scalar v0 = sys.hsc[36 * (size_t)(b0 & 0x7fffffff) + (b0 < 0 ? r * 6 + c : c * 6 + r)];
+		const Scalar v1 = sys.hsc[36 * (size_t)(b1 & 0x7fffffff) + (b1 < 0 ? r * 6 + c : c * 6 + r)];
+		const Scalar v2 = sys.hsc[36 * (size_t)(b2 & 0x7fffffff) + (b2 < 0 ? r * 6 + c : c * 6 + r)];
+		const Scalar v3 = sys.hsc[36 * (size_t)(b3 & 0x7fffffff) + (b3 < 0 ? r * 6 + c : c * 6 + r)];
+		acc += (v0 + v1) + (v2 + v3);
 	}
-	__syncthreads();
-	for (int t = threadIdx.x; t < 6 * Nc; t += 256)
+	for (; p < p1; p++)
 	{
-		const int col = t / 6, r = t % 6;
-		Ac[(size_t)col * Nc + I * 6 + r] = rowbuf[t];
+		const int b0 = st.cb_blk[p];
+		acc += sys.hsc[36 * (size_t)(b0 & 0x7fffffff) + (b0 < 0 ? r * 6 + c : c * 6 + r)];
 	}
+	Ac[(size_t)(st.cb_J[cb] * 6 + c) * Nc + st.cb_I[cb] * 6 + r] = acc;
 }
 
 constexpr int GJ_B = 24;      // pivot block width of the Gauss-Jordan sweep
@@ -1483,7 +1514,8 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s)
 {
 	const int Nc = 6 * sys.nc;
-	hipLaunchKernelGGL(coarse_assemble_kernel, dim3(sys.nc), dim3(256), sizeof(Scalar) * 6 * Nc, s, g, st, sys, work0);
+	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
+	hipLaunchKernelGGL(coarse_assemble_kernel, dim3((st.nCb + 3) / 4), dim3(256), 0, s, st, sys, work0);
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (Nc + GJ_T - 1) / GJ_T;
 	for (int p0 = 0; p0 < Nc; p0 += GJ_B)
@@ -1525,34 +1557,34 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const Scalar s_0 = doUpdate ? load_parts(sys.rz, sys.nrz0, lane) : Scalar(0);
 	const Scalar s_q = doUpdate ? load_parts(pq_slot(sys, k), sys.npq, lane) : Scalar(0);
 
-	for (int j = threadIdx.x; j < 2 * Nc; j += PCG2_T) sR[j] = 0;
-	__syncthreads();
+	// restricted sums P^T r and P^T q: thread (J, c) adds component c over the poses of aggregate J in index order
+	// (fixed order => reproducible); loads are issued in batches of 8 so that they overlap
 	const int n6 = 6 * g.Pf;
 	const int own0 = 6 * I * sys.agg, own1 = min(n6, own0 + 6 * sys.agg);
-	constexpr int SWEEP = 8;   // independent loads in flight per thread
-	for (int base = 0; base < n6; base += SWEEP * PCG2_T)
+	for (int jc = threadIdx.x; jc < Nc; jc += PCG2_T)
 	{
-		Scalar rv[SWEEP], qv[SWEEP];
-#pragma unroll
-		for (int m = 0; m < SWEEP; m++)
+		const int J = jc / 6, c = jc - 6 * J;
+		const int i0 = J * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+		Scalar sr = 0, sq = 0;
+		for (int i = i0; i < i1; i += 8)
 		{
-			const int idx = base + m * PCG2_T + threadIdx.x;
-			rv[m] = idx < n6 ? rin[idx] : Scalar(0);
-			qv[m] = (doUpdate && idx < n6) ? sys.ap[idx] : Scalar(0);
-		}
+			Scalar rv[8], qv[8];
 #pragma unroll
-		for (int m = 0; m < SWEEP; m++)
-		{
-			const int idx = base + m * PCG2_T + threadIdx.x;
-			if (idx < n6)
+			for (int m = 0; m < 8; m++)
 			{
-				const int pose = idx / 6;
-				const int slot = (pose / sys.agg) * 6 + (idx - 6 * pose);
-				if (idx >= own0 && idx < own1) { rown[idx - own0] = rv[m]; qown[idx - own0] = qv[m]; }
-				__hip_atomic_fetch_add(&sR[slot], rv[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				if (doUpdate) __hip_atomic_fetch_add(&sQ[slot], qv[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const bool in = i + m < i1;
+				const size_t idx = 6 * (size_t)(in ? i + m : i) + c;
+				rv[m] = in ? rin[idx] : Scalar(0);
+				qv[m] = (in && doUpdate) ? sys.ap[idx] : Scalar(0);
+			}
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+			{
+				sr += rv[m]; sq += qv[m];
+				if (J == I && i + m < i1) { rown[6 * (i + m - i0) + c] = rv[m]; qown[6 * (i + m - i0) + c] = qv[m]; }
 			}
 		}
+		sR[jc] = sr; sQ[jc] = sq;
 	}
 	// the part of the coarse inverse this workgroup needs (symmetric: columns 6I..6I+5 are contiguous), also early
 	Scalar ainv[6] = { 0, 0, 0, 0, 0, 0 };

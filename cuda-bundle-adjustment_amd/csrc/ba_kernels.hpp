@@ -57,6 +57,9 @@ struct DeviceStructure
 	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
 	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)
 	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
+	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
+	int nCb = 0;                       // non-empty coarse blocks
+	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo}
 };
 
@@ -68,6 +71,7 @@ struct DeviceSystem
 	Scalar* lm_sys = nullptr;  // [9*Lf]  6 unique of Hll or inv(Hll+lambda I), then bl
 	Scalar* xp = nullptr;      // [6*Pf]
 	Scalar* xl = nullptr;      // [3*Lf]
+	Scalar* parts = nullptr;   // per-workgroup partial sums (first stage of the deterministic global reductions)
 	Scalar* slots = nullptr;   // [4*NSLOT] chi2 | landmark scale (back_substitute) | per-edge chi2 scratch | stage scale
 	unsigned long long* maxdiag = nullptr;  // bit pattern of a non-negative double
 	int* fail = nullptr;       // numeric failure flag
@@ -92,7 +96,7 @@ struct DeviceSystem
 
 // residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
 // per_edge (optional, sorted edge order): non-robust omega*|r|^2.
-void launch_residual_chi2(const DeviceGraph& g, Scalar* slots, Scalar* per_edge, hipStream_t st);
+void launch_residual_chi2(const DeviceGraph& g, Scalar* parts, Scalar* slots, Scalar* per_edge, hipStream_t st);
 
 // mode 0: assemble only (Hpp -> diagonal blocks of hsc, bp, Hll/bl -> lm_sys, max diagonal of Hll)
 // mode 1: full linearise + Schur reduction with damping lambda (hsc, bsc, bp, inv(Hll+lambda)/bl -> lm_sys)

@@ -107,12 +107,13 @@ struct cuba_hip_solver
 	DevBuf<long long> d_bigOfs, d_lmPairBase;
 	DevBuf<Scalar> d_bigHpl;
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
-	DevBuf<Scalar> d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
+	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done;
 	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2;
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
+	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
 	std::vector<int> h_rowptr, h_colind;
 	Scalar* h_pinned = nullptr;   // 4*NSLOT doubles + small ints
 
@@ -254,7 +255,7 @@ struct cuba_hip_solver
 		d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream);
 		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
 		d_perEdge.resize(E);
-		d_slots.resize(4 * NSLOT); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1);
+		d_slots.resize(4 * NSLOT); d_parts.resize(4096 + (size_t)E / 2 + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1);
 		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream);
 		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
 		sync();   // host staging vectors go out of scope
@@ -447,6 +448,28 @@ struct cuba_hip_solver
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		if (nc < 2) { agg = 0; nc = 0; }
 		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc); d_r2.resize((size_t)6 * Pf);
+		// coarse-matrix assembly lists: fine blocks grouped by the coarse block (I,J) they fall into (both triangles)
+		std::vector<int> cbI, cbJ, cbPtr(1, 0), cbBlk;
+		if (nc > 0)
+		{
+			std::vector<uint64_t> ck; ck.reserve(adjBlk.size());
+			for (int i = 0; i < Pf; i++)
+				for (int a = adjPtr[i]; a < adjPtr[i + 1]; a++)
+					ck.push_back(((uint64_t)((size_t)(i / agg) * nc + adjCol[a] / agg) << 32) | (uint32_t)a);
+			std::sort(ck.begin(), ck.end());
+			for (size_t x = 0; x < ck.size(); x++)
+			{
+				const int cbid = (int)(ck[x] >> 32);
+				if (x == 0 || cbid != (int)(ck[x - 1] >> 32))
+				{
+					if (x) cbPtr.push_back((int)cbBlk.size());
+					cbI.push_back(cbid / nc); cbJ.push_back(cbid % nc);
+				}
+				cbBlk.push_back(adjBlk[(uint32_t)ck[x]]);
+			}
+			cbPtr.push_back((int)cbBlk.size());
+		}
+		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
 		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + 3) / 4;   // SPMV_ROWS
@@ -463,9 +486,10 @@ struct cuba_hip_solver
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = (int)odBlocks.size(); st.od_blocks = d_odBlocks.data();
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
+		st.nCb = (int)cbI.size(); st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
-		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = d_slots.data();
+		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = d_slots.data(); sys.parts = d_parts.data();
 		sys.maxdiag = d_maxdiag.data(); sys.fail = d_fail.data();
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
 		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data();
@@ -494,7 +518,7 @@ struct cuba_hip_solver
 		need();
 		StageTimer tm(this, 2);
 		HIP_TRY(hipMemsetAsync(d_slots.data(), 0, sizeof(Scalar) * NSLOT, stream));
-		launch_residual_chi2(g, d_slots.data(), nullptr, stream);
+		launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream);
 		return readSlots(0);
 	}
 
@@ -633,10 +657,9 @@ struct cuba_hip_solver
 	double computeScale(double lam)
 	{
 		need();
-		HIP_TRY(hipMemsetAsync(d_slots.data() + 3 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
-		launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
-		launch_landmark_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
-		return readSlots(3);
+		double a = 0, b = 0;
+		scaleParts(lam, &a, &b);
+		return a + b;
 	}
 
 	void push() { need(); HIP_TRY(hipMemcpyAsync(d_backup.data(), d_state.data(), d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, stream)); }
@@ -736,7 +759,7 @@ struct cuba_hip_solver
 			return (double)ms / reps;
 		};
 		const double lam = lambda > 0 ? lambda : 1.0;
-		msOut[0] = timeit([&] { launch_residual_chi2(g, d_slots.data(), nullptr, stream); });
+		msOut[0] = timeit([&] { launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream); });
 		d_red.zero(stream);
 		msOut[1] = timeit([&] { linearize(1, lam); });
 		// a consistent reduced system for the PCG kernels
@@ -771,7 +794,7 @@ struct cuba_hip_solver
 	{
 		need();
 		HIP_TRY(hipMemsetAsync(d_slots.data() + 2 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
-		launch_residual_chi2(g, d_slots.data() + 2 * NSLOT, d_perEdge.data(), stream);
+		launch_residual_chi2(g, d_parts.data(), d_slots.data() + 2 * NSLOT, d_perEdge.data(), stream);
 		std::vector<double> sorted(E);
 		if (E) HIP_TRY(hipMemcpyAsync(sorted.data(), d_perEdge.data(), sizeof(double) * E, hipMemcpyDeviceToHost, stream));
 		sync();
