@@ -138,9 +138,9 @@ def main():
         kernels = {k: {"ms_per_launch": kt[k], "launches": launches[k], "alg_bytes": alg[k],
                        "achieved_GBs": alg[k] / (kt[k] * 1e-3) / 1e9} for k in kt}
         # measured HBM-side traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, see
-        # profiles/r01d_kitti00_pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        # profiles/r01e_kitti00_pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01d_kitti00_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01e_kitti00_pmc_traffic.json")
         pmc_names = {"pcg_spmv": ["pcg_spmv_kernel"], "pcg_update": ["pcg2_fused_kernel"], "residual_chi2": ["residual_chi2_kernel"],
                      "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1>", "pose_pass_kernel<1>", "block_pass_kernel"]}
         if args.shape == "kitti00" and os.path.exists(pmc_path) and dom in pmc_names:
