@@ -15,6 +15,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cuba_hip.h"
@@ -186,6 +187,37 @@ struct cuba_hip_solver
 
 	void sync() { HIP_TRY(hipStreamSynchronize(stream)); }
 
+	// run fn(row) for all rows on a few host threads, rows split into contiguous chunks of similar weight
+	template <class F>
+	static void parallelRows(int nrows, const std::vector<long long>& start, F&& fn)
+	{
+		const long long total = nrows > 0 ? start[nrows] - start[0] : 0;
+		int T = (int)std::min<long long>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), total / 50000 + 1);
+		if (T <= 1) { for (int i = 0; i < nrows; i++) fn(i); return; }
+		std::vector<std::thread> th;
+		int r0 = 0;
+		for (int t = 0; t < T; t++)
+		{
+			const long long target = start[0] + total * (t + 1) / T;
+			int r1 = t == T - 1 ? nrows : (int)(std::upper_bound(start.begin(), start.begin() + nrows + 1, target) - start.begin()) - 1;
+			r1 = std::max(r1, r0);
+			th.emplace_back([=, &fn] { for (int i = r0; i < r1; i++) fn(i); });
+			r0 = r1;
+		}
+		for (auto& x : th) x.join();
+	}
+
+	// set-up phase breakdown on stderr when CUBA_HIP_DEBUG is set
+	Clock::time_point lapT;
+	void lap(const char* what)
+	{
+		static const bool on = std::getenv("CUBA_HIP_DEBUG") != nullptr;
+		if (!on) return;
+		const auto now = Clock::now();
+		if (what) std::fprintf(stderr, "[cuba_hip] %-34s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - lapT).count());
+		lapT = now;
+	}
+
 	struct StageTimer
 	{
 		cuba_hip_solver* s; int item; Clock::time_point t0;
@@ -219,6 +251,7 @@ struct cuba_hip_solver
 			if (edim[e] != 2 && edim[e] != 3) throw ArgError{ "edge_dim must be 2 or 3" };
 			if (ep[e] >= Pf && el[e] >= Lf) throw ArgError{ "edge with both ends fixed (must be dropped by the caller)" };
 		}
+		lap(nullptr);
 		// sort edges by (landmark, pose, original index): counting sort on the landmark, small sorts inside
 		h_lmptr.assign(Lt + 1, 0);
 		for (int e = 0; e < E; e++) h_lmptr[el[e] + 1]++;
@@ -231,24 +264,29 @@ struct cuba_hip_solver
 				std::sort(perm.begin() + h_lmptr[l], perm.begin() + h_lmptr[l + 1],
 					[&](int a, int b) { return ep[a] != ep[b] ? ep[a] < ep[b] : a < b; });
 		}
+		lap("set_graph: validate + sort edges");
 		std::vector<int> sPose(E), sLm(E);
 		std::vector<Scalar> mu(E), mv(E), mr(E), w(E);
 		h_epose.assign(E, 0);
-		for (int i = 0; i < E; i++)
 		{
-			const int e = perm[i];
-			h_epose[i] = ep[e];
-			sPose[i] = ep[e] | (edim[e] == 3 ? STEREO_BIT : 0);
-			sLm[i] = el[e];
-			mu[i] = meas[3 * (size_t)e]; mv[i] = meas[3 * (size_t)e + 1];
-			mr[i] = edim[e] == 3 ? meas[3 * (size_t)e + 2] : 0.0;
-			w[i] = omega[e];
+			std::vector<long long> uniform(E + 1);
+			for (int i = 0; i <= E; i++) uniform[i] = i;
+			parallelRows(E, uniform, [&](int i) {       // random gather through the sort permutation
+				const int e = perm[i];
+				h_epose[i] = ep[e];
+				sPose[i] = ep[e] | (edim[e] == 3 ? STEREO_BIT : 0);
+				sLm[i] = el[e];
+				mu[i] = meas[3 * (size_t)e]; mv[i] = meas[3 * (size_t)e + 1];
+				mr[i] = edim[e] == 3 ? meas[3 * (size_t)e + 2] : 0.0;
+				w[i] = omega[e];
+			});
 		}
 		std::vector<Scalar> state((size_t)7 * Pt + (size_t)3 * Lt);
 		if (Pt) { std::memcpy(state.data(), q, sizeof(double) * 4 * Pt); std::memcpy(state.data() + 4 * (size_t)Pt, t, sizeof(double) * 3 * Pt); }
 		if (Lt) std::memcpy(state.data() + 7 * (size_t)Pt, Xw, sizeof(double) * 3 * Lt);
 		std::vector<Scalar> camv(cam, cam + 5 * (size_t)Pt);
 
+		lap("set_graph: gather sorted arrays");
 		d_state.upload(state, stream);
 		d_backup.resize(state.size());
 		d_cam.upload(camv, stream);
@@ -260,6 +298,7 @@ struct cuba_hip_solver
 		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
 		sync();   // host staging vectors go out of scope
 
+		lap("set_graph: alloc + upload + sync");
 		g = DeviceGraph();
 		g.Pt = Pt; g.Pf = Pf; g.Lt = Lt; g.Lf = Lf; g.E = E;
 		g.q = d_state.data(); g.t = d_state.data() + 4 * (size_t)Pt; g.Xw = d_state.data() + 7 * (size_t)Pt;
@@ -302,48 +341,56 @@ struct cuba_hip_solver
 			nmul += (long long)n * (n + 1) / 2;
 		}
 		if (npairs >= (1LL << 31)) throw ArgError{ "graph too dense: more than 2^31 Schur block products" };
-		// unique (row, col) keys of the upper triangle
-		std::vector<uint64_t> keys;
-		keys.reserve((size_t)npairs + Pf);
-		for (int i = 0; i < Pf; i++) keys.push_back(((uint64_t)i << 32) | (uint32_t)i);
+		lap(nullptr);
+		// Pattern of Hsc + destination block of every product in one pass: bucket the (column, product id) pairs by
+		// block row, sort every row on its own (cache resident, rows spread over host threads), then walk the
+		// sorted rows: a new column opens a new block, every product learns its block id.
+		std::vector<long long> rowStart(Pf + 1, 0);
+		for (int i = 0; i < Pf; i++) rowStart[i + 1] = 1;                    // the diagonal block always exists
 		for (int l = 0; l < Lf; l++)
 		{
-			const int b = h_lmptr[l], n = nfree[l];
-			for (int a = 0; a < n; a++)
-				for (int c = a + 1; c < n; c++)
-					keys.push_back(((uint64_t)h_epose[b + a] << 32) | (uint32_t)h_epose[b + c]);
+			const int b0 = h_lmptr[l], n = nfree[l];
+			for (int a2 = 0; a2 < n; a2++) rowStart[h_epose[b0 + a2] + 1] += n - 1 - a2;
 		}
-		std::sort(keys.begin(), keys.end());
-		keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-		const int nblk = (int)keys.size();
-		h_rowptr.assign(Pf + 1, 0);
-		h_colind.assign(nblk, 0);
-		for (int k = 0; k < nblk; k++)
+		for (int i = 0; i < Pf; i++) rowStart[i + 1] += rowStart[i];
+		std::vector<uint64_t> ent((size_t)rowStart[Pf]);
 		{
-			h_rowptr[(keys[k] >> 32) + 1]++;
-			h_colind[k] = (int)(keys[k] & 0xffffffffu);
-		}
-		for (int i = 0; i < Pf; i++) h_rowptr[i + 1] += h_rowptr[i];
-		// destination block of every product
-		std::vector<int> pairBlk((size_t)npairs);
-		for (int l = 0; l < Lf; l++)
-		{
-			const int b = h_lmptr[l], n = nfree[l];
-			long long idx = pairBase[l];
-			for (int a = 0; a < n; a++)
+			std::vector<long long> cur(rowStart.begin(), rowStart.end() - 1);
+			for (int i = 0; i < Pf; i++) ent[cur[i]++] = (uint64_t)i << 32;   // id 0 = diagonal seed, sorts first
+			for (int l = 0; l < Lf; l++)
 			{
-				const int pa = h_epose[b + a];
-				const int* rb = h_colind.data() + h_rowptr[pa];
-				const int* re = h_colind.data() + h_rowptr[pa + 1];
-				const int* cur = rb;
-				for (int c = a + 1; c < n; c++, idx++)
+				const int b0 = h_lmptr[l], n = nfree[l];
+				long long idx = pairBase[l];
+				for (int a2 = 0; a2 < n; a2++)
 				{
-					const int pc = h_epose[b + c];
-					cur = std::lower_bound(cur, re, pc);
-					pairBlk[idx] = (int)(cur - h_colind.data()) | (pc == pa ? 0x40000000 : 0);
+					const int pa = h_epose[b0 + a2];
+					for (int c = a2 + 1; c < n; c++, idx++) ent[cur[pa]++] = ((uint64_t)h_epose[b0 + c] << 32) | (uint64_t)(idx + 1);
 				}
 			}
 		}
+		std::vector<int> rowBlocks(Pf, 0);
+		parallelRows(Pf, rowStart, [&](int i) {
+			uint64_t* e0 = ent.data() + rowStart[i]; uint64_t* e1 = ent.data() + rowStart[i + 1];
+			std::sort(e0, e1);
+			int u = 0; uint32_t last = 0xffffffffu;
+			for (uint64_t* e = e0; e < e1; e++) { const uint32_t c = (uint32_t)(*e >> 32); u += c != last; last = c; }
+			rowBlocks[i] = u;
+		});
+		h_rowptr.assign(Pf + 1, 0);
+		for (int i = 0; i < Pf; i++) h_rowptr[i + 1] = h_rowptr[i] + rowBlocks[i];
+		const int nblk = h_rowptr[Pf];
+		h_colind.assign(nblk, 0);
+		std::vector<int> pairBlk((size_t)npairs);
+		parallelRows(Pf, rowStart, [&](int i) {
+			int k = h_rowptr[i] - 1; uint32_t last = 0xffffffffu;
+			for (long long x = rowStart[i]; x < rowStart[i + 1]; x++)
+			{
+				const uint32_t c = (uint32_t)(ent[x] >> 32); const uint32_t id = (uint32_t)ent[x];
+				if (c != last) { k++; h_colind[k] = (int)c; last = c; }
+				if (id) pairBlk[id - 1] = k | ((int)c == i ? 0x40000000 : 0);
+			}
+		});
+		lap("structure: Hsc pattern + product blocks");
 		// symmetric adjacency over the upper storage
 		std::vector<int> adjPtr(Pf + 1, 0);
 		for (int i = 0; i < Pf; i++)
@@ -366,6 +413,7 @@ struct cuba_hip_solver
 			for (int i = 0; i < Pf; i++)
 				for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) { adjBlk[cur[i]] = k; adjCol[cur[i]] = h_colind[k]; cur[i]++; }
 		}
+		lap("structure: adjacency");
 		// landmark partition (multi-GPU): the PATTERN above is global, everything below covers [lo, hi) only
 		const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
 		g.e_begin = h_lmptr[lo]; g.e_end = h_lmptr[hi];
@@ -395,6 +443,7 @@ struct cuba_hip_solver
 			std::stable_sort(odBlocks.begin(), odBlocks.end(), [&](int x, int y) {
 				return prodPtr[x + 1] - prodPtr[x] > prodPtr[y + 1] - prodPtr[y]; });
 		}
+		lap("structure: product lists");
 		// per free pose: its edges (sorted-edge ids, ascending)
 		std::vector<int> pePtr(Pf + 1, 0), peEdge;
 		for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
@@ -404,6 +453,7 @@ struct cuba_hip_solver
 			std::vector<int> cur(pePtr.begin(), pePtr.end() - 1);
 			for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) peEdge[cur[h_epose[i]]++] = i;
 		}
+		lap("structure: pose edge lists");
 		// wave work list: whole landmarks, at most 64 edges per wave; larger landmarks get a workgroup each
 		std::vector<int> waveLm, bigLm;
 		std::vector<long long> bigOfs;
@@ -428,6 +478,7 @@ struct cuba_hip_solver
 			flush(hi);
 		}
 
+		lap("structure: wave list");
 		d_waveLm.upload(waveLm, stream); d_bigLm.upload(bigLm, stream); d_bigOfs.upload(bigOfs, stream);
 		d_bigHpl.resize((size_t)bigEdges * 18);
 		d_rowptr.upload(h_rowptr, stream); d_colind.upload(h_colind, stream);
@@ -448,6 +499,7 @@ struct cuba_hip_solver
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		if (nc < 2) { agg = 0; nc = 0; }
 		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc); d_r2.resize((size_t)6 * Pf);
+		lap("structure: uploads + allocs");
 		// coarse-matrix assembly lists: fine blocks grouped by the coarse block (I,J) they fall into (both triangles)
 		std::vector<int> cbI, cbJ, cbPtr(1, 0), cbBlk;
 		if (nc > 0)
@@ -477,6 +529,7 @@ struct cuba_hip_solver
 		d_rz.resize((size_t)5 * rzStride); d_pq.resize((size_t)4 * pqStride);
 		sync();
 
+		lap("structure: coarse lists + sync");
 		st = DeviceStructure();
 		st.nWaves = (int)waveLm.size() / 2; st.wave_lm = d_waveLm.data();
 		st.nBig = (int)bigLm.size(); st.big_lm = d_bigLm.data(); st.big_scratch_ofs = d_bigOfs.data(); st.big_hpl = d_bigHpl.data();

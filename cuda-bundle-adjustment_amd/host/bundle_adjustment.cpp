@@ -20,6 +20,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -35,34 +36,33 @@ const char* const kProfileKeys[CUBA_HIP_PROFILE_ITEMS] = {
 	"4: Schur Complement", "5: Symbolic Decomposition", "6: Numerical Decomposition", "7: Update Solution"
 };
 
-// insertion-ordered pointer set
+// insertion-ordered pointer set: dense vector (erased slots become null) + hash index, so that the linear sweep in
+// initialize() touches contiguous memory
 template <class T>
 class OrderedSet
 {
 public:
 	bool insert(T* p)
 	{
-		if (index_.count(p)) return false;
-		index_[p] = next_;
-		order_[next_++] = p;
+		if (!index_.emplace(p, items_.size()).second) return false;
+		items_.push_back(p);
 		return true;
 	}
 	bool erase(T* p)
 	{
 		auto it = index_.find(p);
 		if (it == index_.end()) return false;
-		order_.erase(it->second);
+		items_[it->second] = nullptr;
 		index_.erase(it);
 		return true;
 	}
 	bool contains(T* p) const { return index_.count(p) != 0; }
 	size_t size() const { return index_.size(); }
-	void clear() { index_.clear(); order_.clear(); next_ = 0; }
-	const std::map<uint64_t, T*>& ordered() const { return order_; }
+	void clear() { index_.clear(); items_.clear(); }
+	const std::vector<T*>& slots() const { return items_; }   // may contain nullptr
 private:
-	std::unordered_map<T*, uint64_t> index_;
-	std::map<uint64_t, T*> order_;
-	uint64_t next_ = 0;
+	std::unordered_map<T*, size_t> index_;
+	std::vector<T*> items_;
 };
 
 class HipBundleAdjustment final : public CudaBundleAdjustment
@@ -136,6 +136,7 @@ public:
 	void initialize() override
 	{
 		const auto t0 = std::chrono::steady_clock::now();
+		buildChiIndex();                 // results of the previous optimize() stay queryable (they refer to the old edge list)
 		activePoses_.clear(); activeLandmarks_.clear(); activeEdges_.clear();
 		q_.clear(); t_.clear(); cam_.clear(); Xw_.clear();
 		edgePose_.clear(); edgeLandmark_.clear(); edgeDim_.clear(); meas_.clear(); omega_.clear();
@@ -175,19 +176,56 @@ public:
 			v->iL = static_cast<int>(i);
 			Xw_.insert(Xw_.end(), v->Xw.data(), v->Xw.data() + 3);
 		}
-		auto addEdge = [&](BaseEdge* e, const double* m, int dim, double info) {
-			PoseVertex* p = e->poseVertex();
-			LandmarkVertex* l = e->landmarkVertex();
-			if (p->fixed && l->fixed) return;               // inactive edge (ref :209-221)
-			activeEdges_.push_back(e);
-			edgePose_.push_back(p->iP);
-			edgeLandmark_.push_back(l->iL);
-			edgeDim_.push_back(static_cast<uint8_t>(dim));
-			meas_.push_back(m[0]); meas_.push_back(m[1]); meas_.push_back(dim == 3 ? m[2] : 0.0);
-			omega_.push_back(info);
+		// edges: mono first, then stereo, insertion order inside each type; edges with both ends fixed are inactive
+		// (ref :204-243).  561 k edges mean 561 k dependent pointer loads (edge -> vertex -> index), so the sweep is
+		// split over a few host threads: count the active edges per chunk, prefix-sum, fill.
+		const auto& ms = mono_.slots();
+		const auto& ss = stereo_.slots();
+		const size_t nM = ms.size(), nAll = nM + ss.size();
+		auto edgeAt = [&](size_t k) -> BaseEdge* { return k < nM ? static_cast<BaseEdge*>(ms[k]) : static_cast<BaseEdge*>(ss[k - nM]); };
+		auto isActive = [&](BaseEdge* e) { return e && !(e->poseVertex()->fixed && e->landmarkVertex()->fixed); };
+		const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), nAll / 20000 + 1));
+		std::vector<size_t> cnt(T + 1, 0);
+		auto chunk = [&](unsigned t) { return std::make_pair(nAll * t / T, nAll * (t + 1) / T); };
+		auto forThreads = [&](auto&& fn) {
+			if (T == 1) { fn(0u); return; }
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t);
+			for (auto& x : th) x.join();
 		};
-		for (const auto& kv : mono_.ordered()) addEdge(kv.second, kv.second->measurement.data(), 2, kv.second->information);
-		for (const auto& kv : stereo_.ordered()) addEdge(kv.second, kv.second->measurement.data(), 3, kv.second->information);
+		forThreads([&](unsigned t) {
+			size_t c = 0;
+			for (size_t k = chunk(t).first; k < chunk(t).second; k++) c += isActive(edgeAt(k));
+			cnt[t + 1] = c;
+		});
+		for (unsigned t = 0; t < T; t++) cnt[t + 1] += cnt[t];
+		const size_t nAct = cnt[T];
+		activeEdges_.resize(nAct); edgePose_.resize(nAct); edgeLandmark_.resize(nAct); edgeDim_.resize(nAct);
+		meas_.resize(3 * nAct); omega_.resize(nAct);
+		forThreads([&](unsigned t) {
+			size_t o = cnt[t];
+			for (size_t k = chunk(t).first; k < chunk(t).second; k++)
+			{
+				BaseEdge* e = edgeAt(k);
+				if (!isActive(e)) continue;
+				activeEdges_[o] = e;
+				edgePose_[o] = e->poseVertex()->iP;
+				edgeLandmark_[o] = e->landmarkVertex()->iL;
+				if (k < nM)
+				{
+					const MonoEdge* m = ms[k];
+					edgeDim_[o] = 2; meas_[3 * o] = m->measurement[0]; meas_[3 * o + 1] = m->measurement[1]; meas_[3 * o + 2] = 0.0;
+					omega_[o] = m->information;
+				}
+				else
+				{
+					const StereoEdge* m = ss[k - nM];
+					edgeDim_[o] = 3; meas_[3 * o] = m->measurement[0]; meas_[3 * o + 1] = m->measurement[1]; meas_[3 * o + 2] = m->measurement[2];
+					omega_[o] = m->information;
+				}
+				o++;
+			}
+		});
 
 		stats_.clear();
 		graphDirty_ = true;
@@ -232,10 +270,10 @@ public:
 			for (int k = 0; k < 3; k++) activeLandmarks_[i]->Xw.data()[k] = Xw_[3 * i + k];
 
 		// per-edge chi2 (ref getChiSqs :528-543)
-		std::vector<double> perEdge(activeEdges_.size());
-		check(cuba_hip_chi_squares(solver_, perEdge.data()), "cuba_hip_chi_squares");
+		perEdgeChi_.resize(activeEdges_.size());
+		check(cuba_hip_chi_squares(solver_, perEdgeChi_.data()), "cuba_hip_chi_squares");
 		chiSqs_.clear();
-		for (size_t i = 0; i < activeEdges_.size(); i++) chiSqs_[activeEdges_[i]] = perEdge[i];
+		chiIndexBuilt_ = false;          // the edge -> value index is built on the first chiSquared() query
 
 		double prof[CUBA_HIP_PROFILE_ITEMS];
 		check(cuba_hip_get_profile(solver_, prof), "cuba_hip_get_profile");
@@ -256,11 +294,20 @@ public:
 
 	double chiSquared(const BaseEdge* e) const override
 	{
+		buildChiIndex();
 		auto it = chiSqs_.find(e);
 		return it == chiSqs_.end() ? 0.0 : it->second;
 	}
 
 private:
+	void buildChiIndex() const
+	{
+		if (chiIndexBuilt_) return;
+		chiSqs_.reserve(perEdgeChi_.size());
+		for (size_t i = 0; i < perEdgeChi_.size(); i++) chiSqs_[activeEdges_[i]] = perEdgeChi_[i];
+		chiIndexBuilt_ = true;
+	}
+
 	void check(int status, const char* what) const
 	{
 		if (status == CUBA_HIP_OK) return;
@@ -291,7 +338,9 @@ private:
 	cuba_hip_solver* solver_ = nullptr;
 	BatchStatistics stats_;
 	TimeProfile timeProfile_;
-	std::unordered_map<const BaseEdge*, double> chiSqs_;
+	std::vector<double> perEdgeChi_;
+	mutable std::unordered_map<const BaseEdge*, double> chiSqs_;
+	mutable bool chiIndexBuilt_ = true;
 };
 
 }  // namespace
