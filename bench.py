@@ -61,12 +61,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; the modulo only matters for dry runs of the N > 1 code path on a box with fewer GPUs
+    # (CUBA_BENCH_BACKEND=gloo, several ranks sharing a device) -- RCCL itself needs distinct devices
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
+    backend = os.environ.get("CUBA_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from cuba_amd.capi import HipSolver
     from cuba_amd.graph import flatten
@@ -76,7 +83,7 @@ def main():
     partitioned = args.partition and world > 1
     seed = SHAPES[args.shape]["seed"] if (world == 1 or partitioned) else 100 + rank
     fp = flatten(synth_named(args.shape, seed=seed))
-    solver = HipSolver(fp, rk, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    solver = HipSolver(fp, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
     backend = comm = None
     if partitioned:
         from cuba_amd.dist import HipPartitionBackend, TorchComm, partitioned_optimize
@@ -112,7 +119,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     c1 = solver.counters()
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

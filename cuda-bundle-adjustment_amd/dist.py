@@ -48,24 +48,33 @@ class TorchComm:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.device = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
 
-    def _as_tensor(self, a):
+    def _stage(self, a):
+        """tensor the backend can work on (+ whether the result has to be copied back into `a`)"""
         if isinstance(a, np.ndarray):
             t = self.torch.from_numpy(a)
-            return t if self.device == "cpu" else t.to(self.device)
-        return a
+            return (t, False) if self.device == "cpu" else (t.to(self.device), True)
+        if self.device == "cpu" and a.is_cuda:          # gloo dry runs with device buffers: stage through the host
+            return a.cpu(), True
+        return a, False
+
+    def _unstage(self, a, t):
+        if isinstance(a, np.ndarray):
+            a[...] = t.cpu().numpy()
+        else:
+            a.copy_(t)
 
     def allreduce_sum_(self, a):
-        t = self._as_tensor(a)
+        t, back = self._stage(a)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        if isinstance(a, np.ndarray) and self.device != "cpu":
-            a[...] = t.cpu().numpy()
+        if back:
+            self._unstage(a, t)
         return a
 
     def bcast_(self, a, root=0):
-        t = self._as_tensor(a)
+        t, back = self._stage(a)
         self.dist.broadcast(t, src=root, group=self.group)
-        if isinstance(a, np.ndarray) and self.device != "cpu":
-            a[...] = t.cpu().numpy()
+        if back:
+            self._unstage(a, t)
         return a
 
     def _scalar(self, v, op):
