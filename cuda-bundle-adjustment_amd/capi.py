@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcuba_hip.so")
+LIB_PATH_F32 = os.path.join(CSRC, "libcuba_hip_f32.so")     # single-precision build (the reference's USE_FLOAT32 option)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "cuba_hip.h")
 
 _dp = C.POINTER(C.c_double)
@@ -38,20 +39,20 @@ def build_library(force=False):
     """Compile csrc/*.hip for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + [HEADER]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "libcuba_hip.so"])
+    if force or stale or not os.path.exists(LIB_PATH_F32):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "all"])
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise CubaHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+def load_library(precision="f64"):
+    path = {"f64": LIB_PATH, "f32": LIB_PATH_F32}[precision]
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise CubaHipError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     if os.environ.get("CUBA_HIP_NO_TORCH") != "1":
         # PyTorch wheels bundle their own libamdhip64; whichever HIP runtime is loaded first serves the whole
         # process.  Loading torch's first keeps torch.cuda (streams, torch.distributed/RCCL) usable next to this
@@ -60,7 +61,7 @@ def load_library():
             import torch  # noqa: F401
         except Exception:      # pragma: no cover
             pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     H = C.c_void_p
     sig = {
         "cuba_hip_create": [C.c_int, C.POINTER(H)],
@@ -106,7 +107,8 @@ def load_library():
     lib.cuba_hip_last_error.argtypes = [H]
     lib.cuba_hip_last_error.restype = C.c_char_p
     lib.cuba_hip_version.restype = C.c_char_p
-    _lib = lib
+    lib.cuba_hip_scalar_size.restype = C.c_int
+    _libs[path] = lib
     return lib
 
 
@@ -128,8 +130,9 @@ def _close_all():
 class HipSolver:
     """One bundle-adjustment problem on one GPU, driven through the C ABI."""
 
-    def __init__(self, fp=None, robust=((0, 0.0), (0, 0.0)), device=0, stream=None, **options):
-        self.lib = load_library()
+    def __init__(self, fp=None, robust=((0, 0.0), (0, 0.0)), device=0, stream=None, precision="f64", **options):
+        self.lib = load_library(precision)
+        self.scalar_size = self.lib.cuba_hip_scalar_size()
         self.h = C.c_void_p()
         rc = self.lib.cuba_hip_create(int(device), C.byref(self.h))
         if rc != 0:

@@ -33,7 +33,7 @@ __device__ __forceinline__ void atomic_add(Scalar* p, Scalar v)
 __device__ __forceinline__ void atomic_max_nonneg(unsigned long long* p, Scalar v)
 {
 	// IEEE-754 ordering of non-negative doubles equals the ordering of their bit patterns
-	if (v > 0) atomicMax(p, (unsigned long long)__double_as_longlong(v));
+	if (v > 0) atomicMax(p, (unsigned long long)__double_as_longlong((double)v));   // always compared as doubles
 }
 
 __device__ __forceinline__ Scalar wave_sum(Scalar v)

@@ -11,7 +11,13 @@
 namespace cubahip
 {
 
+// fp64 by default; -DCUBA_HIP_FLOAT32 builds the single-precision variant (the reference's USE_FLOAT32 option,
+// /root/reference/src/scalar.h:25-29).  The C ABI stays double at the boundary in both builds.
+#ifdef CUBA_HIP_FLOAT32
+using Scalar = float;
+#else
 using Scalar = double;
+#endif
 
 constexpr int PDIM = 6;   // se(3) increment [rotation; translation]
 constexpr int LDIM = 3;

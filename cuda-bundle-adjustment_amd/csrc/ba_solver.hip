@@ -85,7 +85,7 @@ struct cuba_hip_solver
 	std::string lastError;
 
 	// options
-	double pcgTol = 1e-8;        // relative M^-1-norm residual; the objective is second-order in the solve error
+	double pcgTol = sizeof(Scalar) == 8 ? 1e-8 : 1e-4;       // relative M^-1-norm residual; the objective is second-order in the solve error
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 32;
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
@@ -187,6 +187,29 @@ struct cuba_hip_solver
 
 	void sync() { HIP_TRY(hipStreamSynchronize(stream)); }
 
+	// host double <-> device Scalar transfers (plain copies in the fp64 build, staged conversion in the fp32 build)
+	void downloadAsDouble(const Scalar* dsrc, double* hdst, size_t n)
+	{
+		if (!n) return;
+		if (sizeof(Scalar) == sizeof(double))
+		{
+			HIP_TRY(hipMemcpyAsync(hdst, dsrc, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+			sync();
+			return;
+		}
+		std::vector<Scalar> tmp(n);
+		HIP_TRY(hipMemcpyAsync(tmp.data(), dsrc, n * sizeof(Scalar), hipMemcpyDeviceToHost, stream));
+		sync();
+		for (size_t i = 0; i < n; i++) hdst[i] = (double)tmp[i];
+	}
+	void uploadFromDouble(Scalar* ddst, const double* hsrc, size_t n)
+	{
+		if (!n) return;
+		std::vector<Scalar> tmp(hsrc, hsrc + n);
+		HIP_TRY(hipMemcpyAsync(ddst, tmp.data(), n * sizeof(Scalar), hipMemcpyHostToDevice, stream));
+		sync();
+	}
+
 	// run fn(row) for all rows on a few host threads, rows split into contiguous chunks of similar weight
 	template <class F>
 	static void parallelRows(int nrows, const std::vector<long long>& start, F&& fn)
@@ -282,8 +305,9 @@ struct cuba_hip_solver
 			});
 		}
 		std::vector<Scalar> state((size_t)7 * Pt + (size_t)3 * Lt);
-		if (Pt) { std::memcpy(state.data(), q, sizeof(double) * 4 * Pt); std::memcpy(state.data() + 4 * (size_t)Pt, t, sizeof(double) * 3 * Pt); }
-		if (Lt) std::memcpy(state.data() + 7 * (size_t)Pt, Xw, sizeof(double) * 3 * Lt);
+		for (size_t i = 0; i < (size_t)4 * Pt; i++) state[i] = (Scalar)q[i];
+		for (size_t i = 0; i < (size_t)3 * Pt; i++) state[4 * (size_t)Pt + i] = (Scalar)t[i];
+		for (size_t i = 0; i < (size_t)3 * Lt; i++) state[7 * (size_t)Pt + i] = (Scalar)Xw[i];
 		std::vector<Scalar> camv(cam, cam + 5 * (size_t)Pt);
 
 		lap("set_graph: gather sorted arrays");
@@ -295,7 +319,7 @@ struct cuba_hip_solver
 		d_perEdge.resize(E);
 		d_slots.resize(4 * NSLOT); d_parts.resize(4096 + (size_t)E / 2 + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1);
 		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream);
-		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, sizeof(Scalar) * (4 * NSLOT + 8)));
+		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, 2048));   // viewed as Scalar[], double[] or int[] by the readers below
 		sync();   // host staging vectors go out of scope
 
 		lap("set_graph: alloc + upload + sync");
@@ -595,17 +619,18 @@ struct cuba_hip_solver
 	void maxDiagonalParts(double* posePart, double* lmPart)
 	{
 		need();
+		const double* hD = (const double*)h_pinned;      // maxdiag slots hold bit patterns of non-negative doubles
 		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
 		double v = 0;
-		for (int i = 0; i < 64; i++) v = std::max(v, h_pinned[i]);
+		for (int i = 0; i < 64; i++) v = std::max(v, hD[i]);
 		*lmPart = v;
 		d_maxdiag.zero(stream);
 		launch_pose_maxdiag(g, st, sys, stream);
 		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
 		v = 0;
-		for (int i = 0; i < 64; i++) v = std::max(v, h_pinned[i]);
+		for (int i = 0; i < 64; i++) v = std::max(v, hD[i]);
 		*posePart = v;
 	}
 
@@ -633,7 +658,7 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
 		double v = 0;   // bit patterns of non-negative doubles are doubles again
-		for (int i = 0; i < 64; i++) v = std::max(v, h_pinned[i]);
+		for (int i = 0; i < 64; i++) v = std::max(v, ((const double*)h_pinned)[i]);
 		return v;
 	}
 
@@ -662,7 +687,7 @@ struct cuba_hip_solver
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
 		const int chunk = 2 * ((std::max(1, pcgCheckEvery) + 1) / 2);   // even: the kernels take k's parity from the chunk-local index
-		int* hInts = (int*)(h_pinned + 2 * NSLOT);
+		int* hInts = (int*)((char*)h_pinned + 1024);
 		bool converged = false;
 		if (useGraph && (!pcgGraphExec || pcgGraphChunk != chunk || pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter || pcgGraphAcinv != sys.acinv))
 			buildPcgGraph(chunk, maxIter, tol2);
@@ -849,7 +874,7 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemsetAsync(d_slots.data() + 2 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
 		launch_residual_chi2(g, d_parts.data(), d_slots.data() + 2 * NSLOT, d_perEdge.data(), stream);
 		std::vector<double> sorted(E);
-		if (E) HIP_TRY(hipMemcpyAsync(sorted.data(), d_perEdge.data(), sizeof(double) * E, hipMemcpyDeviceToHost, stream));
+		downloadAsDouble(d_perEdge.data(), sorted.data(), (size_t)E);
 		sync();
 		for (int i = 0; i < E; i++) out[perm[i]] = sorted[i];
 	}
@@ -887,7 +912,8 @@ int guarded(cuba_hip_solver* s, F&& f)
 
 extern "C" {
 
-const char* cuba_hip_version(void) { return "cuba-hip 0.1 (gfx950, fp64)"; }
+const char* cuba_hip_version(void) { return sizeof(Scalar) == 8 ? "cuba-hip 0.1 (gfx950, fp64)" : "cuba-hip 0.1 (gfx950, fp32)"; }
+int cuba_hip_scalar_size(void) { return (int)sizeof(Scalar); }
 
 int cuba_hip_create(int device, cuba_hip_solver** out)
 {
@@ -953,7 +979,7 @@ int cuba_hip_set_robust_kernel(cuba_hip_solver* s, int edge_type, int kind, doub
 {
 	return guarded(s, [&] {
 		if (edge_type < 0 || edge_type > 1 || kind < 0 || kind > 2) throw ArgError{ "bad robust kernel" };
-		s->rk[edge_type] = RobustKernel{ kind, delta };
+		s->rk[edge_type] = RobustKernel{ kind, (Scalar)delta };
 	});
 }
 
@@ -1015,10 +1041,9 @@ int cuba_hip_get_solution(cuba_hip_solver* s, double* q, double* t, double* Xw)
 	return guarded(s, [&] {
 		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
 		const Scalar* base = s->d_state.data();
-		if (q && s->Pt) HIP_TRY(hipMemcpyAsync(q, base, sizeof(double) * 4 * s->Pt, hipMemcpyDeviceToHost, s->stream));
-		if (t && s->Pt) HIP_TRY(hipMemcpyAsync(t, base + 4 * (size_t)s->Pt, sizeof(double) * 3 * s->Pt, hipMemcpyDeviceToHost, s->stream));
-		if (Xw && s->Lt) HIP_TRY(hipMemcpyAsync(Xw, base + 7 * (size_t)s->Pt, sizeof(double) * 3 * s->Lt, hipMemcpyDeviceToHost, s->stream));
-		s->sync();
+		if (q) s->downloadAsDouble(base, q, (size_t)4 * s->Pt);
+		if (t) s->downloadAsDouble(base + 4 * (size_t)s->Pt, t, (size_t)3 * s->Pt);
+		if (Xw) s->downloadAsDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
 	});
 }
 
@@ -1027,10 +1052,9 @@ int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, 
 	return guarded(s, [&] {
 		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
 		Scalar* base = s->d_state.data();
-		if (q && s->Pt) HIP_TRY(hipMemcpyAsync(base, q, sizeof(double) * 4 * s->Pt, hipMemcpyHostToDevice, s->stream));
-		if (t && s->Pt) HIP_TRY(hipMemcpyAsync(base + 4 * (size_t)s->Pt, t, sizeof(double) * 3 * s->Pt, hipMemcpyHostToDevice, s->stream));
-		if (Xw && s->Lt) HIP_TRY(hipMemcpyAsync(base + 7 * (size_t)s->Pt, Xw, sizeof(double) * 3 * s->Lt, hipMemcpyHostToDevice, s->stream));
-		s->sync();
+		if (q) s->uploadFromDouble(base, q, (size_t)4 * s->Pt);
+		if (t) s->uploadFromDouble(base + 4 * (size_t)s->Pt, t, (size_t)3 * s->Pt);
+		if (Xw) s->uploadFromDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
 	});
 }
 
@@ -1075,7 +1099,7 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
 		default: throw ArgError{ "unknown array id" };
 		}
 		if (count) *count = n;
-		if (out && n) { HIP_TRY(hipMemcpyAsync(out, src, n * sizeof(double), hipMemcpyDeviceToHost, s->stream)); s->sync(); }
+		if (out && n) s->downloadAsDouble(src, out, n);
 	});
 }
 

@@ -149,8 +149,8 @@ class ThreadComm:
 # HIP backend: one solver handle restricted to a landmark range
 # ---------------------------------------------------------------------------------------------------
 class _DeviceArray:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, n, itemsize=8):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f%d" % itemsize, "data": (ptr, False), "version": 2}
 
 
 class HipPartitionBackend:
@@ -161,9 +161,9 @@ class HipPartitionBackend:
         solver.set_partition(*self.range)
         solver.build_structure()
         ptr, n = solver.reduction_buffer()
-        self.red = torch.as_tensor(_DeviceArray(ptr, n), device="cuda")
+        self.red = torch.as_tensor(_DeviceArray(ptr, n, solver.scalar_size), device="cuda")
         ptr, n = solver.device_pointer("xp")
-        self.xp = torch.as_tensor(_DeviceArray(ptr, n), device="cuda") if n else None
+        self.xp = torch.as_tensor(_DeviceArray(ptr, n, solver.scalar_size), device="cuda") if n else None
         self._torch = torch
 
     def _sync(self):

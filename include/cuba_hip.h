@@ -72,6 +72,10 @@ int cuba_hip_create(int device, cuba_hip_solver** out);
 int cuba_hip_destroy(cuba_hip_solver* s);
 const char* cuba_hip_last_error(const cuba_hip_solver* s);
 const char* cuba_hip_version(void);
+/* 8 for libcuba_hip.so, 4 for libcuba_hip_f32.so (the reference's USE_FLOAT32 build option, src/scalar.h:25-29):
+   element size of the device arrays behind cuba_hip_device_pointer / cuba_hip_reduction_buffer.  Host-side
+   arguments of every entry point are double in both builds. */
+int cuba_hip_scalar_size(void);
 
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);

@@ -84,10 +84,13 @@ def test_capi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "cuba_hip.h")).read()
     declared = sorted(set(re.findall(r"^(?:int|const char\*)\s+(cuba_hip_[a-z_0-9]+)\s*\(", header, re.M)))
     assert len(declared) >= 30
-    lib = ctypes.CDLL(capi.build_library())
-    for name in declared:
-        assert hasattr(lib, name), f"{name} declared in cuba_hip.h but not exported"
-    capi.load_library()
+    capi.build_library()
+    for path in (capi.LIB_PATH, capi.LIB_PATH_F32):          # fp64 build and the USE_FLOAT32-style fp32 build
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), f"{name} declared in cuba_hip.h but not exported by {path}"
+    assert capi.load_library("f64").cuba_hip_scalar_size() == 8
+    assert capi.load_library("f32").cuba_hip_scalar_size() == 4
 
 
 def test_capi_fails_loudly_without_gpu():
