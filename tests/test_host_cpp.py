@@ -60,3 +60,53 @@ def test_sample_binaries_match_python_path(tmp_path):
         assert out.returncode == 0, out.stdout + out.stderr
         got2 = np.array([float(m) for m in re.findall(r"iter:\s*\d+, chi2: ([0-9.]+)", out.stdout)])
         assert len(got2) == len(want2) and np.all(np.abs(got2 - want2) <= 0.06 + 1e-9 * want2)   # printed with %.1f
+
+
+def _local_ba_flow(g, make_solver, fix_every=3, iters1=5, iters2=10):
+    """ORB-SLAM2-style local BA through flat arrays: fixed keyframes, robust stage, chi2 outlier rejection,
+    edge removal + re-initialize, plain stage (mirrors host/samples/local_ba_flow.cpp)."""
+    import copy
+    from conftest import RK_NONE
+    from cuba_amd.graph import flatten, write_back
+    g = copy.deepcopy(g)
+    g.pose_fixed |= (g.pose_ids % fix_every == 0)
+    fp = flatten(g)
+    s1 = make_solver(fp, RK_HUBER)
+    chi_a = s1.optimize(iters1)["chi2"]
+    write_back(g, fp, *s1.state())
+    per_edge = np.zeros(g.nedges)                    # inactive (fixed-fixed) edges report 0, as chiSquared() does
+    per_edge[fp.edge_src] = s1.chi_squares()
+    E2 = len(g.mono_vp)
+    keep_m = per_edge[:E2] <= 5.991
+    keep_s = per_edge[E2:] <= 7.815
+    removed = int((~keep_m).sum() + (~keep_s).sum())
+    g.mono_vp, g.mono_vl, g.mono_meas, g.mono_info = g.mono_vp[keep_m], g.mono_vl[keep_m], g.mono_meas[keep_m], g.mono_info[keep_m]
+    g.stereo_vp, g.stereo_vl, g.stereo_meas, g.stereo_info = (g.stereo_vp[keep_s], g.stereo_vl[keep_s], g.stereo_meas[keep_s],
+                                                              g.stereo_info[keep_s])
+    fp2 = flatten(g)
+    chi_b = make_solver(fp2, RK_NONE).optimize(iters2)["chi2"]
+    return chi_a, removed, chi_b
+
+
+@pytest.mark.gpu
+def test_local_ba_flow_cpp_api_vs_c_abi_vs_oracle(tmp_path):
+    """removeEdge / chiSquared / fixed keyframes / re-initialize through the C++ API."""
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.synth import synth_ba
+    from oracle.oracle import OracleSolver
+    g = synth_ba(120, 6000, 24000, seed=9)
+    path = str(tmp_path / "graph.json")
+    g.to_json(path)
+    exe = os.path.join(HOST, "samples", "local_ba_flow")
+    out = subprocess.run([exe, path, "3", "5", "10"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got_a = np.array([float(m) for m in re.findall(r"stage1 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
+    got_b = np.array([float(m) for m in re.findall(r"stage2 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
+    got_removed = int(re.search(r"removed (\d+) of", out.stdout).group(1))
+    hip_a, hip_removed, hip_b = _local_ba_flow(g, lambda fp, rk: HipSolver(fp, rk))
+    ora_a, ora_removed, ora_b = _local_ba_flow(g, lambda fp, rk: OracleSolver(fp, rk))
+    assert got_removed == hip_removed == ora_removed and got_removed > 100
+    assert len(got_a) == len(hip_a) and np.all(np.abs(got_a - hip_a) <= 1e-9 * hip_a)      # C++ API == C ABI path (bitwise in practice)
+    assert len(got_b) == len(hip_b) and np.all(np.abs(got_b - hip_b) <= 1e-9 * hip_b)
+    assert np.all(np.abs(hip_a - ora_a) <= 1e-6 * ora_a) and np.all(np.abs(hip_b - ora_b) <= 1e-6 * ora_b)   # vs exact-solve oracle
+    assert got_b[-1] < 0.5 * got_a[-1]                  # the outliers carried most of the robust objective
