@@ -89,6 +89,8 @@ struct cuba_hip_solver
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 32;
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
+	int coarseMaxAge = 2;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
+	                             // changes the iteration count only); refreshed early when the count degrades
 	bool schurAtomic = false;    // true: first-generation landmark-major Schur kernel with fp64 atomics (A/B runs)
 	bool profile = false;
 
@@ -170,6 +172,9 @@ struct cuba_hip_solver
 		pcgGraphTol2 = tol2; pcgGraphMaxIter = maxIter; pcgGraphAcinv = sys.acinv;
 	}
 	Scalar pcgGraphTol2 = 0; int pcgGraphMaxIter = 0; const Scalar* pcgGraphAcinv = nullptr;
+
+	bool coarseValid = false, coarseFresh = false;
+	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
 
 	double lambda = 0;
 	int maxIterAlloc = 0;
@@ -573,6 +578,7 @@ struct cuba_hip_solver
 		dropPcgGraph();
 		sys.rzStride = rzStride; sys.pqStride = pqStride; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
+		coarseValid = false;
 		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -683,7 +689,14 @@ struct cuba_hip_solver
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
-			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
+			const bool refresh = !coarseValid || coarseAge >= coarseMaxAge || lastSolveIters > itersAtRefresh + itersAtRefresh / 4 + 8;
+			if (refresh)
+			{
+				launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
+				coarseValid = true; coarseAge = 0;
+			}
+			else coarseAge++;
+			coarseFresh = refresh;
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
 		const int chunk = 2 * ((std::max(1, pcgCheckEvery) + 1) / 2);   // even: the kernels take k's parity from the chunk-local index
@@ -700,10 +713,12 @@ struct cuba_hip_solver
 			HIP_TRY(hipMemcpyAsync(hInts + 1, d_iters.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts + 2, d_done.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			sync();
-			if (hInts[0] != 0) { cntPcgIters += hInts[1]; return false; }
+			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; return false; }
 			if (hInts[2] != 0 || hInts[1] < k1) converged = true;   // the device-side stop test fired
 		}
 		cntPcgIters += hInts[1];
+		lastSolveIters = hInts[1];
+		if (coarseFresh) itersAtRefresh = hInts[1];
 		return true;   // hitting max_iter returns the best iterate, like an inexact LM step
 	}
 
@@ -747,13 +762,15 @@ struct cuba_hip_solver
 	int optimize(int niter, double* chi2Out)
 	{
 		need();
+		coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
 		const int maxq = 10;
 		const double tau = 1e-5;
 		double nu = 2, lam = 0, F = 0;
 		int done = 0;
+		bool haveF = false;           // after an accepted step the objective at the new estimate is already known
 		for (int it = 0; it < niter; it++)
 		{
-			F = computeErrors();
+			if (!haveF) F = computeErrors();
 			if (it == 0) lam = tau * maxDiagonal();
 			int qn = 0;
 			double rho = -1;
@@ -764,9 +781,8 @@ struct cuba_hip_solver
 				lambda = lam;
 				const bool ok = solve();
 				if (ok) update();
-				const double Fhat = computeErrors();
-				double scale = 0;
-				if (ok) scale = scaleOfLastSolve(lam);
+				double Fhat = 0, scale = 0;
+				evaluateTrial(lam, ok, &Fhat, &scale);      // chi2 at the trial estimate + gain-ratio denominator, one host sync
 				scale += 1e-3;
 				rho = ok ? (F - Fhat) / scale : -1;
 				if (rho > 0)
@@ -775,6 +791,7 @@ struct cuba_hip_solver
 					lam *= std::max(1. / 3, std::min(a, 2. / 3));
 					nu = 2;
 					F = Fhat;
+					haveF = true;
 					break;
 				}
 				else
@@ -782,6 +799,7 @@ struct cuba_hip_solver
 					lam *= nu;
 					nu *= 2;
 					pop();
+					haveF = true;      // F still describes the restored estimate
 				}
 			}
 			if (chi2Out) chi2Out[it] = F;
@@ -790,6 +808,18 @@ struct cuba_hip_solver
 		}
 		lambda = lam;
 		return done;
+	}
+
+	// chi2 of the trial estimate and sum x (lambda x + b) of the step that led to it, read back with ONE synchronisation
+	void evaluateTrial(double lam, bool withScale, double* Fhat, double* scale)
+	{
+		StageTimer tm(this, 2);
+		launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream);
+		if (withScale) launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
+		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data(), sizeof(Scalar) * 4 * NSLOT, hipMemcpyDeviceToHost, stream));
+		sync();
+		*Fhat = (double)h_pinned[0];
+		*scale = withScale ? (double)h_pinned[NSLOT] + (double)h_pinned[3 * NSLOT] : 0.0;   // landmark part (back_substitute) + pose part
 	}
 
 	// Fused version used by optimize(): the landmark part was accumulated by back_substitute (same lambda),
@@ -962,6 +992,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "schur_atomic") s->schurAtomic = value != 0;
+		else if (k == "coarse_max_age") s->coarseMaxAge = std::max(0, (int)value);
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
