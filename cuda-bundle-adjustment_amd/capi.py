@@ -49,6 +49,7 @@ _libs = {}
 
 def load_library(precision="f64"):
     path = {"f64": LIB_PATH, "f32": LIB_PATH_F32}[precision]
+    path = os.environ.get("CUBA_HIP_LIB_" + precision.upper(), path)     # e.g. the stage-timestamp build (make libcuba_hip_trace.so)
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):

@@ -22,6 +22,19 @@
 namespace cubahip
 {
 
+// Stage timestamps for latency studies (scripts/trace_pcg.py): only in the separate libcuba_hip_trace.so build.
+#ifdef CUBA_HIP_TRACE
+__device__ unsigned long long cuba_trace_buf[2][8192 * 8];
+#define TRACE_DECL unsigned long long tr_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int trn_ = 0;
+#define TRACE_MARK() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr_[trn_++] = wall_clock64(); } while (0)
+#define TRACE_FLUSH(kid, wave) do { if ((threadIdx.x & 63) == 0 && (wave) < 8192) for (int t_ = 0; t_ < 8; t_++) cuba_trace_buf[kid][(wave) * 8 + t_] = tr_[t_]; } while (0)
+#else
+#define TRACE_DECL
+#define TRACE_MARK() do { } while (0)
+#define TRACE_FLUSH(kid, wave) do { } while (0)
+#endif
+
+
 // ---------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------
@@ -36,11 +49,58 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned long long* p, Scalar 
 	if (v > 0) atomicMax(p, (unsigned long long)__double_as_longlong((double)v));   // always compared as doubles
 }
 
+// Wave-wide reductions on the DPP data path (a few cycles per step) instead of __shfl_xor (ds_bpermute: an LDS-crossbar
+// round trip per step and per 32-bit half).  row_shr 1/2/4/8 leave each 16-lane row's total in its last lane,
+// row_bcast:15 / row_bcast:31 carry the totals across rows into lane 63, which is then broadcast through a scalar
+// register.  Lanes without a source lane receive the identity 0.  The summation order is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Scalar dpp_shift(Scalar v)
+{
+	union { Scalar s; int w[sizeof(Scalar) / 4]; } a, b;
+	a.s = v;
+#pragma unroll
+	for (int i = 0; i < (int)(sizeof(Scalar) / 4); i++) b.w[i] = __builtin_amdgcn_update_dpp(0, a.w[i], CTRL, ROW_MASK, 0xf, false);
+	return b.s;
+}
+
+__device__ __forceinline__ Scalar broadcast_lane63(Scalar v)
+{
+	union { Scalar s; int w[sizeof(Scalar) / 4]; } u;
+	u.s = v;
+#pragma unroll
+	for (int i = 0; i < (int)(sizeof(Scalar) / 4); i++) u.w[i] = __builtin_amdgcn_readlane(u.w[i], 63);
+	return u.s;
+}
+
 __device__ __forceinline__ Scalar wave_sum(Scalar v)
 {
+	v += dpp_shift<0x111, 0xf>(v);   // row_shr:1
+	v += dpp_shift<0x112, 0xf>(v);   // row_shr:2
+	v += dpp_shift<0x114, 0xf>(v);   // row_shr:4
+	v += dpp_shift<0x118, 0xf>(v);   // row_shr:8
+	v += dpp_shift<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+	v += dpp_shift<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+	return broadcast_lane63(v);
+}
+
+// Load of a uniform flag through the VECTOR memory path. A plain `*p` of a uniform address becomes an s_load, and the
+// next kernel-argument use then waits for lgkmcnt(0), i.e. for this load's full memory round trip, before the first
+// vector load of the kernel can even be issued.
+__device__ __forceinline__ int vector_load_flag(const int* p)
+{
+	int zero;
+	asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+	return p[zero];
+}
+
+// wave-uniform value -> scalar registers (frees the vector registers a long-lived uniform would occupy)
+__device__ __forceinline__ Scalar to_uniform(Scalar v)
+{
+	union { Scalar s; int w[sizeof(Scalar) / 4]; } u;
+	u.s = v;
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-	return v;
+	for (int i = 0; i < (int)(sizeof(Scalar) / 4); i++) u.w[i] = __builtin_amdgcn_readfirstlane(u.w[i]);
+	return u.s;
 }
 
 __device__ __forceinline__ Scalar wave_max(Scalar v)
@@ -82,9 +142,11 @@ __device__ __forceinline__ Scalar load_parts(const Scalar* p, int n, int lane)
 	return ((v0 + e0) + (v1 + e1)) + ((v2 + e2) + v3);
 }
 
-__device__ __forceinline__ const Scalar* rz_slot(const DeviceSystem& sys, int k) { return sys.rz + (size_t)(k == 0 ? 0 : 1 + (k & 3)) * sys.rzStride; }
-__device__ __forceinline__ Scalar* rz_slot_w(const DeviceSystem& sys, int k) { return sys.rz + (size_t)(k == 0 ? 0 : 1 + (k & 3)) * sys.rzStride; }
-__device__ __forceinline__ int rz_count(const DeviceSystem& sys, int k) { return k == 0 ? sys.nrz0 : sys.nrz; }
+// ring slots depend on k & 3 only: graph chunks are multiples of 4, so the chunk-local k of a captured launch selects
+// the same slot as the absolute iteration number and no address has to wait for the kbase load
+__device__ __forceinline__ const Scalar* rz_slot(const DeviceSystem& sys, int k) { return sys.rz + (size_t)(1 + (k & 3)) * sys.rzStride; }
+__device__ __forceinline__ Scalar* rz_slot_w(const DeviceSystem& sys, int k) { return sys.rz + (size_t)(1 + (k & 3)) * sys.rzStride; }
+__device__ __forceinline__ int rz_count(const DeviceSystem& sys, int) { return sys.nrz; }
 __device__ __forceinline__ Scalar* pq_slot(const DeviceSystem& sys, int k) { return sys.pq + (size_t)(k & 3) * sys.pqStride; }
 
 // Deterministic second stage of every global sum (chi2, gain-ratio denominator): one workgroup adds the
@@ -1221,7 +1283,16 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 	__shared__ Scalar part[4];
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rz;
 	__syncthreads();
-	if (sys.agg == 0 && threadIdx.x == 0) sys.rz[blockIdx.x] = part[0] + part[1] + part[2] + part[3];   // slot 0
+	if (sys.agg == 0)   // block-Jacobi only: this kernel produces r0.z0 -> slot 0 and, as "r_k.z_k for k = 0", ring slot 1
+	{
+		if (threadIdx.x == 0)
+		{
+			const Scalar s2 = part[0] + part[1] + part[2] + part[3];
+			sys.rz[blockIdx.x] = s2;
+			sys.rz[sys.rzStride + blockIdx.x] = s2;
+		}
+		for (int t = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; t < sys.nrz; t += gridDim.x * blockDim.x) sys.rz[sys.rzStride + t] = 0;
+	}
 	if (i == 0) { *sys.iters = 0; *sys.done = 0; }
 }
 
@@ -1264,42 +1335,94 @@ __device__ __forceinline__ void spmv_entry(const DeviceStructure& st, const Devi
 	for (int c = 0; c < 6; c++) { accz += av[c] * zv[c]; accp += av[c] * pv[c]; }
 }
 
-constexpr int SPMV_ROWS = 4;    // block rows (= waves) per workgroup: one p.Ap partial per 16 rows keeps the partial list short
-
-__global__ __launch_bounds__(64 * SPMV_ROWS) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+// N entries of one lane at once: all 18 N loads are issued before the first use. Padding entries (column -1) read
+// block 0 / column 0 and are discarded by a select, which keeps the loads of a wave free of branches.
+template <int N>
+__device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar* pold, const int2 (&e)[3], int rr, Scalar& accz, Scalar& accp)
 {
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
-	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
-	const int row = blockIdx.x * SPMV_ROWS + wv;
-	// scalar loads, consumed at the very end
-	k += *sys.kbase;
-	const int failed = *sys.fail | *sys.done;   // consumed after the sweep, like the other scalars
-	const Scalar s_k = load_parts(rz_slot(sys, k), rz_count(sys, k), lane);
-	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
-	const Scalar s_m = k > 0 ? load_parts(rz_slot(sys, k - 1), rz_count(sys, k - 1), lane) : Scalar(0);
-
-	Scalar accz = 0, accp = 0, zi = 0, pi_old = 0;
-	if (row < g.Pf)
+	Scalar av[N][6], zv[N][6], pv[N][6];
+#pragma unroll
+	for (int n = 0; n < N; n++)
 	{
-		const int slot = lane / 6, rr = lane % 6;
-		if (lane < 60)
+		const bool on = e[n].y >= 0;
+		const int bi = on ? e[n].x : 0;
+		const size_t j = on ? e[n].y : 0;
+		const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
+		const int sr = bi < 0 ? 6 : 1, sc = bi < 0 ? 1 : 6;
+#pragma unroll
+		for (int c = 0; c < 6; c++)
 		{
-			const int a1 = st.adj_ptr[row + 1];
-			int a = st.adj_ptr[row] + slot;
-			for (; a + 10 < a1; a += 20)     // two entries per trip: their 36 loads are independent and overlap
-			{
-				spmv_entry(st, sys, pold, a, rr, accz, accp);
-				spmv_entry(st, sys, pold, a + 10, rr, accz, accp);
-			}
-			if (a < a1) spmv_entry(st, sys, pold, a, rr, accz, accp);
-		}
-		if (lane < 6)
-		{
-			zi = sys.z[6 * (size_t)row + lane];
-			pi_old = pold[6 * (size_t)row + lane];
+			av[n][c] = B[rr * sr + c * sc];
+			zv[n][c] = sys.z[6 * j + c];
+			pv[n][c] = pold[6 * j + c];
 		}
 	}
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+		const bool on = e[n].y >= 0;
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+		{
+			const Scalar a = on ? av[n][c] : Scalar(0);
+			accz += a * zv[n][c]; accp += a * pv[n][c];
+		}
+	}
+}
+
+__global__ __launch_bounds__(128 * SPMV_ROWS) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int half = wv & 1, lr = wv >> 1;          // the two waves of a row take 10 of its 20 entry slots each
+	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
+	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
+	const int row = blockIdx.x * SPMV_ROWS + lr;
+	TRACE_DECL
+	TRACE_MARK();
+	// scalar loads, consumed at the very end (k is chunk-local here; the absolute number only enters the tests)
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
+	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
+	const Scalar s_m = load_parts(rz_slot(sys, k - 1), sys.nrz, lane);
+
+	// every index comes from an address known at launch (fixed-width rows): one memory round trip for the indices and
+	// the reduction scalars, one for all matrix / vector operands of the row
+	const bool rowOn = row < g.Pf;
+	const int slot = half * 10 + lane / 6, rr = lane % 6;
+	int2 e[3];
+	int a0 = 0, a1 = 0;
+#pragma unroll
+	for (int m = 0; m < 3; m++)
+		e[m] = (rowOn && lane < 60 && m < st.ell_m) ? st.ell[((size_t)row * st.ell_m + m) * 20 + slot] : int2{ 0, -1 };
+	if (rowOn && st.ell_over && lane < 60) { a0 = st.adj_ptr[row] + 20 * st.ell_m + slot; a1 = st.adj_ptr[row + 1]; }
+	Scalar accz = 0, accp = 0, zi = 0, pi_old = 0;
+	if (rowOn && half == 0 && lane < 6)
+	{
+		zi = sys.z[6 * (size_t)row + lane];
+		pi_old = pold[6 * (size_t)row + lane];
+	}
+	TRACE_MARK();
+	k += __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+		return;
+	}
+	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
+	if (rowOn)
+	{
+		int cnt = 0;                       // wave-uniform: entries of the fullest slot
+#pragma unroll
+		for (int m = 0; m < 3; m++) cnt += __any(e[m].y >= 0) ? 1 : 0;
+		if (cnt == 3) spmv_batch<3>(sys, pold, e, rr, accz, accp);
+		else if (cnt == 2) spmv_batch<2>(sys, pold, e, rr, accz, accp);
+		else if (cnt == 1) spmv_batch<1>(sys, pold, e, rr, accz, accp);
+		for (int a = a0; a < a1; a += 20) spmv_entry(st, sys, pold, a, rr, accz, accp);   // rows wider than the fixed part
+	}
+	TRACE_MARK();
 	// fold the 10 slots onto lanes 0..5
 	accz += __shfl_down(accz, 30); accp += __shfl_down(accp, 30);
 	Scalar tz = accz, tp = accp;
@@ -1307,34 +1430,46 @@ __global__ __launch_bounds__(64 * SPMV_ROWS) void pcg_spmv_kernel(DeviceGraph g,
 	tz += __shfl_down(accz, 12); tp += __shfl_down(accp, 12);
 	tz += __shfl_down(accz, 18); tp += __shfl_down(accp, 18);
 	tz += __shfl_down(accz, 24); tp += __shfl_down(accp, 24);
-
-	const Scalar rzk = wave_sum(s_k), rz0 = wave_sum(s_0), rzm = wave_sum(s_m);
-	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
-	{
-		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
-		return;
-	}
-	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
-	Scalar dot = 0;
-	if (row < g.Pf && lane < 6)
-	{
-		const Scalar pi = zi + beta * pi_old;
-		const Scalar q = tz + beta * tp;
-		pnew[6 * (size_t)row + lane] = pi;
-		sys.ap[6 * (size_t)row + lane] = q;
-		dot = pi * q;
-	}
-	dot = wave_sum(dot);
+	__shared__ Scalar other[SPMV_ROWS][12];
+	__shared__ Scalar qrow[SPMV_ROWS][6];
 	__shared__ Scalar part[SPMV_ROWS];
-	if (lane == 0) part[wv] = dot;
+	if (half == 1 && lane < 6) { other[lr][lane] = tz; other[lr][6 + lane] = tp; }
 	__syncthreads();
-	if (threadIdx.x == 0)
+	TRACE_MARK();
+	Scalar dot = 0;
+	if (half == 0)
+	{
+		Scalar q = 0;
+		if (row < g.Pf && lane < 6)
+		{
+			tz += other[lr][lane]; tp += other[lr][6 + lane];
+			const Scalar pi = zi + beta * pi_old;
+			q = tz + beta * tp;
+			pnew[6 * (size_t)row + lane] = pi;
+			sys.ap[6 * (size_t)row + lane] = q;
+			dot = pi * q;
+		}
+		if (lane < 6) qrow[lr][lane] = q;
+		dot = wave_sum(dot);
+		if (lane == 0) part[lr] = dot;
+	}
+	__syncthreads();
+	if (threadIdx.x < 6)         // row sums of q over this workgroup's rows: the two-level kernel builds P^T q from these
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < SPMV_ROWS; w++) s2 += qrow[w][threadIdx.x];
+		if (sys.qpart) sys.qpart[6 * (size_t)blockIdx.x + threadIdx.x] = s2;
+	}
+	if (threadIdx.x == 64)
 	{
 		Scalar s2 = 0;
 #pragma unroll
 		for (int w = 0; w < SPMV_ROWS; w++) s2 += part[w];
 		pq_slot(sys, k)[blockIdx.x] = s2;
 	}
+	TRACE_MARK();
+	TRACE_FLUSH(0, blockIdx.x * 2 * SPMV_ROWS + wv);
 }
 
 // B(k): alpha = rz[k]/pq[k]; x += alpha p; r -= alpha q; z = Minv r; rz[k+1] += r.z
@@ -1527,75 +1662,155 @@ void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, Device
 }
 
 // Fused B(k) of the two-level PCG: [x += alpha p; r -= alpha q;]  rc = P^T r;  z = Minv r + P (Ac^-1 rc);
-// rz[kOut] += r.z.  One 512-thread workgroup per aggregate.  Every workgroup rebuilds the WHOLE restricted
-// residual rc (6*nc values) from r and q = A p itself -- 2 x 6Pf doubles from L2 per workgroup -- which is
-// cheaper than a kernel boundary (~1.5 us) plus a second launch; only the owner of an aggregate stores x, r, z.
+// rz[kOut] = r.z.  One 512-thread workgroup per aggregate; only the owner of an aggregate stores x, r, z.
+// Every workgroup needs the WHOLE restricted residual rc = P^T r_k - alpha P^T q_k (6*nc values). Neither term is
+// rebuilt from the full vectors: P^T r_k was stored by the owners one iteration earlier (sys.rc, ping-pong), and
+// P^T q_k is summed from the per-workgroup row sums the SpMV kernel leaves in sys.qpart.  Together with the local-k
+// slot addressing every global load of the kernel is issued in its first instructions (one memory round trip).
+// doUpdate = 0 (once per solve: z_0 = M^-1 r_0) still restricts r directly.
 constexpr int PCG2_T = 512;
+
+__device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
+{
+	Scalar v0 = 0, v1 = 0;
+	int t = threadIdx.x;
+	for (; t + PCG2_T < n; t += 2 * PCG2_T)
+	{
+		const Scalar a = p[t], b = p[t + PCG2_T];
+		v0 += a; v1 += b;
+	}
+	const Scalar e = t < n ? p[t] : Scalar(0);
+	return (v0 + e) + v1;
+}
 
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
-	extern __shared__ __attribute__((aligned(16))) Scalar sm[];   // sR[Nc] | sQ[Nc] | part[8][6] | yc[6] | wsum[8] | rown | qown
+	extern __shared__ unsigned char pcg2_lds[];
 	const int Nc = 6 * sys.nc;
-	Scalar* sR = sm;
+	Scalar* sR = reinterpret_cast<Scalar*>(pcg2_lds);
 	Scalar* sQ = sR + Nc;
 	Scalar* part = sQ + Nc;
 	Scalar* yc = part + 48;
-	Scalar* wsum = yc + 6;
-	Scalar* rown = wsum + 8;
+	Scalar* wsum = yc + 6;            // [4][8]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
+	Scalar* rown = wsum + 32;
 	Scalar* qown = rown + 6 * sys.agg;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;
 	// the residual is double-buffered: other workgroups still read r_k of this aggregate while its owner stores r_{k+1}
 	const Scalar* rin = (k & 1) ? sys.r2 : sys.r;
 	Scalar* rout = (k & 1) ? sys.r : sys.r2;
+	const Scalar* rcin = sys.rc + ((k & 1) ? Nc : 0);
+	Scalar* rcout = sys.rc + ((doUpdate != 0) == ((k & 1) != 0) ? 0 : Nc);    // doUpdate = 0 stores P^T r_0 where k = 0 reads it
 	const int I = blockIdx.x;
-	// reduction scalars: loaded now, consumed after the sweep (alpha enters linearly: rc = P^T r - alpha P^T q)
-	const int kb = *sys.kbase;
-	k += kb; kOut += kb;
-	const int failed = *sys.fail | (doUpdate ? *sys.done : 0);
-	const Scalar s_k = doUpdate ? load_parts(rz_slot(sys, k), rz_count(sys, k), lane) : Scalar(0);
-	const Scalar s_0 = doUpdate ? load_parts(sys.rz, sys.nrz0, lane) : Scalar(0);
-	const Scalar s_q = doUpdate ? load_parts(pq_slot(sys, k), sys.npq, lane) : Scalar(0);
-
-	// restricted sums P^T r and P^T q: thread (J, c) adds component c over the poses of aggregate J in index order
-	// (fixed order => reproducible); loads are issued in batches of 8 so that they overlap
-	const int n6 = 6 * g.Pf;
-	const int own0 = 6 * I * sys.agg, own1 = min(n6, own0 + 6 * sys.agg);
-	for (int jc = threadIdx.x; jc < Nc; jc += PCG2_T)
-	{
-		const int J = jc / 6, c = jc - 6 * J;
-		const int i0 = J * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
-		Scalar sr = 0, sq = 0;
-		for (int i = i0; i < i1; i += 8)
-		{
-			Scalar rv[8], qv[8];
-#pragma unroll
-			for (int m = 0; m < 8; m++)
-			{
-				const bool in = i + m < i1;
-				const size_t idx = 6 * (size_t)(in ? i + m : i) + c;
-				rv[m] = in ? rin[idx] : Scalar(0);
-				qv[m] = (in && doUpdate) ? sys.ap[idx] : Scalar(0);
-			}
-#pragma unroll
-			for (int m = 0; m < 8; m++)
-			{
-				sr += rv[m]; sq += qv[m];
-				if (J == I && i + m < i1) { rown[6 * (i + m - i0) + c] = rv[m]; qown[6 * (i + m - i0) + c] = qv[m]; }
-			}
-		}
-		sR[jc] = sr; sQ[jc] = sq;
-	}
-	// the part of the coarse inverse this workgroup needs (symmetric: columns 6I..6I+5 are contiguous), also early
-	Scalar ainv[6] = { 0, 0, 0, 0, 0, 0 };
-	if (threadIdx.x < Nc)
-#pragma unroll
-		for (int c = 0; c < 6; c++) ainv[c] = sys.acinv[(size_t)(6 * I + c) * Nc + threadIdx.x];
-	Scalar alpha = 0;
+	TRACE_DECL
+	TRACE_MARK();
+	const int kb_v = vector_load_flag(sys.kbase);          // k, kOut are chunk-local: slots depend on k & 3 only, the tests use k + kb
+	const int failed_v = vector_load_flag(sys.fail) | (doUpdate ? vector_load_flag(sys.done) : 0);
+	// ---- every global load of the common case is issued here, before the first use of any of them ----------------
+	const int t = threadIdx.x;
+	const int own0 = 6 * I * sys.agg;
+	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
+	const int per = sys.agg / SPMV_ROWS;                 // SpMV workgroups per aggregate
+	const int J = t / 6, cc = t - 6 * J;                 // first (usually only) coarse component of this thread
+	const int g0 = J * per, g1 = min(sys.npq, g0 + per);
+	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
+	Scalar pre_r = 0, pre_q = 0, pre_p = 0, pre_x = 0, pre_m[6] = { 0, 0, 0, 0, 0, 0 };   // own rows
+	Scalar sr = 0, qv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // restricted sums
+	Scalar ainv[6] = { 0, 0, 0, 0, 0, 0 };              // coarse inverse, columns 6I..6I+5 (symmetric: contiguous)
 	if (doUpdate)
 	{
-		const Scalar rzk = wave_sum(s_k), rz0 = wave_sum(s_0), pqk = wave_sum(s_q);
-		if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
+		if (t < sys.nrz) e_k = rz_slot(sys, k)[t];
+		if (t < sys.nrz0) e_0 = sys.rz[t];
+		if (t < sys.npq) e_q0 = pq_slot(sys, k)[t];
+		if (t + PCG2_T < sys.npq) e_q1 = pq_slot(sys, k)[t + PCG2_T];
+	}
+	if (t < ownN)
+	{
+		const size_t gi = (size_t)own0 + t;
+		pre_r = rin[gi];
+		if (doUpdate) { pre_q = sys.ap[gi]; pre_p = p[gi]; pre_x = sys.xp[gi]; }
+		const size_t pose = gi / 6; const int comp = (int)(gi - 6 * pose);
+#pragma unroll
+		for (int c = 0; c < 6; c++) pre_m[c] = sys.minv[36 * pose + c * 6 + comp];
+	}
+	if (t < Nc)
+	{
+		if (doUpdate)
+		{
+			sr = rcin[t];
+			// unconditional loads from clamped addresses (selected below): a predicated load per element makes the
+			// compiler merge registers after each one and wait for it
+#pragma unroll
+			for (int m = 0; m < 8; m++) qv[m] = sys.qpart[6 * (size_t)max(0, min(g0 + m, g1 - 1)) + cc];
+		}
+#pragma unroll
+		for (int c = 0; c < 6; c++) ainv[c] = sys.acinv[(size_t)(6 * I + c) * Nc + t];
+	}
+	// ---- rare remainders (more partials / coarse components / own rows than threads) and the arithmetic ----------
+	Scalar a_k = e_k, a_0 = e_0, a_q = e_q0 + e_q1;
+	if (doUpdate)
+	{
+		for (int u = t + PCG2_T; u < sys.nrz; u += PCG2_T) a_k += rz_slot(sys, k)[u];
+		for (int u = t + PCG2_T; u < sys.nrz0; u += PCG2_T) a_0 += sys.rz[u];
+		for (int u = t + 2 * PCG2_T; u < sys.npq; u += PCG2_T) a_q += pq_slot(sys, k)[u];
+	}
+	if (t < ownN) { rown[t] = pre_r; qown[t] = pre_q; }
+	for (int w = t + PCG2_T; w < ownN; w += PCG2_T)
+	{
+		rown[w] = rin[own0 + w];
+		qown[w] = doUpdate ? sys.ap[own0 + w] : Scalar(0);
+	}
+	// restricted sums P^T r_k and P^T q_k (fixed summation order => reproducible)
+	for (int jc = t; jc < Nc; jc += PCG2_T)
+	{
+		const int Jj = jc / 6, c = jc - 6 * Jj;
+		Scalar s1 = 0, s2 = 0;
+		if (doUpdate)
+		{
+			const int h0 = Jj * per, h1 = min(sys.npq, h0 + per);
+			if (jc == t)
+			{
+				s1 = sr;
+#pragma unroll
+				for (int m = 0; m < 8; m++) s2 += h0 + m < h1 ? qv[m] : Scalar(0);
+			}
+			else s1 = rcin[jc];
+			for (int gq = h0 + (jc == t ? 8 : 0); gq < h1; gq += 8)
+			{
+				Scalar q8[8];
+#pragma unroll
+				for (int m = 0; m < 8; m++) q8[m] = gq + m < h1 ? sys.qpart[6 * (size_t)(gq + m) + c] : Scalar(0);
+#pragma unroll
+				for (int m = 0; m < 8; m++) s2 += q8[m];
+			}
+		}
+		else
+		{
+			const int i0 = Jj * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+			for (int i = i0; i < i1; i += 8)
+			{
+				Scalar rv[8];
+#pragma unroll
+				for (int m = 0; m < 8; m++) rv[m] = i + m < i1 ? rin[6 * (size_t)(i + m) + c] : Scalar(0);
+#pragma unroll
+				for (int m = 0; m < 8; m++) s1 += rv[m];
+			}
+		}
+		sR[jc] = s1; sQ[jc] = s2;
+	}
+	TRACE_MARK();
+	a_k = wave_sum(a_k); a_0 = wave_sum(a_0); a_q = wave_sum(a_q);
+	if (lane == 0) { wsum[wv] = a_k; wsum[8 + wv] = a_0; wsum[16 + wv] = a_q; }
+	__syncthreads();
+	Scalar alpha = 0;
+	const int kabs = k + __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	if (doUpdate)
+	{
+		Scalar rzk = 0, rz0 = 0, pqk = 0;
+#pragma unroll
+		for (int w = 0; w < PCG2_T / 64; w++) { rzk += wsum[w]; rz0 += wsum[8 + w]; pqk += wsum[16 + w]; }
+		if (!(kabs < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
 		{
 			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
 			return;
@@ -1607,16 +1822,17 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		}
 		alpha = rzk / pqk;
 	}
-	__syncthreads();
+	TRACE_MARK();
 	// ---- own rows: r_{k+1}, x_{k+1} ---------------------------------------------------------------------------
-	for (int w = threadIdx.x; w < own1 - own0; w += PCG2_T)
+	const int ow = t;
+	for (int w = ow; w < ownN; w += PCG2_T)
 	{
-		const Scalar r = rown[w] - alpha * qown[w];
+		const Scalar r = rown[w] - alpha * qown[w];      // rown[w] / qown[w] were written by this very thread
 		rown[w] = r;
 		if (doUpdate)
 		{
 			rout[own0 + w] = r;
-			sys.xp[own0 + w] += alpha * p[own0 + w];
+			sys.xp[own0 + w] = (w == ow ? pre_x : sys.xp[own0 + w]) + alpha * (w == ow ? pre_p : p[own0 + w]);
 		}
 	}
 	// ---- yc = Ac^-1[6I..6I+5, :] (P^T r - alpha P^T q) ------------------------------------------------------------
@@ -1648,42 +1864,50 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 		for (int w = 0; w < PCG2_T / 64; w++) s2 += part[w * 6 + threadIdx.x];
 		yc[threadIdx.x] = s2;
+		// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves
+		Scalar s3 = 0;
+		for (int i = threadIdx.x; i < ownN; i += 6) s3 += rown[i];
+		rcout[6 * I + threadIdx.x] = s3;
 	}
 	__syncthreads();
+	TRACE_MARK();
 	// ---- z = Minv r + yc for the poses of this aggregate; r.z --------------------------------------------------
-	const int i0 = I * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
 	Scalar dot = 0;
-	for (int w = threadIdx.x; w < (i1 - i0) * 6; w += PCG2_T)
+	for (int w = ow; w < ownN; w += PCG2_T)
 	{
-		const int i = i0 + w / 6, comp = w % 6;
+		const int il = w / 6, comp = w - 6 * il;
 		Scalar z = yc[comp];
 #pragma unroll
-		for (int c = 0; c < 6; c++) z += sys.minv[36 * (size_t)i + c * 6 + comp] * rown[6 * (i - i0) + c];
-		sys.z[6 * (size_t)i + comp] = z;
-		dot += rown[6 * (i - i0) + comp] * z;
+		for (int c = 0; c < 6; c++)
+			z += (w == ow ? pre_m[c] : sys.minv[36 * ((size_t)I * sys.agg + il) + c * 6 + comp]) * rown[6 * il + c];
+		sys.z[(size_t)own0 + w] = z;
+		dot += rown[w] * z;
 	}
 	dot = wave_sum(dot);
-	if (lane == 0) wsum[wv] = dot;
+	if (lane == 0) wsum[24 + wv] = dot;
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
 		Scalar s2 = 0;
 #pragma unroll
-		for (int w = 0; w < PCG2_T / 64; w++) s2 += wsum[w];
+		for (int w = 0; w < PCG2_T / 64; w++) s2 += wsum[24 + w];
 		rz_slot_w(sys, kOut)[blockIdx.x] = s2;
-		if (doUpdate && blockIdx.x == 0) *sys.iters = k + 1;
+		if (!doUpdate) sys.rz[blockIdx.x] = s2;          // r_0.z_0: kept in slot 0 for the stop test
+		if (doUpdate && blockIdx.x == 0) *sys.iters = kabs + 1;
 	}
+	TRACE_MARK();
+	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
 }
 
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
 {
-	const size_t lds = sizeof(Scalar) * (12 * (size_t)sys.nc + 48 + 6 + 8 + 12 * (size_t)sys.agg);
+	const size_t lds = sizeof(Scalar) * (12 * (size_t)sys.nc + 48 + 6 + 32 + 12 * (size_t)sys.agg);
 	hipLaunchKernelGGL(pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_spmv_kernel, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(64 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
+	hipLaunchKernelGGL(pcg_spmv_kernel, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
 }
 
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -1705,3 +1929,10 @@ void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const
 }
 
 }  // namespace cubahip
+
+#ifdef CUBA_HIP_TRACE
+extern "C" int cuba_hip_debug_read_trace(unsigned long long* out)   // 2 x 8192 x 8 timestamps (100 MHz)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cubahip::cuba_trace_buf), sizeof(unsigned long long) * 2 * 8192 * 8);
+}
+#endif

@@ -50,6 +50,11 @@ struct DeviceStructure
 	long long* lm_pair_base = nullptr; // [Lf] offset of a landmark's pairs in pair_blk
 	int* lm_nfree = nullptr;           // [Lf] number of edges of the landmark whose pose is free
 	int *adj_ptr = nullptr, *adj_blk = nullptr, *adj_col = nullptr;  // adj_blk bit 31 = use transposed
+	// the first 20*ell_m entries of every adjacency row again, padded to a fixed width and interleaved so that lane
+	// (slot, m) finds its (block, column) pair at ((row*ell_m + m)*20 + slot) without reading adj_ptr first;
+	// column -1 = padding. ell_over != 0 when some row has more entries (those stay in adj_* only).
+	int2* ell = nullptr;
+	int ell_m = 0, ell_over = 0;
 	// destination-major (atomic-free) Schur assembly
 	int* hsc_blkrow = nullptr;         // [nblk] block row of every block
 	int nOd = 0;                       // blocks that receive at least one off-diagonal (or duplicate-pose) product
@@ -62,6 +67,8 @@ struct DeviceStructure
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo}
 };
+
+constexpr int SPMV_ROWS = 2;    // block rows per SpMV workgroup (two waves each)
 
 struct DeviceSystem
 {
@@ -78,10 +85,11 @@ struct DeviceSystem
 	// PCG work
 	Scalar *minv = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *ap = nullptr;
 	// CG scalars as per-workgroup partial sums in small rings (no atomics => fixed summation order, nothing to zero):
-	//   rz: slot 0 = r0.z0 (kept for the stop test), slot 1+(k&3) = r_k.z_k for k >= 1;  pq: slot k&3 = p_k.A p_k
+	//   rz: slot 0 = r0.z0 (kept for the stop test), slot 1+(k&3) = r_k.z_k (k = 0: a second copy of slot 0, so that no
+	//   address depends on the absolute iteration number);  pq: slot k&3 = p_k.A p_k
 	Scalar *rz = nullptr, *pq = nullptr;
 	int rzStride = 0, pqStride = 0;        // entries per ring slot
-	int nrz0 = 0, nrz = 0, npq = 0;        // number of partials actually written into slot 0 / the other rz slots / pq slots
+	int nrz0 = 0, nrz = 0, npq = 0;        // number of partials in slot 0 / in the ring slots of rz (nrz0 <= nrz) / in pq slots
 	int* done = nullptr;                   // set once the stop test fails: later queued launches return at once
 	int* iters = nullptr;      // device iteration counter
 	int* kbase = nullptr;      // iteration offset added to the k / kOut kernel arguments (lets one captured hipGraph
@@ -90,7 +98,10 @@ struct DeviceSystem
 	int agg = 0;               // 0 = block-Jacobi only
 	int nc = 0;                // number of aggregates (coarse dimension = 6*nc)
 	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
-	Scalar* rc = nullptr;      // [6nc] restricted residual
+	Scalar* rc = nullptr;      // [2*6nc] restricted residual P^T r_k, ping-pong by the parity of k like r / r2 (each
+	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
+	Scalar* qpart = nullptr;   // [6*npq] sum of q = A p over the SPMV_ROWS block rows of each SpMV workgroup (P^T q is
+	                           // summed from these: aggregates are whole multiples of SPMV_ROWS rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
 };
 

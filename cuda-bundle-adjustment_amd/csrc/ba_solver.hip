@@ -107,13 +107,14 @@ struct cuba_hip_solver
 	DevBuf<int> d_epose, d_elm, d_lmptr;
 	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
 	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_pairBlk, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
+	DevBuf<int2> d_ell;
 	DevBuf<long long> d_bigOfs, d_lmPairBase;
 	DevBuf<Scalar> d_bigHpl;
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
 	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done;
-	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2;
+	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2, d_qpart;
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -513,6 +514,20 @@ struct cuba_hip_solver
 		d_rowptr.upload(h_rowptr, stream); d_colind.upload(h_colind, stream);
 		d_pairBlk.upload(pairBlk, stream); d_lmPairBase.upload(pairBase, stream); d_lmNfree.upload(nfree, stream);
 		d_adjPtr.upload(adjPtr, stream); d_adjBlk.upload(adjBlk, stream); d_adjCol.upload(adjCol, stream);
+		int ellM = 0, ellOver = 0;
+		{
+			int maxRow = 0;
+			for (int i = 0; i < Pf; i++) maxRow = std::max(maxRow, adjPtr[i + 1] - adjPtr[i]);
+			const int M = std::min(3, (maxRow + 19) / 20);
+			ellM = M; ellOver = maxRow > 20 * M;
+			std::vector<int2> ell((size_t)Pf * M * 20, int2{ 0, -1 });
+			for (int i = 0; i < Pf; i++)
+			{
+				const int n = std::min(adjPtr[i + 1] - adjPtr[i], 20 * M);
+				for (int e = 0; e < n; e++) ell[(size_t)i * M * 20 + e] = int2{ adjBlk[adjPtr[i] + e], adjCol[adjPtr[i] + e] };
+			}
+			d_ell.upload(ell, stream);
+		}
 		d_blkrow.upload(blkRow, stream); d_odBlocks.upload(odBlocks, stream); d_prodPtr.upload(prodPtr, stream);
 		d_prodEa.upload(prodEa, stream); d_prodEb.upload(prodEb, stream); d_pePtr.upload(pePtr, stream); d_peEdge.upload(peEdge, stream);
 		d_erec.resize((size_t)8 * E);
@@ -524,10 +539,11 @@ struct cuba_hip_solver
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
 		// coarse level of the preconditioner: aggregates of consecutive free poses
 		int agg = pcgAggregate;
-		if (agg < 0) agg = std::max(16, (Pf + 127) / 128);   // coarse dimension <= 768: the O(Nc^3) inverse stays below ~0.3 ms
+		if (agg < 0) agg = std::max(16, (Pf + 127) / 128);
+		if (agg > 0) agg = (agg + SPMV_ROWS - 1) / SPMV_ROWS * SPMV_ROWS;   // aggregates = whole SpMV workgroups (sys.qpart)   // coarse dimension <= 768: the O(Nc^3) inverse stays below ~0.3 ms
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		if (nc < 2) { agg = 0; nc = 0; }
-		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)6 * nc); d_r2.resize((size_t)6 * Pf);
+		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)12 * nc); d_r2.resize((size_t)6 * Pf);
 		lap("structure: uploads + allocs");
 		// coarse-matrix assembly lists: fine blocks grouped by the coarse block (I,J) they fall into (both triangles)
 		std::vector<int> cbI, cbJ, cbPtr(1, 0), cbBlk;
@@ -553,7 +569,7 @@ struct cuba_hip_solver
 		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
-		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + 3) / 4;   // SPMV_ROWS
+		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + SPMV_ROWS - 1) / SPMV_ROWS;
 		const int rzStride = std::max(1, std::max(std::max(gridSetup, gridUpd), nc)), pqStride = std::max(1, gridSpmv);
 		d_rz.resize((size_t)5 * rzStride); d_pq.resize((size_t)4 * pqStride);
 		sync();
@@ -565,6 +581,7 @@ struct cuba_hip_solver
 		st.nblk = nblk; st.hsc_rowptr = d_rowptr.data(); st.hsc_colind = d_colind.data();
 		st.pair_blk = d_pairBlk.data(); st.lm_pair_base = d_lmPairBase.data(); st.lm_nfree = d_lmNfree.data();
 		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
+		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = (int)odBlocks.size(); st.od_blocks = d_odBlocks.data();
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
@@ -579,6 +596,7 @@ struct cuba_hip_solver
 		sys.rzStride = rzStride; sys.pqStride = pqStride; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
+		d_qpart.resize((size_t)6 * gridSpmv); sys.qpart = d_qpart.data();
 		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();

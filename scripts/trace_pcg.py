@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Stage timestamps of the two PCG kernels (last active launch of a solve), from the libcuba_hip_trace.so build.
+
+    make -C cuda-bundle-adjustment_amd/csrc libcuba_hip_trace.so
+    gpurun -- python scripts/trace_pcg.py [shape]
+Prints, per kernel, the distribution over waves of each stage's time since the first wave started (100 MHz clock).
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CUBA_HIP_LIB_F64"] = os.path.join(ROOT, "cuda-bundle-adjustment_amd", "csrc", "libcuba_hip_trace.so")
+import numpy as np  # noqa: E402
+from cuba_amd import capi  # noqa: E402
+from cuba_amd.graph import flatten  # noqa: E402
+from cuba_amd.synth import synth_named  # noqa: E402
+
+shape = sys.argv[1] if len(sys.argv) > 1 else "kitti00"
+fp = flatten(synth_named(shape))
+rk = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
+h = capi.HipSolver(fp, rk)
+h.build_structure()
+h.optimize(3)
+lib = capi.load_library("f64")
+buf = np.zeros((2, 8192, 8), dtype=np.uint64)
+rc = lib.cuba_hip_debug_read_trace(buf.ctypes.data_as(C.c_void_p))
+assert rc == 0, rc
+for kid, name, stages in ((0, "pcg_spmv", ["entry", "indices+scalars", "operands", "fold+barrier", "end"]),
+                          (1, "pcg2_fused", ["entry", "sweep loads", "barrier 1", "barrier yc", "end"])):
+    t = buf[kid].astype(np.int64)
+    on = t[:, 0] > 0
+    t = t[on]
+    n = len(stages)
+    t0 = t[:, 0].min()
+    print(f"{name}: {on.sum()} waves, span {(t[:, n - 1].max() - t0) * 10} ns")
+    for s in range(n):
+        d = (t[:, s] - t0) * 10
+        print(f"  {stages[s]:18s} min {d.min():6d}  p50 {int(np.median(d)):6d}  p90 {int(np.percentile(d, 90)):6d}  max {d.max():6d} ns")
+    dur = (t[:, n - 1] - t[:, 0]) * 10
+    print(f"  per-wave duration  min {dur.min()} p50 {int(np.median(dur))} max {dur.max()} ns")
+    for s in range(1, n):
+        d = (t[:, s] - t[:, s - 1]) * 10
+        print(f"  stage {stages[s]:18s} p10 {int(np.percentile(d, 10)):6d} p50 {int(np.median(d)):6d} p90 {int(np.percentile(d, 90)):6d} max {d.max():6d} ns")
+h.close()
