@@ -25,7 +25,8 @@ namespace cubahip
 // Stage timestamps for latency studies (scripts/trace_pcg.py): only in the separate libcuba_hip_trace.so build.
 #ifdef CUBA_HIP_TRACE
 __device__ unsigned long long cuba_trace_buf[2][8192 * 8];
-#define TRACE_DECL unsigned long long tr_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int trn_ = 0;
+#define TRACE_DECL unsigned long long tr_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int trn_ = 0; \
+	{ unsigned long long t0_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)); tr_[7] = t0_; }
 #define TRACE_MARK() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr_[trn_++] = wall_clock64(); } while (0)
 #define TRACE_FLUSH(kid, wave) do { if ((threadIdx.x & 63) == 0 && (wave) < 8192) for (int t_ = 0; t_ < 8; t_++) cuba_trace_buf[kid][(wave) * 8 + t_] = tr_[t_]; } while (0)
 #else
@@ -1864,10 +1865,6 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 		for (int w = 0; w < PCG2_T / 64; w++) s2 += part[w * 6 + threadIdx.x];
 		yc[threadIdx.x] = s2;
-		// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves
-		Scalar s3 = 0;
-		for (int i = threadIdx.x; i < ownN; i += 6) s3 += rown[i];
-		rcout[6 * I + threadIdx.x] = s3;
 	}
 	__syncthreads();
 	TRACE_MARK();
@@ -1885,7 +1882,24 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	}
 	dot = wave_sum(dot);
 	if (lane == 0) wsum[24 + wv] = dot;
+	// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves: 8 interleaved partial
+	// sums per component here, folded after the barrier (a single thread per component would chain `agg` LDS reads)
+	if (t < 48)
+	{
+		const int c = t % 6, h = t / 6;
+		Scalar s3 = 0;
+		for (int i = 6 * h + c; i < ownN; i += 48) s3 += rown[i];
+		part[t] = s3;
+	}
 	__syncthreads();
+	if (t >= 64 && t < 70)
+	{
+		const int c = t - 64;
+		Scalar s3 = 0;
+#pragma unroll
+		for (int h = 0; h < 8; h++) s3 += part[6 * h + c];
+		rcout[6 * I + c] = s3;
+	}
 	if (threadIdx.x == 0)
 	{
 		Scalar s2 = 0;

@@ -38,6 +38,9 @@ for kid, name, stages in ((0, "pcg_spmv", ["entry", "indices+scalars", "operands
     for s in range(n):
         d = (t[:, s] - t0) * 10
         print(f"  {stages[s]:18s} min {d.min():6d}  p50 {int(np.median(d)):6d}  p90 {int(np.percentile(d, 90)):6d}  max {d.max():6d} ns")
+    d = (t[:, 0] - t[:, 7]) * 10
+    print(f"  wave start -> entry mark (first kernel-argument fetch): p10 {int(np.percentile(d, 10))} p50 {int(np.median(d))} p90 {int(np.percentile(d, 90))} ns; "
+          f"first wave start -> last wave start {(t[:, 7].max() - t[:, 7].min()) * 10} ns")
     dur = (t[:, n - 1] - t[:, 0]) * 10
     print(f"  per-wave duration  min {dur.min()} p50 {int(np.median(dur))} max {dur.max()} ns")
     for s in range(1, n):
