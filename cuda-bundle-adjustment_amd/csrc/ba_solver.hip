@@ -85,7 +85,7 @@ struct cuba_hip_solver
 	std::string lastError;
 
 	// options
-	double pcgTol = sizeof(Scalar) == 8 ? 1e-8 : 1e-4;       // relative M^-1-norm residual; the objective is second-order in the solve error
+	double pcgTol = sizeof(Scalar) == 8 ? 1e-7 : 1e-4;       // relative M^-1-norm residual; the objective is second-order in the solve error
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 32;
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only

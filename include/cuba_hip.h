@@ -80,7 +80,7 @@ int cuba_hip_scalar_size(void);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-8), "pcg_max_iter"
+/* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
    (default 4*6*Pf capped at 32768), "pcg_check_every" (default 32), "pcg_aggregate" (poses per coarse
    aggregate of the two-level preconditioner; -1 = automatic (16), 0 = block-Jacobi only), "coarse_max_age" (default 1: the coarse inverse
    of the two-level preconditioner is reused for one further solve unless the iteration count degrades; 0 = rebuild
