@@ -1942,6 +1942,41 @@ void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const
 	launch_pcg_update(g, st, sys, k, maxIter, tol2, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// hipGraph of `chunk` PCG iterations + the kbase advance, built node by node (no stream capture: captures are
+// invalidated by unrelated work other host threads put on the legacy stream meanwhile, e.g. a second solver handle).
+// ---------------------------------------------------------------------------------------------------
+template <typename... Args>
+static hipError_t add_kernel_node(hipGraph_t graph, hipGraphNode_t& last, void* fn, dim3 grid, dim3 block, unsigned lds, Args... args)
+{
+	void* ptrs[] = { (void*)&args... };
+	hipKernelNodeParams p = {};
+	p.func = fn; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = lds; p.kernelParams = ptrs; p.extra = nullptr;
+	hipGraphNode_t node = nullptr;
+	const hipError_t e = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p);
+	last = node;
+	return e;
+}
+
+hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2)
+{
+	hipGraphNode_t last = nullptr;
+	hipError_t e = hipSuccess;
+	for (int k = 0; k < chunk && e == hipSuccess; k++)
+	{
+		e = add_kernel_node(graph, last, (void*)pcg_spmv_kernel, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, g, st, sys, k, maxIter, tol2);
+		if (e != hipSuccess) break;
+		if (sys.agg > 0)
+		{
+			const unsigned lds = (unsigned)(sizeof(Scalar) * (12 * (size_t)sys.nc + 48 + 6 + 32 + 12 * (size_t)sys.agg));
+			e = add_kernel_node(graph, last, (void*)pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, g, sys, k, k + 1, maxIter, tol2, 1);
+		}
+		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
+	}
+	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(1), 0, sys.kbase, chunk);
+	return e;
+}
+
 }  // namespace cubahip
 
 #ifdef CUBA_HIP_TRACE

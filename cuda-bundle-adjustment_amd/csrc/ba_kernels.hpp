@@ -141,4 +141,7 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
+// Adds `chunk` PCG iterations (chunk-local k = 0..chunk-1) and the kbase advance to `graph` as a chain of kernel nodes.
+hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2);
+
 }  // namespace cubahip

@@ -16,6 +16,8 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/cuba_hip.h"
@@ -87,7 +89,7 @@ struct cuba_hip_solver
 	// options
 	double pcgTol = sizeof(Scalar) == 8 ? 1e-7 : 1e-4;       // relative M^-1-norm residual; the objective is second-order in the solve error
 	int pcgMaxIter = 0;          // 0 = automatic
-	int pcgCheckEvery = 32;
+	int pcgCheckEvery = 0;       // PCG iterations per host look at the device stop flag; 0 = adaptive (sized from the previous solve)
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
 	int coarseMaxAge = 2;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
 	                             // changes the iteration count only); refreshed early when the count degrades
@@ -127,8 +129,8 @@ struct cuba_hip_solver
 
 	// one captured hipGraph = `pcgGraphChunk` PCG iterations (kernel arguments are chunk-local, the device-side
 	// kbase counter supplies the offset): replaying it costs one host call instead of 2-3 launches per iteration
-	hipGraphExec_t pcgGraphExec = nullptr;
-	int pcgGraphChunk = 0;
+	// (graphs are kept per chunk length: 4, 8, 16, 32 and whatever pcg_check_every asks for)
+	std::map<int, hipGraphExec_t> pcgGraphs;
 	bool useGraph = true;
 	hipStream_t captureStream = nullptr;   // private stream used only to record graphs (the work stream may be the
 	                                       // legacy default stream, which cannot be captured)
@@ -140,7 +142,8 @@ struct cuba_hip_solver
 
 	void dropPcgGraph()
 	{
-		if (pcgGraphExec) { (void)hipGraphExecDestroy(pcgGraphExec); pcgGraphExec = nullptr; }
+		for (auto& kv : pcgGraphs) (void)hipGraphExecDestroy(kv.second);
+		pcgGraphs.clear();
 	}
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -153,29 +156,32 @@ struct cuba_hip_solver
 		else launch_pcg_iteration(g, st, sys, k, maxIter, tol2, s);
 	}
 
-	void buildPcgGraph(int chunk, int maxIter, Scalar tol2)
+	hipGraphExec_t pcgGraph(int chunk, int maxIter, Scalar tol2)
 	{
-		dropPcgGraph();
+		if (pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter || pcgGraphAcinv != sys.acinv) dropPcgGraph();   // baked-in arguments
+		auto it = pcgGraphs.find(chunk);
+		if (it != pcgGraphs.end()) return it->second;
 		hipGraph_t graph = nullptr;
-		hipStream_t cs = capStream();
-		HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-		for (int k = 0; k < chunk; k++) enqueuePcgIteration(k, maxIter, tol2, cs);
-		launch_pcg_advance(sys, chunk, cs);
-		HIP_TRY(hipStreamEndCapture(cs, &graph));
+		hipGraphExec_t exec = nullptr;
+		HIP_TRY(hipGraphCreate(&graph, 0));
+		HIP_TRY(graph_add_pcg_chunk(graph, g, st, sys, chunk, maxIter, tol2));
 		if (std::getenv("CUBA_HIP_DEBUG"))
 		{
 			size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn);
 			std::fprintf(stderr, "[cuba_hip] PCG graph: %zu nodes for a chunk of %d iterations\n", nn, chunk);
 		}
-		HIP_TRY(hipGraphInstantiate(&pcgGraphExec, graph, nullptr, nullptr, 0));
+		HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
 		(void)hipGraphDestroy(graph);
-		pcgGraphChunk = chunk;
+		pcgGraphs[chunk] = exec;
 		pcgGraphTol2 = tol2; pcgGraphMaxIter = maxIter; pcgGraphAcinv = sys.acinv;
+		return exec;
 	}
 	Scalar pcgGraphTol2 = 0; int pcgGraphMaxIter = 0; const Scalar* pcgGraphAcinv = nullptr;
 
 	bool coarseValid = false, coarseFresh = false;
 	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
+	std::vector<int> runIters;   // PCG iterations of the solves of the current LM run (sizes the next batch of launches)
+	int firstSolveIters = 0;     // ... and of the first solve of the previous run
 
 	double lambda = 0;
 	int maxIterAlloc = 0;
@@ -717,24 +723,48 @@ struct cuba_hip_solver
 			coarseFresh = refresh;
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
-		const int chunk = 2 * ((std::max(1, pcgCheckEvery) + 1) / 2);   // even: the kernels take k's parity from the chunk-local index
+		// Iterations are enqueued in chunks (captured graphs of 4/8/16/32 iterations; chunk lengths are multiples of 4
+		// because the kernels address their reduction slots by the chunk-local k & 3) and the host looks at the device
+		// stop flag after each batch.  A launch after convergence still costs ~2.5 us per kernel and a look costs a
+		// host round trip, so the first batch is sized from the previous solve of this run.
+		const int fixedChunk = pcgCheckEvery > 0 ? (pcgCheckEvery + 3) / 4 * 4 : 0;
 		int* hInts = (int*)((char*)h_pinned + 1024);
 		bool converged = false;
-		if (useGraph && (!pcgGraphExec || pcgGraphChunk != chunk || pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter || pcgGraphAcinv != sys.acinv))
-			buildPcgGraph(chunk, maxIter, tol2);
-		for (int k0 = 0; k0 < maxIter && !converged; k0 += chunk)
+		int k0 = 0, looks = 0;
+		// prediction: within an LM run the damping shrinks geometrically and the iteration count grows by a fairly steady
+		// factor from solve to solve, so extrapolate the last two counts of this run
+		int predicted = 32;
+		if (runIters.size() >= 2)
 		{
-			const int k1 = std::min(maxIter, k0 + chunk);
-			if (useGraph) HIP_TRY(hipGraphLaunch(pcgGraphExec, stream));
-			else for (int k = k0; k < k1; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
+			const double a = runIters[runIters.size() - 2], b = runIters.back();
+			predicted = (int)(b * std::min(1.35, std::max(1.0, b / std::max(1.0, a)))) + 4;
+		}
+		else if (runIters.size() == 1) predicted = (int)(1.35 * runIters[0]) + 4;
+		else if (firstSolveIters > 0) predicted = firstSolveIters + 4;
+		int target = fixedChunk ? fixedChunk : (predicted + 3) / 4 * 4;
+		while (k0 < maxIter && !converged)
+		{
+			int todo = std::max(4, std::min(target, maxIter) - k0);
+			while (todo > 0)
+			{
+				const int c = fixedChunk ? fixedChunk : (todo >= 32 ? 32 : todo >= 16 ? 16 : todo >= 8 ? 8 : 4);
+				if (useGraph) HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2), stream));
+				else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
+				k0 += c; todo -= c;
+			}
 			HIP_TRY(hipMemcpyAsync(hInts, d_fail.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts + 1, d_iters.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hInts + 2, d_done.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
 			sync();
-			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; return false; }
-			if (hInts[2] != 0 || hInts[1] < k1) converged = true;   // the device-side stop test fired
+			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; lastSolveIters = 0; return false; }
+			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
+			target = k0 + (fixedChunk ? fixedChunk : std::max(8, k0 / 8 / 4 * 4));
+			looks++;
 		}
+		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued, %d host looks (prediction %d)\n", hInts[1], k0, looks, predicted);
 		cntPcgIters += hInts[1];
+		if (runIters.empty()) firstSolveIters = hInts[1];
+		runIters.push_back(hInts[1]);
 		lastSolveIters = hInts[1];
 		if (coarseFresh) itersAtRefresh = hInts[1];
 		return true;   // hitting max_iter returns the best iterate, like an inexact LM step
@@ -781,6 +811,7 @@ struct cuba_hip_solver
 	{
 		need();
 		coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
+		runIters.clear();
 		const int maxq = 10;
 		const double tau = 1e-5;
 		double nu = 2, lam = 0, F = 0;
