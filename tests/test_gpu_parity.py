@@ -268,6 +268,32 @@ def test_reinitialize_and_repeat(solvers, small_fp):
     assert rel(got, ref) < CHI2_TOL
 
 
+def test_same_topology_reuses_structure_new_values_only(solvers, small_fp):
+    """set_graph with the same vertices/edges but new values keeps the device-side structure (the samples'
+    warm-up + timed protocol); a changed edge set rebuilds it.  Both must match a fresh handle and the oracle."""
+    import copy
+    HipSolver, OracleSolver = solvers
+    h = HipSolver(small_fp, RK_HUBER)
+    h.optimize(2)
+    fp2 = copy.deepcopy(small_fp)
+    rng = np.random.default_rng(5)
+    fp2.Xw = fp2.Xw + rng.normal(0, 0.02, fp2.Xw.shape)          # same topology, other values
+    fp2.meas = fp2.meas + rng.normal(0, 0.3, fp2.meas.shape)
+    h.set_graph(fp2)
+    assert h.counters()["hsc_blocks"] > 0                          # structure still there without build_structure()
+    got = h.optimize(4)["chi2"]
+    fresh = HipSolver(fp2, RK_HUBER).optimize(4)["chi2"]
+    ref = OracleSolver(fp2, RK_HUBER).optimize(4)["chi2"]
+    assert np.array_equal(got, fresh) and rel(got, ref) < CHI2_TOL
+    fp3 = copy.deepcopy(fp2)                                       # drop the last edge: topology changed
+    for name in ("eP", "eL", "eDim", "omega", "meas", "edge_src"):
+        setattr(fp3, name, getattr(fp3, name)[:-1].copy())
+    h.set_graph(fp3)
+    got = h.optimize(4)["chi2"]
+    ref = OracleSolver(fp3, RK_HUBER).optimize(4)["chi2"]
+    assert rel(got, ref) < CHI2_TOL
+
+
 def test_float32_build_variant(solvers, small_fp):
     """libcuba_hip_f32.so = the reference's USE_FLOAT32 option (src/scalar.h:25-29): same ABI (double at the
     boundary), single precision on the device.  Tolerance: chi2 1e-4 relative, estimates 1e-3 RMSE (fp32 round-off)."""
