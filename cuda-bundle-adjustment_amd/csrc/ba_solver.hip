@@ -16,6 +16,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -181,6 +182,7 @@ struct cuba_hip_solver
 	bool coarseValid = false, coarseFresh = false;
 	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
 	double coarseGrowth = 1.25;  // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
+	std::vector<Scalar> h_stage[6];          // host staging of set_graph (sorted measurements, state, cameras)
 	std::vector<int> h_spose[2], h_slm[2];   // sorted edge->pose (with the stereo bit) / edge->landmark of this and the previous set_graph
 	int topoSlot = 0;
 	std::vector<int> runIters;   // PCG iterations of the solves of the current LM run (sizes the next batch of launches)
@@ -245,6 +247,21 @@ struct cuba_hip_solver
 		for (auto& x : th) x.join();
 	}
 
+	// uniform version: fn(i) for i in [0, n)
+	template <class F>
+	static void parallelFor(int n, F&& fn)
+	{
+		const int T = (int)std::min<long long>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / 50000 + 1);
+		if (T <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++)
+		{
+			const int r0 = (int)((long long)n * t / T), r1 = (int)((long long)n * (t + 1) / T);
+			th.emplace_back([=, &fn] { for (int i = r0; i < r1; i++) fn(i); });
+		}
+		for (auto& x : th) x.join();
+	}
+
 	// set-up phase breakdown on stderr when CUBA_HIP_DEBUG is set
 	Clock::time_point lapT;
 	void lap(const char* what)
@@ -284,11 +301,16 @@ struct cuba_hip_solver
 		const bool sameCounts = haveStructure && partHi < 0 && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_;
 		Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
 		haveStructure = false;
-		for (int e = 0; e < E; e++)
 		{
-			if (ep[e] < 0 || ep[e] >= Pt || el[e] < 0 || el[e] >= Lt) throw ArgError{ "edge index out of range" };
-			if (edim[e] != 2 && edim[e] != 3) throw ArgError{ "edge_dim must be 2 or 3" };
-			if (ep[e] >= Pf && el[e] >= Lf) throw ArgError{ "edge with both ends fixed (must be dropped by the caller)" };
+			std::atomic<int> bad{ 0 };
+			parallelFor(E, [&](int e) {
+				if (ep[e] < 0 || ep[e] >= Pt || el[e] < 0 || el[e] >= Lt) bad.store(1, std::memory_order_relaxed);
+				else if (edim[e] != 2 && edim[e] != 3) bad.store(2, std::memory_order_relaxed);
+				else if (ep[e] >= Pf && el[e] >= Lf) bad.store(3, std::memory_order_relaxed);
+			});
+			if (bad == 1) throw ArgError{ "edge index out of range" };
+			if (bad == 2) throw ArgError{ "edge_dim must be 2 or 3" };
+			if (bad == 3) throw ArgError{ "edge with both ends fixed (must be dropped by the caller)" };
 		}
 		lap(nullptr);
 		// sort edges by (landmark, pose, original index): counting sort on the landmark, small sorts inside
@@ -299,20 +321,22 @@ struct cuba_hip_solver
 		{
 			std::vector<int> cursor(h_lmptr.begin(), h_lmptr.end() - 1);
 			for (int e = 0; e < E; e++) perm[cursor[el[e]]++] = e;
-			for (int l = 0; l < Lt; l++)
+			std::vector<long long> byEdges(h_lmptr.begin(), h_lmptr.end());    // balance the small sorts by edge count
+			parallelRows(Lt, byEdges, [&](int l) {
 				std::sort(perm.begin() + h_lmptr[l], perm.begin() + h_lmptr[l + 1],
 					[&](int a, int b) { return ep[a] != ep[b] ? ep[a] < ep[b] : a < b; });
+			});
 		}
 		lap("set_graph: validate + sort edges");
 		std::vector<int>& sPose = h_spose[topoSlot ^ 1];   // the previous call's sorted index arrays stay in the other slot
 		std::vector<int>& sLm = h_slm[topoSlot ^ 1];
 		sPose.resize(E); sLm.resize(E);
-		std::vector<Scalar> mu(E), mv(E), mr(E), w(E);
-		h_epose.assign(E, 0);
+		// staging buffers are members: a second set_graph of similar size touches no fresh pages
+		std::vector<Scalar>&mu = h_stage[0], &mv = h_stage[1], &mr = h_stage[2], &w = h_stage[3], &state = h_stage[4], &camv = h_stage[5];
+		mu.resize(E); mv.resize(E); mr.resize(E); w.resize(E);
+		h_epose.resize(E);
 		{
-			std::vector<long long> uniform(E + 1);
-			for (int i = 0; i <= E; i++) uniform[i] = i;
-			parallelRows(E, uniform, [&](int i) {       // random gather through the sort permutation
+			parallelFor(E, [&](int i) {       // random gather through the sort permutation
 				const int e = perm[i];
 				h_epose[i] = ep[e];
 				sPose[i] = ep[e] | (edim[e] == 3 ? STEREO_BIT : 0);
@@ -322,11 +346,11 @@ struct cuba_hip_solver
 				w[i] = omega[e];
 			});
 		}
-		std::vector<Scalar> state((size_t)7 * Pt + (size_t)3 * Lt);
+		state.resize((size_t)7 * Pt + (size_t)3 * Lt);
 		for (size_t i = 0; i < (size_t)4 * Pt; i++) state[i] = (Scalar)q[i];
 		for (size_t i = 0; i < (size_t)3 * Pt; i++) state[4 * (size_t)Pt + i] = (Scalar)t[i];
 		for (size_t i = 0; i < (size_t)3 * Lt; i++) state[7 * (size_t)Pt + i] = (Scalar)Xw[i];
-		std::vector<Scalar> camv(cam, cam + 5 * (size_t)Pt);
+		camv.assign(cam, cam + 5 * (size_t)Pt);
 
 		// Same vertices, same edges (in sorted order, same types) as last time: everything build_structure() derives from
 		// the topology is still valid on the device -- only the values are new (the samples' warm-up + timed protocol,

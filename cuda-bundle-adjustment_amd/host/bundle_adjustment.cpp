@@ -74,8 +74,8 @@ public:
 	}
 
 	// ---- graph editing (ref :681-764) -----------------------------------------------------------
-	void addPoseVertex(PoseVertex* v) override { poses_.insert({ v->id, v }); }
-	void addLandmarkVertex(LandmarkVertex* v) override { landmarks_.insert({ v->id, v }); }
+	void addPoseVertex(PoseVertex* v) override { poses_.insert({ v->id, v }); posesDirty_ = true; }
+	void addLandmarkVertex(LandmarkVertex* v) override { landmarks_.insert({ v->id, v }); landmarksDirty_ = true; }
 
 	void addMonocularEdge(MonoEdge* e) override
 	{
@@ -101,6 +101,7 @@ public:
 		const std::vector<BaseEdge*> incident(it->second->edges.begin(), it->second->edges.end());
 		for (BaseEdge* e : incident) removeEdge(e);
 		poses_.erase(it);
+		posesDirty_ = true;
 	}
 
 	void removeLandmarkVertex(LandmarkVertex* v) override
@@ -110,6 +111,7 @@ public:
 		const std::vector<BaseEdge*> incident(it->second->edges.begin(), it->second->edges.end());
 		for (BaseEdge* e : incident) removeEdge(e);
 		landmarks_.erase(it);
+		landmarksDirty_ = true;
 	}
 
 	void removeEdge(BaseEdge* e) override
@@ -136,46 +138,31 @@ public:
 	void initialize() override
 	{
 		const auto t0 = std::chrono::steady_clock::now();
-		buildChiIndex();                 // results of the previous optimize() stay queryable (they refer to the old edge list)
+		// results of the previous optimize() stay queryable: they refer to the old edge list, which is set aside (a
+		// move) instead of being indexed here -- the index over 561 k edges costs more than the rest of initialize()
+		if (!chiIndexBuilt_ && chiEdges_.empty()) chiEdges_ = std::move(activeEdges_);
 		activePoses_.clear(); activeLandmarks_.clear(); activeEdges_.clear();
-		q_.clear(); t_.clear(); cam_.clear(); Xw_.clear();
 		edgePose_.clear(); edgeLandmark_.clear(); edgeDim_.clear(); meas_.clear(); omega_.clear();
 
-		std::vector<PoseVertex*> fixedP;
-		std::vector<LandmarkVertex*> fixedL;
-		for (const auto& kv : poses_)           // id order; vertices without edges take no part
-		{
-			PoseVertex* v = kv.second;
-			if (v->edges.empty()) continue;
-			(v->fixed ? fixedP : activePoses_).push_back(v);
-		}
-		numFreePoses_ = static_cast<int>(activePoses_.size());
-		activePoses_.insert(activePoses_.end(), fixedP.begin(), fixedP.end());
-		for (const auto& kv : landmarks_)
-		{
-			LandmarkVertex* v = kv.second;
-			if (v->edges.empty()) continue;
-			(v->fixed ? fixedL : activeLandmarks_).push_back(v);
-		}
-		numFreeLandmarks_ = static_cast<int>(activeLandmarks_.size());
-		activeLandmarks_.insert(activeLandmarks_.end(), fixedL.begin(), fixedL.end());
-
-		for (size_t i = 0; i < activePoses_.size(); i++)
-		{
-			PoseVertex* v = activePoses_[i];
-			v->iP = static_cast<int>(i);
-			const double* qc = v->q.coeffs().data();       // (x, y, z, w)
-			q_.insert(q_.end(), qc, qc + 4);
-			t_.insert(t_.end(), v->t.data(), v->t.data() + 3);
-			const double c[5] = { v->camera.fx, v->camera.fy, v->camera.cx, v->camera.cy, v->camera.bf };
-			cam_.insert(cam_.end(), c, c + 5);
-		}
-		for (size_t i = 0; i < activeLandmarks_.size(); i++)
-		{
-			LandmarkVertex* v = activeLandmarks_[i];
-			v->iL = static_cast<int>(i);
-			Xw_.insert(Xw_.end(), v->Xw.data(), v->Xw.data() + 3);
-		}
+		// vertices in id order (the reference walks its std::maps), free ones first, vertices without edges left out
+		// (ref :128-200).  The id-ordered pointer lists are cached between calls as long as no vertex was added or
+		// removed, and the sweep over them (one dependent load per vertex) is split over a few host threads.
+		if (posesDirty_) { poseList_.clear(); for (const auto& kv : poses_) poseList_.push_back(kv.second); posesDirty_ = false; }
+		if (landmarksDirty_) { landmarkList_.clear(); for (const auto& kv : landmarks_) landmarkList_.push_back(kv.second); landmarksDirty_ = false; }
+		numFreePoses_ = indexVertices(poseList_, activePoses_, [&](size_t n) { q_.resize(4 * n); t_.resize(3 * n); cam_.resize(5 * n); },
+			[&](PoseVertex* v, size_t i) {
+				v->iP = static_cast<int>(i);
+				const double* qc = v->q.coeffs().data();       // (x, y, z, w)
+				std::copy(qc, qc + 4, q_.begin() + 4 * i);
+				std::copy(v->t.data(), v->t.data() + 3, t_.begin() + 3 * i);
+				const double c[5] = { v->camera.fx, v->camera.fy, v->camera.cx, v->camera.cy, v->camera.bf };
+				std::copy(c, c + 5, cam_.begin() + 5 * i);
+			});
+		numFreeLandmarks_ = indexVertices(landmarkList_, activeLandmarks_, [&](size_t n) { Xw_.resize(3 * n); },
+			[&](LandmarkVertex* v, size_t i) {
+				v->iL = static_cast<int>(i);
+				std::copy(v->Xw.data(), v->Xw.data() + 3, Xw_.begin() + 3 * i);
+			});
 		// edges: mono first, then stereo, insertion order inside each type; edges with both ends fixed are inactive
 		// (ref :204-243).  561 k edges mean 561 k dependent pointer loads (edge -> vertex -> index), so the sweep is
 		// split over a few host threads: count the active edges per chunk, prefix-sum, fill.
@@ -184,16 +171,10 @@ public:
 		const size_t nM = ms.size(), nAll = nM + ss.size();
 		auto edgeAt = [&](size_t k) -> BaseEdge* { return k < nM ? static_cast<BaseEdge*>(ms[k]) : static_cast<BaseEdge*>(ss[k - nM]); };
 		auto isActive = [&](BaseEdge* e) { return e && !(e->poseVertex()->fixed && e->landmarkVertex()->fixed); };
-		const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), nAll / 20000 + 1));
+		const unsigned T = hostThreads(nAll);
 		std::vector<size_t> cnt(T + 1, 0);
 		auto chunk = [&](unsigned t) { return std::make_pair(nAll * t / T, nAll * (t + 1) / T); };
-		auto forThreads = [&](auto&& fn) {
-			if (T == 1) { fn(0u); return; }
-			std::vector<std::thread> th;
-			for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t);
-			for (auto& x : th) x.join();
-		};
-		forThreads([&](unsigned t) {
+		forThreads(T, [&](unsigned t) {
 			size_t c = 0;
 			for (size_t k = chunk(t).first; k < chunk(t).second; k++) c += isActive(edgeAt(k));
 			cnt[t + 1] = c;
@@ -202,7 +183,7 @@ public:
 		const size_t nAct = cnt[T];
 		activeEdges_.resize(nAct); edgePose_.resize(nAct); edgeLandmark_.resize(nAct); edgeDim_.resize(nAct);
 		meas_.resize(3 * nAct); omega_.resize(nAct);
-		forThreads([&](unsigned t) {
+		forThreads(T, [&](unsigned t) {
 			size_t o = cnt[t];
 			for (size_t k = chunk(t).first; k < chunk(t).second; k++)
 			{
@@ -273,6 +254,7 @@ public:
 		perEdgeChi_.resize(activeEdges_.size());
 		check(cuba_hip_chi_squares(solver_, perEdgeChi_.data()), "cuba_hip_chi_squares");
 		chiSqs_.clear();
+		chiEdges_.clear();
 		chiIndexBuilt_ = false;          // the edge -> value index is built on the first chiSquared() query
 
 		double prof[CUBA_HIP_PROFILE_ITEMS];
@@ -300,11 +282,63 @@ public:
 	}
 
 private:
+	static unsigned hostThreads(size_t items)
+	{
+		return (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), items / 20000 + 1));
+	}
+
+	template <class Fn>
+	static void forThreads(unsigned T, Fn&& fn)
+	{
+		if (T == 1) { fn(0u); return; }
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t);
+		for (auto& x : th) x.join();
+	}
+
+	// active = [free vertices in list order | fixed vertices in list order], vertices without edges skipped;
+	// emit(v, solver index) runs once per active vertex.  Returns the number of free ones.
+	template <class V, class Resize, class Emit>
+	static int indexVertices(const std::vector<V*>& list, std::vector<V*>& active, Resize&& resize, Emit&& emit)
+	{
+		const size_t n = list.size();
+		const unsigned T = hostThreads(n);
+		std::vector<size_t> nFree(T + 1, 0), nFixed(T + 1, 0);
+		forThreads(T, [&](unsigned t) {
+			size_t a = 0, b = 0;
+			for (size_t k = n * t / T; k < n * (t + 1) / T; k++)
+			{
+				const V* v = list[k];
+				if (v->edges.empty()) continue;
+				(v->fixed ? b : a)++;
+			}
+			nFree[t + 1] = a; nFixed[t + 1] = b;
+		});
+		for (unsigned t = 0; t < T; t++) { nFree[t + 1] += nFree[t]; nFixed[t + 1] += nFixed[t]; }
+		const size_t freeTotal = nFree[T];
+		active.resize(freeTotal + nFixed[T]);
+		resize(active.size());
+		forThreads(T, [&](unsigned t) {
+			size_t a = nFree[t], b = freeTotal + nFixed[t];
+			for (size_t k = n * t / T; k < n * (t + 1) / T; k++)
+			{
+				V* v = list[k];
+				if (v->edges.empty()) continue;
+				const size_t i = v->fixed ? b++ : a++;
+				active[i] = v;
+				emit(v, i);
+			}
+		});
+		return static_cast<int>(freeTotal);
+	}
+
 	void buildChiIndex() const
 	{
 		if (chiIndexBuilt_) return;
+		const std::vector<BaseEdge*>& edges = chiEdges_.empty() ? activeEdges_ : chiEdges_;   // set aside by initialize()?
 		chiSqs_.reserve(perEdgeChi_.size());
-		for (size_t i = 0; i < perEdgeChi_.size(); i++) chiSqs_[activeEdges_[i]] = perEdgeChi_[i];
+		for (size_t i = 0; i < perEdgeChi_.size(); i++) chiSqs_[edges[i]] = perEdgeChi_[i];
+		chiEdges_.clear(); chiEdges_.shrink_to_fit();
 		chiIndexBuilt_ = true;
 	}
 
@@ -319,6 +353,9 @@ private:
 
 	std::map<int, PoseVertex*> poses_;
 	std::map<int, LandmarkVertex*> landmarks_;
+	std::vector<PoseVertex*> poseList_;           // the maps' values in id order, rebuilt when a vertex was added / removed
+	std::vector<LandmarkVertex*> landmarkList_;
+	bool posesDirty_ = true, landmarksDirty_ = true;
 	OrderedSet<MonoEdge> mono_;
 	OrderedSet<StereoEdge> stereo_;
 	int robustKind_[2] = { 0, 0 };
@@ -341,6 +378,7 @@ private:
 	std::vector<double> perEdgeChi_;
 	mutable std::unordered_map<const BaseEdge*, double> chiSqs_;
 	mutable bool chiIndexBuilt_ = true;
+	mutable std::vector<BaseEdge*> chiEdges_;   // edge list the pending per-edge results refer to, once initialize() replaced activeEdges_
 };
 
 }  // namespace
