@@ -23,6 +23,7 @@
 
 #include "../../include/cuba_hip.h"
 #include "ba_kernels.hpp"
+#include "host_pool.hpp"
 
 using namespace cubahip;
 
@@ -182,6 +183,8 @@ struct cuba_hip_solver
 	bool coarseValid = false, coarseFresh = false;
 	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
 	double coarseGrowth = 1.25;  // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
+	struct PatternEntry { uint64_t key; int ea, eb; };   // (column << 32 | product id + 1), the product's two sorted-edge ids
+	std::vector<PatternEntry> h_ent; std::vector<int> h_work[6];   // work arrays of build_structure
 	std::vector<Scalar> h_stage[6];          // host staging of set_graph (sorted measurements, state, cameras)
 	std::vector<int> h_spose[2], h_slm[2];   // sorted edge->pose (with the stereo bit) / edge->landmark of this and the previous set_graph
 	int topoSlot = 0;
@@ -227,39 +230,33 @@ struct cuba_hip_solver
 		sync();
 	}
 
-	// run fn(row) for all rows on a few host threads, rows split into contiguous chunks of similar weight
+	// run fn(row) for all rows on a few host threads (persistent pool), rows split into contiguous chunks of similar weight
 	template <class F>
 	static void parallelRows(int nrows, const std::vector<long long>& start, F&& fn)
 	{
 		const long long total = nrows > 0 ? start[nrows] - start[0] : 0;
-		int T = (int)std::min<long long>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), total / 50000 + 1);
+		const int T = (int)std::min<long long>(HostPool::instance().maxThreads(), total / 50000 + 1);
 		if (T <= 1) { for (int i = 0; i < nrows; i++) fn(i); return; }
-		std::vector<std::thread> th;
-		int r0 = 0;
-		for (int t = 0; t < T; t++)
+		std::vector<int> cut(T + 1, 0);
+		for (int t = 1; t < T; t++)
 		{
-			const long long target = start[0] + total * (t + 1) / T;
-			int r1 = t == T - 1 ? nrows : (int)(std::upper_bound(start.begin(), start.begin() + nrows + 1, target) - start.begin()) - 1;
-			r1 = std::max(r1, r0);
-			th.emplace_back([=, &fn] { for (int i = r0; i < r1; i++) fn(i); });
-			r0 = r1;
+			const long long target = start[0] + total * t / T;
+			cut[t] = std::max(cut[t - 1], (int)(std::upper_bound(start.begin(), start.begin() + nrows + 1, target) - start.begin()) - 1);
 		}
-		for (auto& x : th) x.join();
+		cut[T] = nrows;
+		HostPool::instance().run(T, [&](int t) { for (int i = cut[t]; i < cut[t + 1]; i++) fn(i); });
 	}
 
 	// uniform version: fn(i) for i in [0, n)
 	template <class F>
 	static void parallelFor(int n, F&& fn)
 	{
-		const int T = (int)std::min<long long>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / 50000 + 1);
+		const int T = (int)std::min<long long>(HostPool::instance().maxThreads(), n / 50000 + 1);
 		if (T <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; t++)
-		{
+		HostPool::instance().run(T, [&](int t) {
 			const int r0 = (int)((long long)n * t / T), r1 = (int)((long long)n * (t + 1) / T);
-			th.emplace_back([=, &fn] { for (int i = r0; i < r1; i++) fn(i); });
-		}
-		for (auto& x : th) x.join();
+			for (int i = r0; i < r1; i++) fn(i);
+		});
 	}
 
 	// set-up phase breakdown on stderr when CUBA_HIP_DEBUG is set
@@ -298,7 +295,8 @@ struct cuba_hip_solver
 		if (Pt_ >= STEREO_BIT) throw ArgError{ "too many poses" };
 		if ((Pt_ && (!q || !t || !cam)) || (Lt_ && !Xw) || (E_ && (!ep || !el || !edim || !meas || !omega))) throw ArgError{ "null array" };
 		const auto t0 = Clock::now();
-		const bool sameCounts = haveStructure && partHi < 0 && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_;
+		static const bool noCache = std::getenv("CUBA_HIP_NO_STRUCTURE_CACHE") != nullptr;   // A/B knob for set-up timings
+		const bool sameCounts = !noCache && haveStructure && partHi < 0 && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_;
 		Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
 		haveStructure = false;
 		{
@@ -412,65 +410,116 @@ struct cuba_hip_solver
 		std::vector<long long> pairBase(Lf, 0);
 		nmul = 0;
 		long long npairs = 0;
+		parallelFor(Lf, [&](int l) {
+			int n = 0;
+			for (int i = h_lmptr[l]; i < h_lmptr[l + 1]; i++) n += h_epose[i] < Pf;   // edges are sorted by pose: the free ones come first
+			nfree[l] = n;
+		});
 		for (int l = 0; l < Lf; l++)
 		{
-			int n = 0;
-			for (int i = h_lmptr[l]; i < h_lmptr[l + 1]; i++) n += h_epose[i] < Pf;
-			nfree[l] = n;
+			const int n = nfree[l];
 			pairBase[l] = npairs;
 			npairs += (long long)n * (n - 1) / 2;
 			nmul += (long long)n * (n + 1) / 2;
 		}
 		if (npairs >= (1LL << 31)) throw ArgError{ "graph too dense: more than 2^31 Schur block products" };
 		lap(nullptr);
-		// Pattern of Hsc + destination block of every product in one pass: bucket the (column, product id) pairs by
-		// block row, sort every row on its own (cache resident, rows spread over host threads), then walk the
-		// sorted rows: a new column opens a new block, every product learns its block id.
-		std::vector<long long> rowStart(Pf + 1, 0);
-		for (int i = 0; i < Pf; i++) rowStart[i + 1] = 1;                    // the diagonal block always exists
-		for (int l = 0; l < Lf; l++)
+		// Pattern of Hsc + product lists: bucket the (column, product id) pairs by block row, sort every row on its own
+		// (cache resident, rows spread over host threads), then walk the sorted rows: a new column opens a new block,
+		// and the products of a block are the consecutive entries with its column, already in landmark order (product
+		// ids grow with the landmark index) -- the fixed summation order that makes the results reproducible.
+		// per free pose: its edges (sorted-edge ids, ascending = landmark order), over the whole graph
+		std::vector<int> peAllPtr(Pf + 1, 0);
+		std::vector<int>& peAll = h_work[5];
+		for (int i = 0; i < E; i++) if (h_epose[i] < Pf) peAllPtr[h_epose[i] + 1]++;
+		for (int i = 0; i < Pf; i++) peAllPtr[i + 1] += peAllPtr[i];
+		peAll.resize(peAllPtr[Pf]);
 		{
-			const int b0 = h_lmptr[l], n = nfree[l];
-			for (int a2 = 0; a2 < n; a2++) rowStart[h_epose[b0 + a2] + 1] += n - 1 - a2;
+			std::vector<int> cur(peAllPtr.begin(), peAllPtr.end() - 1);
+			for (int i = 0; i < E; i++) if (h_epose[i] < Pf) peAll[cur[h_epose[i]]++] = i;
 		}
-		for (int i = 0; i < Pf; i++) rowStart[i + 1] += rowStart[i];
-		std::vector<uint64_t> ent((size_t)rowStart[Pf]);
+		lap("structure:   nfree + pose lists");
+		const std::vector<int>& slm = h_slm[topoSlot];          // sorted edge -> landmark (set_graph)
+		std::vector<long long> peWeight(peAllPtr.begin(), peAllPtr.end());
+		// row i of the pattern collects, for every landmark pose i sees, the poses after it in that landmark's edge list:
+		// each row is produced by one thread into its own segment (no atomics)
+		std::vector<long long> rowStart(Pf + 1, 0);
 		{
-			std::vector<long long> cur(rowStart.begin(), rowStart.end() - 1);
-			for (int i = 0; i < Pf; i++) ent[cur[i]++] = (uint64_t)i << 32;   // id 0 = diagonal seed, sorts first
-			for (int l = 0; l < Lf; l++)
-			{
-				const int b0 = h_lmptr[l], n = nfree[l];
-				long long idx = pairBase[l];
-				for (int a2 = 0; a2 < n; a2++)
+			std::vector<long long> cnt(Pf, 1);                   // the diagonal block always exists
+			parallelRows(Pf, peWeight, [&](int i) {
+				long long c = 1;
+				for (int x = peAllPtr[i]; x < peAllPtr[i + 1]; x++)
 				{
-					const int pa = h_epose[b0 + a2];
-					for (int c = a2 + 1; c < n; c++, idx++) ent[cur[pa]++] = ((uint64_t)h_epose[b0 + c] << 32) | (uint64_t)(idx + 1);
+					const int e = peAll[x], l = slm[e];
+					if (l < Lf) c += nfree[l] - 1 - (e - h_lmptr[l]);
+				}
+				cnt[i] = c;
+			});
+			for (int i = 0; i < Pf; i++) rowStart[i + 1] = rowStart[i] + cnt[i];
+		}
+		lap("structure:   count per row");
+		// (the large work arrays are members: rebuilding for the next graph touches no fresh pages)
+		// an entry carries its two (sorted) edges along: every pass below streams through memory, nothing is looked up
+		// by product id (a product -> edges table is written once per landmark by several rows: cache-line ping-pong)
+		std::vector<PatternEntry>& ent = h_ent; ent.resize((size_t)rowStart[Pf]);
+		parallelRows(Pf, rowStart, [&](int i) {
+			long long slot = rowStart[i];
+			ent[slot++] = PatternEntry{ (uint64_t)i << 32, -1, -1 };                    // id 0 = diagonal seed, sorts first
+			for (int x = peAllPtr[i]; x < peAllPtr[i + 1]; x++)
+			{
+				const int e = peAll[x], l = slm[e];
+				if (l >= Lf) continue;
+				const int b0 = h_lmptr[l], n = nfree[l], a2 = e - b0;
+				long long idx = pairBase[l] + (long long)a2 * (n - 1) - (long long)a2 * (a2 - 1) / 2;   // id of product (a2, a2 + 1)
+				for (int c = a2 + 1; c < n; c++, idx++, slot++)
+				{
+					ent[slot] = PatternEntry{ ((uint64_t)h_epose[b0 + c] << 32) | (uint64_t)(idx + 1), e, b0 + c };
 				}
 			}
-		}
-		std::vector<int> rowBlocks(Pf, 0);
-		parallelRows(Pf, rowStart, [&](int i) {
-			uint64_t* e0 = ent.data() + rowStart[i]; uint64_t* e1 = ent.data() + rowStart[i + 1];
-			std::sort(e0, e1);
-			int u = 0; uint32_t last = 0xffffffffu;
-			for (uint64_t* e = e0; e < e1; e++) { const uint32_t c = (uint32_t)(*e >> 32); u += c != last; last = c; }
-			rowBlocks[i] = u;
 		});
+		lap("structure:   bucket fill");
+		// landmark partition (multi-GPU): the PATTERN is global, the product lists cover the landmarks [lo, hi) only --
+		// product ids are in landmark order, so that is an id range
+		const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
+		const long long idLo = std::min(lo, Lf) < Lf ? pairBase[std::min(lo, Lf)] : npairs;
+		const long long idHi = std::min(hi, Lf) < Lf ? pairBase[std::min(hi, Lf)] : npairs;
+		std::vector<int> rowBlocks(Pf, 0);
+		std::vector<long long> rowProducts(Pf + 1, 0);
+		parallelRows(Pf, rowStart, [&](int i) {
+			PatternEntry* e0 = ent.data() + rowStart[i]; PatternEntry* e1 = ent.data() + rowStart[i + 1];
+			std::sort(e0, e1, [](const PatternEntry& x, const PatternEntry& y) { return x.key < y.key; });
+			int u = 0; uint32_t last = 0xffffffffu; long long np = 0;
+			for (PatternEntry* e = e0; e < e1; e++)
+			{
+				const uint32_t c = (uint32_t)(e->key >> 32); u += c != last; last = c;
+				const long long id = (long long)(uint32_t)e->key - 1;
+				np += id >= idLo && id < idHi;
+			}
+			rowBlocks[i] = u; rowProducts[i + 1] = np;
+		});
+		lap("structure:   row sorts");
 		h_rowptr.assign(Pf + 1, 0);
-		for (int i = 0; i < Pf; i++) h_rowptr[i + 1] = h_rowptr[i] + rowBlocks[i];
+		for (int i = 0; i < Pf; i++) { h_rowptr[i + 1] = h_rowptr[i] + rowBlocks[i]; rowProducts[i + 1] += rowProducts[i]; }
 		const int nblk = h_rowptr[Pf];
+		const long long nprodLocal = rowProducts[Pf];
 		h_colind.assign(nblk, 0);
-		std::vector<int> pairBlk((size_t)npairs);
+		std::vector<int> blkRow(nblk), prodPtr(nblk + 1, 0), odBlocks;
+		std::vector<int>&prodEa = h_work[2], &prodEb = h_work[3], &pairBlk = h_work[4];
+		prodEa.resize((size_t)nprodLocal); prodEb.resize((size_t)nprodLocal);
+		pairBlk.resize(schurAtomic ? (size_t)npairs : 0);                  // product -> block, only the first-generation kernel wants it
 		parallelRows(Pf, rowStart, [&](int i) {
 			int k = h_rowptr[i] - 1; uint32_t last = 0xffffffffu;
+			long long out = rowProducts[i];
 			for (long long x = rowStart[i]; x < rowStart[i + 1]; x++)
 			{
-				const uint32_t c = (uint32_t)(ent[x] >> 32); const uint32_t id = (uint32_t)ent[x];
-				if (c != last) { k++; h_colind[k] = (int)c; last = c; }
-				if (id) pairBlk[id - 1] = k | ((int)c == i ? 0x40000000 : 0);
+				const uint32_t c = (uint32_t)(ent[x].key >> 32); const uint32_t id = (uint32_t)ent[x].key;
+				if (c != last) { k++; h_colind[k] = (int)c; blkRow[k] = i; prodPtr[k] = (int)out; last = c; }
+				if (!id) continue;
+				if (schurAtomic) pairBlk[id - 1] = k | ((int)c == i ? 0x40000000 : 0);
+				if ((long long)id - 1 >= idLo && (long long)id - 1 < idHi) { prodEa[out] = ent[x].ea; prodEb[out] = ent[x].eb; out++; }
 			}
 		});
+		prodPtr[nblk] = (int)nprodLocal;
 		lap("structure: Hsc pattern + product blocks");
 		// symmetric adjacency over the upper storage
 		std::vector<int> adjPtr(Pf + 1, 0);
@@ -495,42 +544,20 @@ struct cuba_hip_solver
 				for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) { adjBlk[cur[i]] = k; adjCol[cur[i]] = h_colind[k]; cur[i]++; }
 		}
 		lap("structure: adjacency");
-		// landmark partition (multi-GPU): the PATTERN above is global, everything below covers [lo, hi) only
-		const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
 		g.e_begin = h_lmptr[lo]; g.e_end = h_lmptr[hi];
-		// destination-major product lists: for every block the (edge of row pose, edge of column pose) pairs of all
-		// landmarks seen by both poses, in landmark order (fixed summation order => reproducible results)
-		std::vector<int> blkRow(nblk), prodPtr(nblk + 1, 0), prodEa((size_t)npairs), prodEb((size_t)npairs), odBlocks;
-		for (int i = 0; i < Pf; i++)
-			for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++) blkRow[k] = i;
-		for (int l = std::min(lo, Lf); l < std::min(hi, Lf); l++)
-			for (long long i = pairBase[l], iend = pairBase[l] + (long long)nfree[l] * (nfree[l] - 1) / 2; i < iend; i++)
-				prodPtr[(pairBlk[i] & 0x3fffffff) + 1]++;
-		for (int k = 0; k < nblk; k++) prodPtr[k + 1] += prodPtr[k];
-		{
-			std::vector<int> cur(prodPtr.begin(), prodPtr.end() - 1);
-			for (int l = std::min(lo, Lf); l < std::min(hi, Lf); l++)
-			{
-				const int b = h_lmptr[l], n = nfree[l];
-				long long idx = pairBase[l];
-				for (int a = 0; a < n; a++)
-					for (int c = a + 1; c < n; c++, idx++)
-					{
-						const int k = pairBlk[idx] & 0x3fffffff;
-						prodEa[cur[k]] = b + a; prodEb[cur[k]] = b + c; cur[k]++;
-					}
-			}
-			for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k);
-			std::stable_sort(odBlocks.begin(), odBlocks.end(), [&](int x, int y) {
-				return prodPtr[x + 1] - prodPtr[x] > prodPtr[y + 1] - prodPtr[y]; });
-		}
+		// blocks with products, longest lists first (the block pass takes them in this order)
+		for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k);
+		std::stable_sort(odBlocks.begin(), odBlocks.end(), [&](int x, int y) {
+			return prodPtr[x + 1] - prodPtr[x] > prodPtr[y + 1] - prodPtr[y]; });
 		lap("structure: product lists");
-		// per free pose: its edges (sorted-edge ids, ascending)
+		// per free pose: its edges inside this handle's landmark range (a contiguous run of the global list)
 		std::vector<int> pePtr(Pf + 1, 0), peEdge;
-		for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
-		for (int i = 0; i < Pf; i++) pePtr[i + 1] += pePtr[i];
-		peEdge.resize(pePtr[Pf]);
+		if (g.e_begin == 0 && g.e_end == E) { pePtr = peAllPtr; peEdge = peAll; }
+		else
 		{
+			for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
+			for (int i = 0; i < Pf; i++) pePtr[i + 1] += pePtr[i];
+			peEdge.resize(pePtr[Pf]);
 			std::vector<int> cur(pePtr.begin(), pePtr.end() - 1);
 			for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) peEdge[cur[h_epose[i]]++] = i;
 		}
@@ -1086,7 +1113,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
-		else if (k == "schur_atomic") s->schurAtomic = value != 0;
+		else if (k == "schur_atomic") { s->schurAtomic = value != 0; s->haveStructure = false; }   // the product -> block map is built on demand
 		else if (k == "coarse_max_age") s->coarseMaxAge = std::max(0, (int)value);
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "cuba_hip.h"
+#include "../csrc/host_pool.hpp"
 
 namespace cuba
 {
@@ -284,16 +285,13 @@ public:
 private:
 	static unsigned hostThreads(size_t items)
 	{
-		return (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), items / 20000 + 1));
+		return (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)cubahip::HostPool::instance().maxThreads(), items / 20000 + 1));
 	}
 
 	template <class Fn>
 	static void forThreads(unsigned T, Fn&& fn)
 	{
-		if (T == 1) { fn(0u); return; }
-		std::vector<std::thread> th;
-		for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t);
-		for (auto& x : th) x.join();
+		cubahip::HostPool::instance().run((int)T, [&](int t) { fn((unsigned)t); });   // persistent pool shared with the device library
 	}
 
 	// active = [free vertices in list order | fixed vertices in list order], vertices without edges skipped;
