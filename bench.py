@@ -34,7 +34,7 @@ def algorithmic_bytes(fp, nblk, nc):
     return {
         "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
         "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
-        "pcg_spmv": 288 * nblk + 4 * 48 * Pf,
+        "pcg_spmv": 288 * nblk + 4 * 48 * Pf + 8 * (2 * nblk - Pf),     # blocks + z, p in / p, q out + (block, column) index pairs
         # two-level: fused update + restrict + preconditioner (one read of r, q, p, x, Minv, one of the coarse inverse)
         "pcg_update": (288 + 6 * 48) * Pf if nc == 0 else (288 + 7 * 48) * Pf + 8 * Nc * Nc,
         "pcg_precond": 8 * Nc * Nc + 8 * Nc + (288 + 2 * 48) * Pf,
@@ -138,16 +138,20 @@ def main():
         nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + max(16, (fp.Pf + 127) // 128) - 1) // max(16, (fp.Pf + 127) // 128)
         alg = algorithmic_bytes(fp, nblk, nc)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
-                    "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials, "coarse_setup": trials}
+                    "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials,
+                    "coarse_setup": c1["coarse_refreshes"] - c0["coarse_refreshes"]}
         kt = {k: v for k, v in kt.items() if v > 0}
         share = {k: kt[k] * launches[k] for k in kt}
         dom = max(share, key=share.get)
         kernels = {k: {"ms_per_launch": kt[k], "launches": launches[k], "alg_bytes": alg[k],
                        "achieved_GBs": alg[k] / (kt[k] * 1e-3) / 1e9} for k in kt}
         # measured HBM-side traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, see
-        # profiles/r01e_kitti00_pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        # the newest profiles/*_kitti00_pmc_traffic.json, written by scripts/profile_round.sh; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950)
+        import glob
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01e_kitti00_pmc_traffic.json")
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kitti00_pmc_traffic.json")))
+        pmc_path = pmc_files[-1] if pmc_files else ""
         pmc_names = {"pcg_spmv": ["pcg_spmv_kernel"], "pcg_update": ["pcg2_fused_kernel"], "residual_chi2": ["residual_chi2_kernel"],
                      "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1>", "pose_pass_kernel<1>", "block_pass_kernel"]}
         if args.shape == "kitti00" and os.path.exists(pmc_path) and dom in pmc_names:
@@ -156,7 +160,8 @@ def main():
                 traffic = sum(pk[n]["hbm_bytes_fetch_x2"] for n in pmc_names[dom])
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "kernels": kernels}
+                "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "traffic_source": os.path.basename(pmc_path) if traffic else None,
+                "kernels": kernels}
         out = {
             "metric": "edges/sec (edge-iterations/s = E x LM iterations / wall) on KITTI-00-shaped graph, fp64, chi2 vs g2o-faithful oracle",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,7 +174,9 @@ def main():
             "wall_ms_total": elapsed * 1e3,
             "wall_ms_10iter": elapsed * 1e3 * LM_RUN / args.steps,
             "edges_per_s_strict_10iter": E * graphs / (elapsed * LM_RUN / args.steps),
-            "pcg_iterations": pcg_iters, "lm_trials": trials, "hsc_blocks": nblk, "schur_products": c1["schur_products"],
+            "pcg_iterations": pcg_iters, "pcg_iterations_enqueued": c1["pcg_iterations_enqueued"] - c0["pcg_iterations_enqueued"],
+            "pcg_host_looks": c1["pcg_host_looks"] - c0["pcg_host_looks"], "coarse_refreshes": c1["coarse_refreshes"] - c0["coarse_refreshes"],
+            "lm_trials": trials, "hsc_blocks": nblk, "schur_products": c1["schur_products"],
             "final_chi2": float(chi2[-1]),
             "roofline": roof,
         }

@@ -194,7 +194,7 @@ struct cuba_hip_solver
 	double lambda = 0;
 	int maxIterAlloc = 0;
 	long long nmul = 0;
-	int64_t cntPcgIters = 0, cntTrials = 0;
+	int64_t cntPcgIters = 0, cntTrials = 0, cntCoarseRefresh = 0, cntPcgLooks = 0, cntPcgEnqueued = 0;
 	double prof[CUBA_HIP_PROFILE_ITEMS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 
 	~cuba_hip_solver()
@@ -390,7 +390,7 @@ struct cuba_hip_solver
 		haveGraph = true;
 		lambda = 0;
 		for (double& v : prof) v = 0;
-		cntPcgIters = cntTrials = 0;
+		cntPcgIters = cntTrials = cntCoarseRefresh = cntPcgLooks = cntPcgEnqueued = 0;
 		prof[0] += std::chrono::duration<double>(Clock::now() - t0).count();
 	}
 
@@ -789,7 +789,7 @@ struct cuba_hip_solver
 			if (refresh)
 			{
 				launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
-				coarseValid = true; coarseAge = 0;
+				coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
 			}
 			else coarseAge++;
 			coarseFresh = refresh;
@@ -831,10 +831,10 @@ struct cuba_hip_solver
 			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; lastSolveIters = 0; return false; }
 			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 			target = k0 + (fixedChunk ? fixedChunk : std::max(8, k0 / 8 / 4 * 4));
-			looks++;
+			looks++; cntPcgLooks++;
 		}
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued, %d host looks (prediction %d)\n", hInts[1], k0, looks, predicted);
-		cntPcgIters += hInts[1];
+		cntPcgIters += hInts[1]; cntPcgEnqueued += k0;
 		if (runIters.empty()) firstSolveIters = hInts[1];
 		runIters.push_back(hInts[1]);
 		lastSolveIters = hInts[1];
@@ -1221,9 +1221,12 @@ int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITE
 	return guarded(s, [&] { for (int i = 0; i < CUBA_HIP_PROFILE_ITEMS; i++) seconds[i] = s->prof[i]; });
 }
 
-int cuba_hip_get_counters(cuba_hip_solver* s, int64_t c[4])
+int cuba_hip_get_counters(cuba_hip_solver* s, int64_t c[8])
 {
-	return guarded(s, [&] { c[0] = s->cntPcgIters; c[1] = s->cntTrials; c[2] = s->st.nblk; c[3] = s->nmul; });
+	return guarded(s, [&] {
+		c[0] = s->cntPcgIters; c[1] = s->cntTrials; c[2] = s->st.nblk; c[3] = s->nmul;
+		c[4] = s->cntCoarseRefresh; c[5] = s->cntPcgLooks; c[6] = s->cntPcgEnqueued; c[7] = 0;
+	});
 }
 
 int cuba_hip_get_hsc_structure(cuba_hip_solver* s, int32_t* row_ptr, int32_t* col_ind, int* nblk)

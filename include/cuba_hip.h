@@ -173,8 +173,10 @@ int cuba_hip_chi_squares(cuba_hip_solver* s, double* chi2_per_edge);
 int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITEMS]);
 
 /* Counters of the last optimize / solve: [0] PCG iterations (total), [1] LM trials (total),
-   [2] number of 6x6 blocks in upper-triangular Hsc, [3] number of Schur block products (nmul). */
-int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[4]);
+   [2] number of 6x6 blocks in upper-triangular Hsc, [3] number of Schur block products (nmul),
+   [4] coarse-inverse refreshes of the two-level preconditioner, [5] host looks at the device stop flag,
+   [6] PCG iterations enqueued (>= [0]: launches after convergence return at once), [7] reserved. */
+int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
 
 /* ---- introspection (parity tests) and multi-GPU plumbing ------------------------------------------ */
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel-trace stats, HBM traffic counters (separate --pmc passes, no other trace domains),
+# and the bench line.  Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
+#   gpurun -- bash scripts/profile_round.sh r01g
+tag=${1:-round}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+run() { timeout 300 "$@" </dev/null; }
+run rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python $root/scripts/prof_run.py kitti00 5 > $out/${tag}_stats.log 2>&1
+cp "$(find $out/${tag}_stats -name '*kernel_stats.csv' | head -1)" $out/${tag}_kitti00_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  run rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python $root/scripts/prof_run.py kitti00 1 > $out/${tag}_pmc_$c.log 2>&1
+done
+cd $root
+python scripts/pmc_traffic.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE > $out/${tag}_kitti00_pmc_traffic.json
+python bench.py --steps 50 --warmup 10 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+tail -c 600 $out/${tag}_bench.json
