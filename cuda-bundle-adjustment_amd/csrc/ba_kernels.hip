@@ -24,7 +24,7 @@ namespace cubahip
 
 // Stage timestamps for latency studies (scripts/trace_pcg.py): only in the separate libcuba_hip_trace.so build.
 #ifdef CUBA_HIP_TRACE
-__device__ unsigned long long cuba_trace_buf[2][8192 * 8];
+__device__ unsigned long long cuba_trace_buf[3][8192 * 8];
 #define TRACE_DECL unsigned long long tr_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int trn_ = 0; \
 	{ unsigned long long t0_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)); tr_[7] = t0_; }
 #define TRACE_MARK() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr_[trn_++] = wall_clock64(); } while (0)
@@ -92,6 +92,16 @@ __device__ __forceinline__ int vector_load_flag(const int* p)
 	int zero;
 	asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 	return p[zero];
+}
+
+// 1/x for a normal positive x: hardware reciprocal estimate + two Newton steps (full double precision, none of the
+// scaling / fix-up steps of the IEEE division sequence)
+__device__ __forceinline__ Scalar fast_rcp(Scalar x)
+{
+	Scalar r = __builtin_amdgcn_rcp(x);
+	r = r * (Scalar(2) - x * r);
+	r = r * (Scalar(2) - x * r);
+	return r;
 }
 
 // wave-uniform value -> scalar registers (frees the vector registers a long-lived uniform would occupy)
@@ -1558,92 +1568,131 @@ __global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st
 	Ac[(size_t)(st.cb_J[cb] * 6 + c) * Nc + st.cb_I[cb] * 6 + r] = acc;
 }
 
-constexpr int GJ_B = 24;      // pivot block width of the Gauss-Jordan sweep
-constexpr int GJ_T = 32;      // output tile edge
+constexpr int GJ_B = 32;      // pivot block width of the Gauss-Jordan sweep = output tile edge
 
-// One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk): dst = GJ_step(src). After the last step dst = A^-1.
+// One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B: dst = GJ_step(src). After the
+// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile; thread (r, cb) owns the elements (r, cb + 8u),
+// u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32 dependent launches), so:
+//   * every global load of the kernel is issued before the first use (clamped addresses, selected afterwards);
+//   * the pivot block is inverted with 2x2 block pivots -- 16 dependent steps instead of 32, one reciprocal
+//     (v_rcp_f64 + two Newton steps: the pivots of an SPD matrix are positive and well scaled) per step -- ping-ponging
+//     between two LDS copies so that one barrier per step is enough; a thread keeps its own elements in registers;
+//   * the two 32x32x32 products reuse one LDS operand across the thread's four outputs.
 __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk)
 {
 	__shared__ Scalar D[GJ_B][GJ_B + 1];
-	__shared__ Scalar Apj[GJ_B][GJ_T + 1];
-	__shared__ Scalar R[GJ_B][GJ_T + 1];
-	__shared__ Scalar F[GJ_T][GJ_B + 1];
+	__shared__ Scalar D2[GJ_B][GJ_B + 1];
+	__shared__ Scalar Apj[GJ_B][GJ_B + 1];
+	__shared__ Scalar R[GJ_B][GJ_B + 1];
+	__shared__ Scalar F[GJ_B][GJ_B + 1];
 	const int tid = threadIdx.x;
-	const int i0 = blockIdx.y * GJ_T, j0 = blockIdx.x * GJ_T;
-	for (int t = tid; t < GJ_B * GJ_B; t += 256)
+	TRACE_DECL
+	TRACE_MARK();
+	const int i0 = blockIdx.y * GJ_B, j0 = blockIdx.x * GJ_B;
+	const int r = tid & 31, cb = tid >> 5;
+	const bool rowTile = i0 == p0, colTile = j0 == p0;      // this tile lies in the pivot rows / columns
+	Scalar dv[4], av[4], fv[4], sv[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++)
 	{
-		const int r = t % GJ_B, c = t / GJ_B;
-		D[r][c] = (r < bk && c < bk) ? src[(size_t)(p0 + c) * n + p0 + r] : (r == c ? Scalar(1) : Scalar(0));
+		const int c = cb + 8 * u;
+		const size_t pr = (size_t)min(p0 + r, n - 1), pc = (size_t)min(p0 + c, n - 1);
+		const size_t gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + c, n - 1);
+		dv[u] = src[pc * n + pr];      // D[r][c]   = A[p0+r, p0+c]
+		av[u] = src[gj * n + pr];      // Apj[r][c] = A[p0+r, j0+c]
+		fv[u] = src[pc * n + gi];      // F[r][c]   = A[i0+r, p0+c]
+		sv[u] = src[gj * n + gi];      // own tile
 	}
-	for (int t = tid; t < GJ_B * GJ_T; t += 256)
+#pragma unroll
+	for (int u = 0; u < 4; u++)
 	{
-		const int k = t % GJ_B, c = t / GJ_B;      // Apj[k][c] = A[p0+k, j0+c]
-		Apj[k][c] = (k < bk && j0 + c < n) ? src[(size_t)(j0 + c) * n + p0 + k] : Scalar(0);
-		const int r = t % GJ_T, kk = t / GJ_T;    // F[r][kk] = A[i0+r, p0+kk]
-		F[r][kk] = (kk < bk && i0 + r < n) ? src[(size_t)(p0 + kk) * n + i0 + r] : Scalar(0);
+		const int c = cb + 8 * u;
+		dv[u] = (r < bk && c < bk) ? dv[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short last block
+		D[r][c] = dv[u];
+		D2[r][c] = r == c ? Scalar(1) : Scalar(0);
+		Apj[r][c] = (r < bk && j0 + c < n) ? av[u] : Scalar(0);
+		F[r][c] = (c < bk && i0 + r < n) ? fv[u] : Scalar(0);
 	}
 	__syncthreads();
-	// in-place scalar Gauss-Jordan inverse of the pivot block (every workgroup repeats it: bk^3 flops);
-	// all elements are updated at once from values read before the barrier: two barriers per pivot
-	for (int p = 0; p < bk; p++)
+	TRACE_MARK();
+	Scalar (*Dcur)[GJ_B + 1] = D, (*Dnext)[GJ_B + 1] = D2;
+	const int bkPad = (bk + 1) & ~1;
+	for (int p = 0; p < bkPad; p += 2)
 	{
-		Scalar nv[3];
+		const Scalar a00 = Dcur[p][p], a01 = Dcur[p][p + 1], a10 = Dcur[p + 1][p], a11 = Dcur[p + 1][p + 1];
+		const Scalar mi0 = Dcur[r][p], mi1 = Dcur[r][p + 1];
+		Scalar m0[4], m1[4];
 #pragma unroll
-		for (int u = 0; u < 3; u++)
+		for (int u = 0; u < 4; u++) { m0[u] = Dcur[p][cb + 8 * u]; m1[u] = Dcur[p + 1][cb + 8 * u]; }
+		const Scalar rdet = fast_rcp(a00 * a11 - a01 * a10);
+		const Scalar w00 = a11 * rdet, w01 = -a01 * rdet, w10 = -a10 * rdet, w11 = a00 * rdet;     // W = inverse of the 2x2 pivot block
+		const bool ip = r == p || r == p + 1;
+#pragma unroll
+		for (int u = 0; u < 4; u++)
 		{
-			const int t = tid + 256 * u;
-			const int i = t % GJ_B, j = t / GJ_B;
-			nv[u] = 0;
-			if (t < GJ_B * GJ_B && i < bk && j < bk)
-			{
-				const Scalar d = 1 / D[p][p];
-				const Scalar mip = D[i][p], mpj = D[p][j];
-				nv[u] = (i == p) ? (j == p ? d : mpj * d) : (j == p ? -mip * d : D[i][j] - mip * mpj * d);
-			}
+			const int c = cb + 8 * u;
+			const bool jp = c == p || c == p + 1;
+			const Scalar t0 = w00 * m0[u] + w01 * m1[u], t1 = w10 * m0[u] + w11 * m1[u];   // (W D[P][j])
+			// all four cases are computed and selected (lanes of a wave fall into different ones: branches would
+			// run them one after the other)
+			const Scalar wA = c == p ? w00 : w01, wB = c == p ? w10 : w11;                  // column c - p of W
+			const Scalar vGen = dv[u] - (mi0 * t0 + mi1 * t1);
+			const Scalar vRow = r == p ? t0 : t1;
+			const Scalar vCol = -(mi0 * wA + mi1 * wB);
+			const Scalar vBoth = r == p ? wA : wB;
+			const Scalar v = ip ? (jp ? vBoth : vRow) : (jp ? vCol : vGen);
+			if (r < bkPad && c < bkPad) { dv[u] = v; Dnext[r][c] = v; }
 		}
 		__syncthreads();
-#pragma unroll
-		for (int u = 0; u < 3; u++)
-		{
-			const int t = tid + 256 * u;
-			const int i = t % GJ_B, j = t / GJ_B;
-			if (t < GJ_B * GJ_B && i < bk && j < bk) D[i][j] = nv[u];
-		}
-		__syncthreads();
+		Scalar (*tmp)[GJ_B + 1] = Dcur; Dcur = Dnext; Dnext = tmp;
 	}
-	// R = D * Apj
-	for (int t = tid; t < GJ_B * GJ_T; t += 256)
+	TRACE_MARK();
+	// R = Dinv * Apj (not needed by the tiles of the pivot columns)
+	Scalar acc[4] = { 0, 0, 0, 0 };
+	if (!colTile)
 	{
-		const int k = t % GJ_B, c = t / GJ_B;
-		Scalar s = 0;
-		if (k < bk)
-			for (int m = 0; m < bk; m++) s += D[k][m] * Apj[m][c];
-		R[k][c] = s;
+		for (int m = 0; m < bk; m++)
+		{
+			const Scalar d = Dcur[r][m];
+#pragma unroll
+			for (int u = 0; u < 4; u++) acc[u] += d * Apj[m][cb + 8 * u];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) R[r][cb + 8 * u] = r < bk ? acc[u] : Scalar(0);
 	}
 	__syncthreads();
-	for (int t = tid; t < GJ_T * GJ_T; t += 256)
+	Scalar out[4];
+	if (rowTile && colTile)
 	{
-		const int r = t % GJ_T, c = t / GJ_T;
-		const int gi = i0 + r, gj = j0 + c;
-		if (gi >= n || gj >= n) continue;
-		const bool rp = gi >= p0 && gi < p0 + bk, cp = gj >= p0 && gj < p0 + bk;
-		Scalar v;
-		if (rp && cp) v = D[gi - p0][gj - p0];
-		else if (rp) v = R[gi - p0][c];
-		else if (cp)
-		{
-			Scalar s = 0;
-			for (int k = 0; k < bk; k++) s += F[r][k] * D[k][gj - p0];
-			v = -s;
-		}
-		else
-		{
-			Scalar s = src[(size_t)gj * n + gi];
-			for (int k = 0; k < bk; k++) s -= F[r][k] * R[k][c];
-			v = s;
-		}
-		dst[(size_t)gj * n + gi] = v;
+#pragma unroll
+		for (int u = 0; u < 4; u++) out[u] = dv[u];
 	}
+	else if (rowTile)
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++) out[u] = acc[u];
+	}
+	else
+	{
+		Scalar s2[4] = { 0, 0, 0, 0 };
+		Scalar (*B)[GJ_B + 1] = colTile ? Dcur : R;            // pivot columns: -F Dinv; elsewhere: S - F R
+		for (int k = 0; k < bk; k++)
+		{
+			const Scalar f = F[r][k];
+#pragma unroll
+			for (int u = 0; u < 4; u++) s2[u] += f * B[k][cb + 8 * u];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) out[u] = colTile ? -s2[u] : sv[u] - s2[u];
+	}
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int gi = i0 + r, gj = j0 + cb + 8 * u;
+		if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
+	}
+	TRACE_MARK();
+	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
 }
 
 // Assemble P^T A P from the (already damped) reduced matrix and invert it. Leaves sys.acinv pointing at the result.
@@ -1653,7 +1702,7 @@ void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, Device
 	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
 	hipLaunchKernelGGL(coarse_assemble_kernel, dim3((st.nCb + 3) / 4), dim3(256), 0, s, st, sys, work0);
 	Scalar* src = work0; Scalar* dst = work1;
-	const int tiles = (Nc + GJ_T - 1) / GJ_T;
+	const int tiles = (Nc + GJ_B - 1) / GJ_B;
 	for (int p0 = 0; p0 < Nc; p0 += GJ_B)
 	{
 		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles), dim3(256), 0, s, src, dst, Nc, p0, min(GJ_B, Nc - p0));
@@ -1980,8 +2029,8 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 }  // namespace cubahip
 
 #ifdef CUBA_HIP_TRACE
-extern "C" int cuba_hip_debug_read_trace(unsigned long long* out)   // 2 x 8192 x 8 timestamps (100 MHz)
+extern "C" int cuba_hip_debug_read_trace(unsigned long long* out)   // 3 x 8192 x 8 timestamps (100 MHz)
 {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cubahip::cuba_trace_buf), sizeof(unsigned long long) * 2 * 8192 * 8);
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cubahip::cuba_trace_buf), sizeof(unsigned long long) * 3 * 8192 * 8);
 }
 #endif
