@@ -135,7 +135,8 @@ def main():
         solver.set_state(q0, t0, X0)
         kt = solver.time_kernels(reps=20)
         nblk = c1["hsc_blocks"]
-        nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + max(16, (fp.Pf + 127) // 128) - 1) // max(16, (fp.Pf + 127) // 128)
+        agg = (max(12, (fp.Pf + 159) // 160) + 1) // 2 * 2           # the solver's automatic aggregate size
+        nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + agg - 1) // agg
         alg = algorithmic_bytes(fp, nblk, nc)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
                     "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials,

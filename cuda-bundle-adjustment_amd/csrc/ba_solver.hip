@@ -617,7 +617,7 @@ struct cuba_hip_solver
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
 		// coarse level of the preconditioner: aggregates of consecutive free poses
 		int agg = pcgAggregate;
-		if (agg < 0) agg = std::max(16, (Pf + 127) / 128);
+		if (agg < 0) agg = std::max(12, (Pf + 159) / 160);   // coarse dimension <= 960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
 		if (agg > 0) agg = (agg + SPMV_ROWS - 1) / SPMV_ROWS * SPMV_ROWS;   // aggregates = whole SpMV workgroups (sys.qpart)   // coarse dimension <= 768: the O(Nc^3) inverse stays below ~0.3 ms
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		if (nc < 2) { agg = 0; nc = 0; }

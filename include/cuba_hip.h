@@ -82,7 +82,7 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
 /* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
    (default 4*6*Pf capped at 32768), "pcg_check_every" (default 32), "pcg_aggregate" (poses per coarse
-   aggregate of the two-level preconditioner; -1 = automatic (16), 0 = block-Jacobi only), "coarse_max_age" (default 1: the coarse inverse
+   aggregate of the two-level preconditioner; -1 = automatic: max(12, Pf/160), 0 = block-Jacobi only), "coarse_max_age" (default 1: the coarse inverse
    of the two-level preconditioner is reused for one further solve unless the iteration count degrades; 0 = rebuild
    it for every solve), "pcg_graph" (default 1: replay the PCG iterations as a captured hipGraph), "schur_atomic"
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "profile" (0/1: per-stage
