@@ -1346,37 +1346,56 @@ __device__ __forceinline__ void spmv_entry(const DeviceStructure& st, const Devi
 	for (int c = 0; c < 6; c++) { accz += av[c] * zv[c]; accp += av[c] * pv[c]; }
 }
 
-// N entries of one lane at once: all 18 N loads are issued before the first use. Padding entries (column -1) read
-// block 0 / column 0 and are discarded by a select, which keeps the loads of a wave free of branches.
-template <int N>
-__device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar* pold, const int2 (&e)[3], int rr, Scalar& accz, Scalar& accp)
+typedef Scalar Scalar2 __attribute__((ext_vector_type(2)));
+
+// Row-ordered copy of the reduced matrix for the SpMV: entry (row, m, slot) of the fixed-width adjacency rows holds its
+// 6x6 block as seen from that row (transposed for the lower half), row-major, so that lane (slot, rr) reads the six
+// numbers it needs as three aligned 16-byte loads (half as many load instructions as element-wise strided reads of
+// the upper storage; the per-CU load path, not bandwidth, limits this kernel at KITTI-00 size).
+__global__ __launch_bounds__(256) void hsc_expand_kernel(DeviceStructure st, DeviceSystem sys, size_t total)
 {
-	Scalar av[N][6], zv[N][6], pv[N][6];
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= total) return;
+	const size_t slot = t / 36;
+	const int e = (int)(t - 36 * slot);
+	const int2 en = st.ell[slot];
+	if (en.y < 0) return;
+	const int rr = e / 6, c = e - 6 * rr;
+	sys.hrow[t] = sys.hsc[36 * (size_t)(en.x & 0x7fffffff) + (en.x < 0 ? rr * 6 + c : c * 6 + rr)];
+}
+
+void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s)
+{
+	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
+	if (total) hipLaunchKernelGGL(hsc_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st, sys, total);
+}
+
+// N entries of one lane at once: all 9 N (16-byte) loads are issued before the first use. Padding entries (column -1)
+// read column 0 and are discarded by a select, which keeps the loads of a wave free of branches.
+template <int N>
+__device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar* pold, const int2 (&e)[3], const Scalar* Arow, int rr, Scalar& accz, Scalar& accp)
+{
+	Scalar2 av[N][3], zv[N][3], pv[N][3];
 #pragma unroll
 	for (int n = 0; n < N; n++)
 	{
-		const bool on = e[n].y >= 0;
-		const int bi = on ? e[n].x : 0;
-		const size_t j = on ? e[n].y : 0;
-		const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
-		const int sr = bi < 0 ? 6 : 1, sc = bi < 0 ? 1 : 6;
+		const size_t j = e[n].y >= 0 ? e[n].y : 0;
+		const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + (size_t)n * (20 * 36) + 6 * rr);
+		const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
+		const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
 #pragma unroll
-		for (int c = 0; c < 6; c++)
-		{
-			av[n][c] = B[rr * sr + c * sc];
-			zv[n][c] = sys.z[6 * j + c];
-			pv[n][c] = pold[6 * j + c];
-		}
+		for (int c = 0; c < 3; c++) { av[n][c] = A2[c]; zv[n][c] = z2[c]; pv[n][c] = p2[c]; }
 	}
 #pragma unroll
 	for (int n = 0; n < N; n++)
 	{
 		const bool on = e[n].y >= 0;
 #pragma unroll
-		for (int c = 0; c < 6; c++)
+		for (int c = 0; c < 3; c++)
 		{
-			const Scalar a = on ? av[n][c] : Scalar(0);
-			accz += a * zv[n][c]; accp += a * pv[n][c];
+			const Scalar a0 = on ? av[n][c].x : Scalar(0), a1 = on ? av[n][c].y : Scalar(0);
+			accz += a0 * zv[n][c].x; accp += a0 * pv[n][c].x;
+			accz += a1 * zv[n][c].y; accp += a1 * pv[n][c].y;
 		}
 	}
 }
@@ -1428,9 +1447,10 @@ __global__ __launch_bounds__(128 * SPMV_ROWS) void pcg_spmv_kernel(DeviceGraph g
 		int cnt = 0;                       // wave-uniform: entries of the fullest slot
 #pragma unroll
 		for (int m = 0; m < 3; m++) cnt += __any(e[m].y >= 0) ? 1 : 0;
-		if (cnt == 3) spmv_batch<3>(sys, pold, e, rr, accz, accp);
-		else if (cnt == 2) spmv_batch<2>(sys, pold, e, rr, accz, accp);
-		else if (cnt == 1) spmv_batch<1>(sys, pold, e, rr, accz, accp);
+		const Scalar* Arow = sys.hrow + 36 * ((size_t)row * st.ell_m * 20 + slot);     // entry (row, m, slot) at + m * 20 * 36
+		if (cnt == 3) spmv_batch<3>(sys, pold, e, Arow, rr, accz, accp);
+		else if (cnt == 2) spmv_batch<2>(sys, pold, e, Arow, rr, accz, accp);
+		else if (cnt == 1) spmv_batch<1>(sys, pold, e, Arow, rr, accz, accp);
 		for (int a = a0; a < a1; a += 20) spmv_entry(st, sys, pold, a, rr, accz, accp);   // rows wider than the fixed part
 	}
 	TRACE_MARK();

@@ -100,6 +100,7 @@ struct DeviceSystem
 	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
 	Scalar* rc = nullptr;      // [2*6nc] restricted residual P^T r_k, ping-pong by the parity of k like r / r2 (each
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
+	Scalar* hrow = nullptr;    // [36 * 20 * ell_m * Pf] row-ordered copy of Hsc for the SpMV (launch_hsc_expand), entry (row, m, slot)
 	Scalar* qpart = nullptr;   // [6*npq] sum of q = A p over the SPMV_ROWS block rows of each SpMV workgroup (P^T q is
 	                           // summed from these: aggregates are whole multiples of SPMV_ROWS rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
@@ -143,5 +144,8 @@ void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const
 
 // Adds `chunk` PCG iterations (chunk-local k = 0..chunk-1) and the kbase advance to `graph` as a chain of kernel nodes.
 hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2);
+
+// hsc (damped, after pcg_setup) -> sys.hrow
+void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
 
 }  // namespace cubahip

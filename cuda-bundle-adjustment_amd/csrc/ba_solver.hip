@@ -118,7 +118,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done;
-	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2, d_qpart;
+	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2, d_qpart, d_hrow;
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -675,6 +675,7 @@ struct cuba_hip_solver
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
 		d_qpart.resize((size_t)6 * gridSpmv); sys.qpart = d_qpart.data();
+		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
 		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -782,6 +783,7 @@ struct cuba_hip_solver
 		d_fail.zero(stream);
 		d_kbase.zero(stream);
 		launch_pcg_setup(g, st, sys, lambda, stream);   // also clears the device-side `done` flag
+		launch_hsc_expand(g, st, sys, stream);          // row-ordered copy of the damped matrix for the SpMV
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
@@ -997,6 +999,7 @@ struct cuba_hip_solver
 		d_fail.zero(stream);
 		d_kbase.zero(stream);
 		launch_pcg_setup(g, st, sys, lam, stream);
+		launch_hsc_expand(g, st, sys, stream);
 		if (sys.agg > 0)
 		{
 			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
