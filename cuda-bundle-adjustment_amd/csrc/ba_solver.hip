@@ -620,6 +620,9 @@ struct cuba_hip_solver
 		if (agg < 0) agg = std::max(12, (Pf + 159) / 160);   // coarse dimension <= 960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
 		if (agg > 0) agg = (agg + SPMV_ROWS - 1) / SPMV_ROWS * SPMV_ROWS;   // aggregates = whole SpMV workgroups (sys.qpart)   // coarse dimension <= 768: the O(Nc^3) inverse stays below ~0.3 ms
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
+		// the two-level kernel keeps two coarse vectors in LDS (12 nc + 12 agg + 86 scalars, 64 KB without opting in to more)
+		// and the dense inverse costs O(nc^3): a user-chosen aggregate that small for this many poses is widened
+		while (agg > 0 && (nc > 600 || sizeof(Scalar) * (12 * (size_t)nc + 12 * (size_t)agg + 86) > 60 * 1024)) { agg *= 2; nc = (Pf + agg - 1) / agg; }
 		if (nc < 2) { agg = 0; nc = 0; }
 		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)12 * nc); d_r2.resize((size_t)6 * Pf);
 		lap("structure: uploads + allocs");
