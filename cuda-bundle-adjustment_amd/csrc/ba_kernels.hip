@@ -1715,12 +1715,13 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
 }
 
-// Assemble P^T A P from the (already damped) reduced matrix and invert it. Leaves sys.acinv pointing at the result.
-void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s)
+// Assemble P^T A P from the (already damped) reduced matrix and invert it; returns the buffer (work0 or work1) holding the inverse.
+Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled)
 {
 	const int Nc = 6 * sys.nc;
 	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
 	hipLaunchKernelGGL(coarse_assemble_kernel, dim3((st.nCb + 3) / 4), dim3(256), 0, s, st, sys, work0);
+	if (assembled) (void)hipEventRecord(assembled, s);      // from here on the sweep no longer reads the reduced matrix
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (Nc + GJ_B - 1) / GJ_B;
 	for (int p0 = 0; p0 < Nc; p0 += GJ_B)
@@ -1728,7 +1729,7 @@ void launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, Device
 		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles), dim3(256), 0, s, src, dst, Nc, p0, min(GJ_B, Nc - p0));
 		Scalar* tmp = src; src = dst; dst = tmp;
 	}
-	sys.acinv = src;
+	return src;
 }
 
 // Fused B(k) of the two-level PCG: [x += alpha p; r -= alpha q;]  rc = P^T r;  z = Minv r + P (Ac^-1 rc);

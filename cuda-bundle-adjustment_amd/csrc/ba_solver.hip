@@ -118,7 +118,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done;
-	DevBuf<Scalar> d_coarse0, d_coarse1, d_rc, d_r2, d_qpart, d_hrow;
+	DevBuf<Scalar> d_coarse[3], d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -132,7 +132,7 @@ struct cuba_hip_solver
 	// one captured hipGraph = `pcgGraphChunk` PCG iterations (kernel arguments are chunk-local, the device-side
 	// kbase counter supplies the offset): replaying it costs one host call instead of 2-3 launches per iteration
 	// (graphs are kept per chunk length: 4, 8, 16, 32 and whatever pcg_check_every asks for)
-	std::map<int, hipGraphExec_t> pcgGraphs;
+	std::map<std::pair<int, const Scalar*>, hipGraphExec_t> pcgGraphs;   // key: chunk length, coarse inverse the kernels read
 	bool useGraph = true;
 	hipStream_t captureStream = nullptr;   // private stream used only to record graphs (the work stream may be the
 	                                       // legacy default stream, which cannot be captured)
@@ -160,8 +160,9 @@ struct cuba_hip_solver
 
 	hipGraphExec_t pcgGraph(int chunk, int maxIter, Scalar tol2)
 	{
-		if (pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter || pcgGraphAcinv != sys.acinv) dropPcgGraph();   // baked-in arguments
-		auto it = pcgGraphs.find(chunk);
+		if (pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter) dropPcgGraph();   // baked-in arguments
+		const auto key = std::make_pair(chunk, (const Scalar*)sys.acinv);
+		auto it = pcgGraphs.find(key);
 		if (it != pcgGraphs.end()) return it->second;
 		hipGraph_t graph = nullptr;
 		hipGraphExec_t exec = nullptr;
@@ -174,13 +175,38 @@ struct cuba_hip_solver
 		}
 		HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
 		(void)hipGraphDestroy(graph);
-		pcgGraphs[chunk] = exec;
-		pcgGraphTol2 = tol2; pcgGraphMaxIter = maxIter; pcgGraphAcinv = sys.acinv;
+		pcgGraphs[key] = exec;
+		pcgGraphTol2 = tol2; pcgGraphMaxIter = maxIter;
 		return exec;
 	}
-	Scalar pcgGraphTol2 = 0; int pcgGraphMaxIter = 0; const Scalar* pcgGraphAcinv = nullptr;
+	Scalar pcgGraphTol2 = 0; int pcgGraphMaxIter = 0;
 
 	bool coarseValid = false, coarseFresh = false;
+	// overlapped refresh: while the PCG of trial k runs (with the inverse built from trial k-1's matrix), a second stream
+	// assembles and inverts trial k's coarse matrix for trial k+1
+	bool coarseOverlap = false;   // measured: the concurrent sweep slows the latency-bound PCG kernels by ~15 %, which costs more than
+	                              // the hidden inversions save (scripts/overlap_ab.py: 12.2 vs 11.9 ms KITTI-00, 43.9 vs 42.8 ms S2M) -> off
+	hipStream_t gjStream = nullptr;
+	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr;
+	int liveInv = 0, pendingInv = -1;   // buffer with the inverse in use / buffer the running inversion will leave its result in
+	bool assemblePending = false;       // the other stream may still be reading hsc
+	void ensureOverlapObjects()
+	{
+		if (gjStream) return;
+		int prioLow = 0, prioHigh = 0;
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
+		HIP_TRY(hipStreamCreateWithPriority(&gjStream, hipStreamNonBlocking, prioLow));   // fills the gaps of the latency-bound PCG kernels, must not delay them
+		HIP_TRY(hipEventCreateWithFlags(&evSetup, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&evAssembled, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&evInverse, hipEventDisableTiming));
+	}
+	// the work stream must not touch what a running inversion still uses
+	void waitAssembled() { if (assemblePending) { HIP_TRY(hipStreamWaitEvent(stream, evAssembled, 0)); assemblePending = false; } }
+	void drainInversion()
+	{
+		if (pendingInv >= 0) { HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0)); pendingInv = -1; }
+		assemblePending = false;
+	}
 	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
 	double coarseGrowth = 1.25;  // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
 	struct PatternEntry { uint64_t key; int ea, eb; };   // (column << 32 | product id + 1), the product's two sorted-edge ids
@@ -200,6 +226,7 @@ struct cuba_hip_solver
 	~cuba_hip_solver()
 	{
 		dropPcgGraph();
+		if (gjStream) { (void)hipStreamSynchronize(gjStream); (void)hipStreamDestroy(gjStream); (void)hipEventDestroy(evSetup); (void)hipEventDestroy(evAssembled); (void)hipEventDestroy(evInverse); }
 		if (captureStream) (void)hipStreamDestroy(captureStream);
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
@@ -405,6 +432,7 @@ struct cuba_hip_solver
 	{
 		if (!haveGraph) throw StateError{ "set_graph must be called first" };
 		if (haveStructure) return;
+		if (gjStream) { HIP_TRY(hipStreamSynchronize(gjStream)); pendingInv = -1; assemblePending = false; }   // an overlapped coarse inversion uses the old structure
 		const auto t0 = Clock::now();
 		std::vector<int> nfree(Lf, 0);
 		std::vector<long long> pairBase(Lf, 0);
@@ -624,7 +652,8 @@ struct cuba_hip_solver
 		// and the dense inverse costs O(nc^3): a user-chosen aggregate that small for this many poses is widened
 		while (agg > 0 && (nc > 600 || sizeof(Scalar) * (12 * (size_t)nc + 12 * (size_t)agg + 86) > 60 * 1024)) { agg *= 2; nc = (Pf + agg - 1) / agg; }
 		if (nc < 2) { agg = 0; nc = 0; }
-		d_coarse0.resize((size_t)36 * nc * nc); d_coarse1.resize((size_t)36 * nc * nc); d_rc.resize((size_t)12 * nc); d_r2.resize((size_t)6 * Pf);
+		for (auto& b : d_coarse) b.resize((size_t)36 * nc * nc);
+		d_rc.resize((size_t)12 * nc); d_r2.resize((size_t)6 * Pf);
 		lap("structure: uploads + allocs");
 		// coarse-matrix assembly lists: fine blocks grouped by the coarse block (I,J) they fall into (both triangles)
 		std::vector<int> cbI, cbJ, cbPtr(1, 0), cbBlk;
@@ -679,7 +708,7 @@ struct cuba_hip_solver
 		coarseValid = false;
 		d_qpart.resize((size_t)6 * gridSpmv); sys.qpart = d_qpart.data();
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
-		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse0.data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
+		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
 		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;   // pattern of Hsc doubles as the "symbolic" phase of the reduced solver
@@ -705,8 +734,11 @@ struct cuba_hip_solver
 		return readSlots(0);
 	}
 
+	void zeroReduced() { waitAssembled(); d_red.zero(stream); }
+
 	void linearize(int mode, double lam)
 	{
+		waitAssembled();            // an overlapped coarse assembly may still be reading the previous reduced matrix
 		if (schurAtomic) launch_linearize(g, st, sys, mode, lam, stream);
 		else launch_linearize_dm(g, st, sys, mode, lam, stream);
 	}
@@ -716,7 +748,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 3);
-		d_red.zero(stream);
+		zeroReduced();
 		d_maxdiag.zero(stream);
 		linearize(0, 0.0);
 	}
@@ -757,7 +789,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 3);
-		d_red.zero(stream);
+		zeroReduced();
 		d_maxdiag.zero(stream);
 		linearize(0, 0.0);
 		launch_pose_maxdiag(g, st, sys, stream);
@@ -772,7 +804,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 4);
-		d_red.zero(stream);
+		zeroReduced();
 		linearize(1, lambda);
 	}
 
@@ -790,14 +822,44 @@ struct cuba_hip_solver
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
-			const bool refresh = !coarseValid || coarseAge >= coarseMaxAge || lastSolveIters > coarseGrowth * itersAtRefresh + 8;
-			if (refresh)
+			if (coarseOverlap)
 			{
-				launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
-				coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
+				ensureOverlapObjects();
+				if (!coarseValid)
+				{
+					// first solve of a run: nothing to overlap with, invert here
+					drainInversion();
+					Scalar* res = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
+					liveInv = res == d_coarse[0].data() ? 0 : 1;
+					coarseValid = true; cntCoarseRefresh++;
+				}
+				else if (pendingInv >= 0)
+				{
+					HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done: it ran under the previous PCG
+					liveInv = pendingInv; pendingInv = -1;
+				}
+				sys.acinv = d_coarse[liveInv].data();
+				// this trial's matrix -> the inverse the next trial will use, on the other stream, into the two idle buffers
+				const int a = (liveInv + 1) % 3, b = (liveInv + 2) % 3;
+				HIP_TRY(hipEventRecord(evSetup, stream));
+				HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
+				Scalar* res = launch_coarse_setup(g, st, sys, d_coarse[a].data(), d_coarse[b].data(), gjStream, evAssembled);
+				HIP_TRY(hipEventRecord(evInverse, gjStream));
+				pendingInv = res == d_coarse[a].data() ? a : b;
+				assemblePending = true; cntCoarseRefresh++;
+				coarseFresh = false;
 			}
-			else coarseAge++;
-			coarseFresh = refresh;
+			else
+			{
+				const bool refresh = !coarseValid || coarseAge >= coarseMaxAge || lastSolveIters > coarseGrowth * itersAtRefresh + 8;
+				if (refresh)
+				{
+					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
+					coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
+				}
+				else coarseAge++;
+				coarseFresh = refresh;
+			}
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
 		// Iterations are enqueued in chunks (captured graphs of 4/8/16/32 iterations; chunk lengths are multiples of 4
@@ -994,10 +1056,10 @@ struct cuba_hip_solver
 		};
 		const double lam = lambda > 0 ? lambda : 1.0;
 		msOut[0] = timeit([&] { launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream); });
-		d_red.zero(stream);
+		zeroReduced();
 		msOut[1] = timeit([&] { linearize(1, lam); });
 		// a consistent reduced system for the PCG kernels
-		d_red.zero(stream);
+		zeroReduced();
 		linearize(1, lam);
 		d_fail.zero(stream);
 		d_kbase.zero(stream);
@@ -1005,7 +1067,9 @@ struct cuba_hip_solver
 		launch_hsc_expand(g, st, sys, stream);
 		if (sys.agg > 0)
 		{
-			launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream);
+			drainInversion();
+			sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
+			coarseValid = false;
 			launch_pcg2_fused(g, sys, 0, 0, 1 << 30, -1.0, 0, stream);
 		}
 		msOut[2] = timeit([&] { launch_pcg_spmv(g, st, sys, 0, 1 << 30, -1.0, stream); });
@@ -1013,7 +1077,7 @@ struct cuba_hip_solver
 		{
 			msOut[3] = timeit([&] { launch_pcg2_fused(g, sys, 0, 1, 1 << 30, -1.0, 1, stream); });
 			msOut[5] = 0;   // merged into [3] (update + restrict + two-level preconditioner in one kernel)
-			msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse0.data(), d_coarse1.data(), stream); });
+			msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream); });
 		}
 		else
 		{
@@ -1117,6 +1181,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		if (k == "pcg_tol") s->pcgTol = value;
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
+		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "schur_atomic") { s->schurAtomic = value != 0; s->haveStructure = false; }   // the product -> block map is built on demand

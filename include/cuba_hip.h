@@ -81,10 +81,13 @@ int cuba_hip_scalar_size(void);
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
 /* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
-   (default 4*6*Pf capped at 32768), "pcg_check_every" (default 32), "pcg_aggregate" (poses per coarse
-   aggregate of the two-level preconditioner; -1 = automatic: max(12, Pf/160), 0 = block-Jacobi only), "coarse_max_age" (default 1: the coarse inverse
-   of the two-level preconditioner is reused for one further solve unless the iteration count degrades; 0 = rebuild
-   it for every solve), "pcg_graph" (default 1: replay the PCG iterations as a captured hipGraph), "schur_atomic"
+   (default 4*6*Pf capped at 32768), "pcg_check_every" (PCG iterations between host looks at the device stop flag; default 0 =
+   batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
+   preconditioner; -1 = automatic: max(12, Pf/160), 0 = block-Jacobi only), "coarse_max_age" (default 2: the coarse
+   inverse of the two-level preconditioner is reused for up to two further solves of a run; 0 = rebuild it for every
+   solve), "coarse_refresh_growth" (default 1.25: rebuild early once a solve needs that many times the iterations of
+   the solve the inverse was built for), "coarse_overlap" (default 0; 1 = invert every trial's coarse matrix on a second
+   stream under the PCG of that trial, for use by the next one -- measured slower, kept for A/B runs), "pcg_graph" (default 1: replay the PCG iterations as a captured hipGraph), "schur_atomic"
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "profile" (0/1: per-stage
    synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */
 int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value);

@@ -228,6 +228,20 @@ def test_preconditioner_modes_agree(solvers, small_fp):
     assert its[16] < its[0] and its[5] < its[0] and its[2] < its[5], its       # the coarse level must pay off on a keyframe chain
 
 
+def test_overlapped_coarse_inversion_option(solvers):
+    """coarse_overlap=1 (inverse of trial k built on a second stream for trial k+1) solves the same problems."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
+    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
+    h = HipSolver(fp, RK_HUBER, coarse_overlap=1)
+    a = h.optimize(6)["chi2"]
+    q0, t0, X0 = h.state()
+    assert rel(a, ref) < CHI2_TOL
+    h2 = HipSolver(fp, RK_HUBER, coarse_overlap=1)
+    assert np.array_equal(h2.optimize(6)["chi2"], a)          # still deterministic
+    assert h.counters()["coarse_refreshes"] >= 6
+
+
 def test_golden_trajectories_on_gpu(solvers):
     HipSolver, _ = solvers
     with open(os.path.join(os.path.dirname(__file__), "golden", "lm_trajectories.json")) as f:
