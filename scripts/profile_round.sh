@@ -15,5 +15,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $root
 python scripts/pmc_traffic.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE > $out/${tag}_kitti00_pmc_traffic.json
+cp $out/${tag}_kitti00_pmc_traffic.json profiles/        # the bench line cites the traffic measured in this very run
 python bench.py --steps 50 --warmup 10 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 tail -c 600 $out/${tag}_bench.json
