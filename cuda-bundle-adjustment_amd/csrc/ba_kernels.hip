@@ -1999,11 +1999,27 @@ void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const De
 	hipLaunchKernelGGL(pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
 }
 
-__global__ void pcg_advance_kernel(int* kbase, int n) { *kbase += n; }
+// last node of an iteration graph: advance the iteration offset and report the solver's flags straight into the
+// device-mapped host block the host looks at after synchronising (no copy kernels on the way)
+__global__ void pcg_advance_kernel(DeviceSystem sys, int n)
+{
+	*sys.kbase += n;
+	if (sys.host_flags)
+	{
+		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
+		__threadfence_system();
+		sys.host_flags[3] = ++(*sys.ticket);      // the host spins on this word instead of paying a stream-synchronise round trip
+	}
+}
+
+void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, 0);
+}
 
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys.kbase, n);
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, n);
 }
 
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -2043,7 +2059,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		}
 		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
 	}
-	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(1), 0, sys.kbase, chunk);
+	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(1), 0, sys, chunk);
 	return e;
 }
 

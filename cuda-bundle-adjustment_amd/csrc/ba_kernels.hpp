@@ -92,6 +92,9 @@ struct DeviceSystem
 	int nrz0 = 0, nrz = 0, npq = 0;        // number of partials in slot 0 / in the ring slots of rz (nrz0 <= nrz) / in pq slots
 	int* done = nullptr;                   // set once the stop test fails: later queued launches return at once
 	int* iters = nullptr;      // device iteration counter
+	int* host_flags = nullptr; // device-mapped host ints: {fail, iterations done, stop flag, ticket}, refreshed by the last node of every
+	                           // iteration graph and by launch_pcg_report
+	int* ticket = nullptr;     // device counter of those reports
 	int* kbase = nullptr;      // iteration offset added to the k / kOut kernel arguments (lets one captured hipGraph
 	                           // of `chunk` iterations be replayed: the graph's last node advances it by `chunk`)
 	// two-level preconditioner: aggregates of `agg` consecutive free poses, 6 coarse dof each
@@ -147,5 +150,8 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 
 // hsc (damped, after pcg_setup) -> sys.hrow
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
+
+// copies {fail, iters, done} into sys.host_flags (what the last node of an iteration graph does anyway)
+void launch_pcg_report(const DeviceSystem& sys, hipStream_t s);
 
 }  // namespace cubahip

@@ -17,6 +17,7 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -115,15 +116,21 @@ struct cuba_hip_solver
 	DevBuf<long long> d_bigOfs, d_lmPairBase;
 	DevBuf<Scalar> d_bigHpl;
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
-	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_slots, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
+	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
-	DevBuf<int> d_fail, d_iters, d_kbase, d_done;
+	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_coarse[3], d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
 	std::vector<int> h_rowptr, h_colind;
-	Scalar* h_pinned = nullptr;   // 4*NSLOT doubles + small ints
+	// Pinned, device-mapped host block: [0, 1024) the 4*NSLOT result slots the reduction kernels write DIRECTLY (the host
+	// reads them after a stream synchronisation: no copy kernel, no copy latency), [1024, 2048) PCG flags written by the
+	// last node of every iteration graph, [2048, 4096) staging for the few remaining explicit read-backs.
+	Scalar* h_pinned = nullptr;
+	Scalar* slotsDev = nullptr;   // device-side address of h_pinned
+	int* flagsDev = nullptr;
+	Scalar* hostStage() const { return (Scalar*)((char*)h_pinned + 2048); }
 
 	DeviceGraph g;
 	DeviceStructure st;
@@ -233,6 +240,27 @@ struct cuba_hip_solver
 	}
 
 	void sync() { HIP_TRY(hipStreamSynchronize(stream)); }
+
+	// Completion of the work enqueued so far, learnt from the ticket the last reporting kernel writes into the mapped host
+	// block: a spin on host memory sees it ~1 us after the kernel, hipStreamSynchronize only after ~20 us.
+	int expectedTicket = 0;
+	bool spinWait = true;
+	bool speculateTail = false;  // optimize(): enqueue back-substitution/update/evaluation behind the first PCG batch. Measured with
+	                             // spin_wait on: 12.01 vs 11.95 ms (the saved host look is cheap now, a misprediction is not) -> off
+	void noteReport() { expectedTicket++; }
+	void waitReport()
+	{
+		volatile int* flags = (volatile int*)((char*)h_pinned + 1024);
+		if (spinWait)
+		{
+			const auto t0 = Clock::now();
+			for (long spins = 0; flags[3] != expectedTicket; spins++)
+				if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(Clock::now() - t0).count() > 2.0) break;   // hung or failed launch: let the runtime say so
+			if (flags[3] == expectedTicket) return;
+		}
+		sync();
+		expectedTicket = flags[3];
+	}
 
 	// host double <-> device Scalar transfers (plain copies in the fp64 build, staged conversion in the fp32 build)
 	void downloadAsDouble(const Scalar* dsrc, double* hdst, size_t n)
@@ -390,9 +418,17 @@ struct cuba_hip_solver
 		d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream);
 		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
 		d_perEdge.resize(E);
-		d_slots.resize(4 * NSLOT); d_parts.resize(4096 + (size_t)E / 2 + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1);
-		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream);
-		if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, 2048));   // viewed as Scalar[], double[] or int[] by the readers below
+		if (!h_pinned)
+		{
+			HIP_TRY(hipHostMalloc((void**)&h_pinned, 4096, hipHostMallocMapped));
+			std::memset(h_pinned, 0, 4096);
+			void* dev = nullptr;
+			HIP_TRY(hipHostGetDevicePointer(&dev, h_pinned, 0));
+			slotsDev = (Scalar*)dev; flagsDev = (int*)((char*)dev + 1024);
+		}
+		d_parts.resize(4096 + (size_t)E / 2 + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1); d_ticket.resize(1);
+		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream); d_ticket.zero(stream);
+		sync(); expectedTicket = 0; ((volatile int*)((char*)h_pinned + 1024))[3] = 0;
 		sync();   // host staging vectors go out of scope
 
 		lap("set_graph: alloc + upload + sync");
@@ -698,10 +734,10 @@ struct cuba_hip_solver
 		st.nCb = (int)cbI.size(); st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
-		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = d_slots.data(); sys.parts = d_parts.data();
+		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = slotsDev; sys.host_flags = flagsDev; sys.parts = d_parts.data();
 		sys.maxdiag = d_maxdiag.data(); sys.fail = d_fail.data();
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
-		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data();
+		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data(); sys.ticket = d_ticket.data();
 		dropPcgGraph();
 		sys.rzStride = rzStride; sys.pqStride = pqStride; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
@@ -718,10 +754,9 @@ struct cuba_hip_solver
 
 	double readSlots(int which)
 	{
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data() + which * NSLOT, sizeof(Scalar) * NSLOT, hipMemcpyDeviceToHost, stream));
 		sync();
 		double s = 0;
-		for (int i = 0; i < NSLOT; i++) s += h_pinned[i];
+		for (int i = 0; i < NSLOT; i++) s += h_pinned[which * NSLOT + i];
 		return s;
 	}
 
@@ -729,8 +764,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 2);
-		HIP_TRY(hipMemsetAsync(d_slots.data(), 0, sizeof(Scalar) * NSLOT, stream));
-		launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream);
+		launch_residual_chi2(g, d_parts.data(), slotsDev, nullptr, stream);   // its second stage writes all NSLOT entries of the slot group
 		return readSlots(0);
 	}
 
@@ -757,15 +791,15 @@ struct cuba_hip_solver
 	void maxDiagonalParts(double* posePart, double* lmPart)
 	{
 		need();
-		const double* hD = (const double*)h_pinned;      // maxdiag slots hold bit patterns of non-negative doubles
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
+		const double* hD = (const double*)hostStage();      // maxdiag slots hold bit patterns of non-negative doubles
+		HIP_TRY(hipMemcpyAsync(hostStage(), d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
 		double v = 0;
 		for (int i = 0; i < 64; i++) v = std::max(v, hD[i]);
 		*lmPart = v;
 		d_maxdiag.zero(stream);
 		launch_pose_maxdiag(g, st, sys, stream);
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(hostStage(), d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
 		v = 0;
 		for (int i = 0; i < 64; i++) v = std::max(v, hD[i]);
@@ -775,13 +809,11 @@ struct cuba_hip_solver
 	void scaleParts(double lam, double* posePart, double* lmPart)
 	{
 		need();
-		HIP_TRY(hipMemsetAsync(d_slots.data() + 2 * NSLOT, 0, sizeof(Scalar) * 2 * NSLOT, stream));
-		launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
-		launch_landmark_scale(g, sys, lam, d_slots.data() + 2 * NSLOT, stream);
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data() + 2 * NSLOT, sizeof(Scalar) * 2 * NSLOT, hipMemcpyDeviceToHost, stream));
+		launch_pose_scale(g, sys, lam, slotsDev + 3 * NSLOT, stream);
+		launch_landmark_scale(g, sys, lam, slotsDev + 2 * NSLOT, stream);
 		sync();
 		double a = 0, b = 0;
-		for (int i = 0; i < NSLOT; i++) { b += h_pinned[i]; a += h_pinned[NSLOT + i]; }
+		for (int i = 0; i < NSLOT; i++) { b += h_pinned[2 * NSLOT + i]; a += h_pinned[3 * NSLOT + i]; }
 		*posePart = a; *lmPart = b;
 	}
 
@@ -793,10 +825,10 @@ struct cuba_hip_solver
 		d_maxdiag.zero(stream);
 		linearize(0, 0.0);
 		launch_pose_maxdiag(g, st, sys, stream);
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(hostStage(), d_maxdiag.data(), 8 * 64, hipMemcpyDeviceToHost, stream));
 		sync();
 		double v = 0;   // bit patterns of non-negative doubles are doubles again
-		for (int i = 0; i < 64; i++) v = std::max(v, ((const double*)h_pinned)[i]);
+		for (int i = 0; i < 64; i++) v = std::max(v, ((const double*)hostStage())[i]);
 		return v;
 	}
 
@@ -808,8 +840,13 @@ struct cuba_hip_solver
 		linearize(1, lambda);
 	}
 
-	bool solveReduced()
+	// `tail` (optional): work that only makes sense once the solve has converged (back-substitution, update, evaluation of
+	// the trial) but is enqueued right behind the FIRST batch of iterations, speculating that the predicted batch size was
+	// enough -- it is for ~9 solves in 10, and then the whole trial costs one host look instead of two.  If the batch was
+	// too short, `undo` restores what the tail changed, the iterations continue, and *tailValid stays false.
+	bool solveReduced(const std::function<void()>* tail = nullptr, const std::function<void()>* undo = nullptr, bool* tailValid = nullptr)
 	{
+		if (tailValid) *tailValid = false;
 		need();
 		StageTimer tm(this, 6);
 		if (Pf == 0) return true;
@@ -862,12 +899,12 @@ struct cuba_hip_solver
 			}
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
-		// Iterations are enqueued in chunks (captured graphs of 4/8/16/32 iterations; chunk lengths are multiples of 4
+		// Iterations are enqueued in chunks (graphs of 4/8/.../256 iterations; chunk lengths are multiples of 4
 		// because the kernels address their reduction slots by the chunk-local k & 3) and the host looks at the device
 		// stop flag after each batch.  A launch after convergence still costs ~2.5 us per kernel and a look costs a
 		// host round trip, so the first batch is sized from the previous solve of this run.
 		const int fixedChunk = pcgCheckEvery > 0 ? (pcgCheckEvery + 3) / 4 * 4 : 0;
-		int* hInts = (int*)((char*)h_pinned + 1024);
+		volatile int* hInts = (volatile int*)((char*)h_pinned + 1024);   // fail, iterations done, stop flag: written by the device
 		bool converged = false;
 		int k0 = 0, looks = 0;
 		// prediction: within an LM run the damping shrinks geometrically and the iteration count grows by a fairly steady
@@ -886,26 +923,33 @@ struct cuba_hip_solver
 			int todo = std::max(4, std::min(target, maxIter) - k0);
 			while (todo > 0)
 			{
-				const int c = fixedChunk ? fixedChunk : (todo >= 32 ? 32 : todo >= 16 ? 16 : todo >= 8 ? 8 : 4);
-				if (useGraph) HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2), stream));
+				int c = fixedChunk;
+				if (!c) for (c = 256; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
+				if (useGraph) { HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2), stream)); noteReport(); }
 				else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				k0 += c; todo -= c;
 			}
-			HIP_TRY(hipMemcpyAsync(hInts, d_fail.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipMemcpyAsync(hInts + 1, d_iters.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipMemcpyAsync(hInts + 2, d_done.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
-			sync();
+			const bool speculate = tail && looks == 0;
+			if (speculate) (*tail)();                                             // ends with its own report
+			else if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (the graphs end with this report)
+			waitReport();
 			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; lastSolveIters = 0; return false; }
 			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
+			if (speculate)
+			{
+				if (converged || k0 >= maxIter) *tailValid = true;
+				else (*undo)();
+			}
 			target = k0 + (fixedChunk ? fixedChunk : std::max(8, k0 / 8 / 4 * 4));
 			looks++; cntPcgLooks++;
 		}
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued, %d host looks (prediction %d)\n", hInts[1], k0, looks, predicted);
-		cntPcgIters += hInts[1]; cntPcgEnqueued += k0;
-		if (runIters.empty()) firstSolveIters = hInts[1];
-		runIters.push_back(hInts[1]);
-		lastSolveIters = hInts[1];
-		if (coarseFresh) itersAtRefresh = hInts[1];
+		const int itersDone = hInts[1];
+		cntPcgIters += itersDone; cntPcgEnqueued += k0;
+		if (runIters.empty()) firstSolveIters = itersDone;
+		runIters.push_back(itersDone);
+		lastSolveIters = itersDone;
+		if (coarseFresh) itersAtRefresh = itersDone;
 		return true;   // hitting max_iter returns the best iterate, like an inexact LM step
 	}
 
@@ -913,7 +957,6 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 4);
-		HIP_TRY(hipMemsetAsync(d_slots.data() + NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
 		launch_back_substitute(g, st, sys, lambda, stream);
 	}
 
@@ -967,10 +1010,16 @@ struct cuba_hip_solver
 				cntTrials++;
 				push();
 				lambda = lam;
-				const bool ok = solve();
-				if (ok) update();
+				schur();
+				// back-substitution, update and evaluation of the trial ride behind the first batch of PCG iterations
+				const std::function<void()> tail = [&] { backSubstitute(); update(); enqueueEvaluate(lam, true); };
+				const std::function<void()> undo = [&] { pop(); };
+				bool tailValid = false;
+				const bool ok = speculateTail ? solveReduced(&tail, &undo, &tailValid) : solveReduced();
+				if (ok && !tailValid) { backSubstitute(); update(); }
 				double Fhat = 0, scale = 0;
-				evaluateTrial(lam, ok, &Fhat, &scale);      // chi2 at the trial estimate + gain-ratio denominator, one host sync
+				if (ok && tailValid) readEvaluate(true, &Fhat, &scale);     // already there: it came with the solver's flags
+				else evaluateTrial(lam, ok, &Fhat, &scale);                 // chi2 at the trial estimate + gain-ratio denominator, one host look
 				scale += 1e-3;
 				rho = ok ? (F - Fhat) / scale : -1;
 				if (rho > 0)
@@ -999,27 +1048,33 @@ struct cuba_hip_solver
 	}
 
 	// chi2 of the trial estimate and sum x (lambda x + b) of the step that led to it, read back with ONE synchronisation
+	void enqueueEvaluate(double lam, bool withScale)
+	{
+		launch_residual_chi2(g, d_parts.data(), slotsDev, nullptr, stream);
+		if (withScale) launch_pose_scale(g, sys, lam, slotsDev + 3 * NSLOT, stream);
+		launch_pcg_report(sys, stream); noteReport();       // ticket behind the results (which the kernels wrote into the mapped host block)
+	}
+	void readEvaluate(bool withScale, double* Fhat, double* scale)
+	{
+		waitReport();
+		*Fhat = (double)h_pinned[0];
+		*scale = withScale ? (double)h_pinned[NSLOT] + (double)h_pinned[3 * NSLOT] : 0.0;   // landmark part (back_substitute) + pose part
+	}
 	void evaluateTrial(double lam, bool withScale, double* Fhat, double* scale)
 	{
 		StageTimer tm(this, 2);
-		launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream);
-		if (withScale) launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data(), sizeof(Scalar) * 4 * NSLOT, hipMemcpyDeviceToHost, stream));
-		sync();
-		*Fhat = (double)h_pinned[0];
-		*scale = withScale ? (double)h_pinned[NSLOT] + (double)h_pinned[3 * NSLOT] : 0.0;   // landmark part (back_substitute) + pose part
+		enqueueEvaluate(lam, withScale);
+		readEvaluate(withScale, Fhat, scale);
 	}
 
 	// Fused version used by optimize(): the landmark part was accumulated by back_substitute (same lambda),
 	// only the 6*Pf pose part is added here.
 	double scaleOfLastSolve(double lam)
 	{
-		HIP_TRY(hipMemsetAsync(d_slots.data() + 3 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
-		launch_pose_scale(g, sys, lam, d_slots.data() + 3 * NSLOT, stream);
-		HIP_TRY(hipMemcpyAsync(h_pinned, d_slots.data() + NSLOT, sizeof(Scalar) * 3 * NSLOT, hipMemcpyDeviceToHost, stream));
+		launch_pose_scale(g, sys, lam, slotsDev + 3 * NSLOT, stream);
 		sync();
 		double v = 0;
-		for (int i = 0; i < NSLOT; i++) v += h_pinned[i] + h_pinned[2 * NSLOT + i];
+		for (int i = 0; i < NSLOT; i++) v += h_pinned[NSLOT + i] + h_pinned[3 * NSLOT + i];
 		return v;
 	}
 
@@ -1055,7 +1110,7 @@ struct cuba_hip_solver
 			return (double)ms / reps;
 		};
 		const double lam = lambda > 0 ? lambda : 1.0;
-		msOut[0] = timeit([&] { launch_residual_chi2(g, d_parts.data(), d_slots.data(), nullptr, stream); });
+		msOut[0] = timeit([&] { launch_residual_chi2(g, d_parts.data(), slotsDev, nullptr, stream); });
 		zeroReduced();
 		msOut[1] = timeit([&] { linearize(1, lam); });
 		// a consistent reduced system for the PCG kernels
@@ -1092,8 +1147,7 @@ struct cuba_hip_solver
 	void chiSquares(double* out)
 	{
 		need();
-		HIP_TRY(hipMemsetAsync(d_slots.data() + 2 * NSLOT, 0, sizeof(Scalar) * NSLOT, stream));
-		launch_residual_chi2(g, d_parts.data(), d_slots.data() + 2 * NSLOT, d_perEdge.data(), stream);
+		launch_residual_chi2(g, d_parts.data(), slotsDev + 2 * NSLOT, d_perEdge.data(), stream);
 		std::vector<double> sorted(E);
 		downloadAsDouble(d_perEdge.data(), sorted.data(), (size_t)E);
 		sync();
@@ -1181,6 +1235,8 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		if (k == "pcg_tol") s->pcgTol = value;
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
+		else if (k == "spin_wait") s->spinWait = value != 0;
+		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }

@@ -86,7 +86,10 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    preconditioner; -1 = automatic: max(12, Pf/160), 0 = block-Jacobi only), "coarse_max_age" (default 2: the coarse
    inverse of the two-level preconditioner is reused for up to two further solves of a run; 0 = rebuild it for every
    solve), "coarse_refresh_growth" (default 1.25: rebuild early once a solve needs that many times the iterations of
-   the solve the inverse was built for), "coarse_overlap" (default 0; 1 = invert every trial's coarse matrix on a second
+   the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
+   the device writes into mapped host memory, not from hipStreamSynchronize), "speculate_tail" (default 0; 1 = optimize()
+   enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
+   was too short -- measured slightly slower), "coarse_overlap" (default 0; 1 = invert every trial's coarse matrix on a second
    stream under the PCG of that trial, for use by the next one -- measured slower, kept for A/B runs), "pcg_graph" (default 1: replay the PCG iterations as a captured hipGraph), "schur_atomic"
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "profile" (0/1: per-stage
    synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */
