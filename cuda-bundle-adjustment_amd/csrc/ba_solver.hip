@@ -218,6 +218,7 @@ struct cuba_hip_solver
 	double coarseGrowth = 1.25;  // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
 	struct PatternEntry { uint64_t key; int ea, eb; };   // (column << 32 | product id + 1), the product's two sorted-edge ids
 	std::vector<PatternEntry> h_ent; std::vector<int> h_work[6];   // work arrays of build_structure
+	std::vector<double> h_chiSorted;         // per-edge chi2 in sorted order (staging of chi_squares)
 	std::vector<Scalar> h_stage[6];          // host staging of set_graph (sorted measurements, state, cameras)
 	std::vector<int> h_spose[2], h_slm[2];   // sorted edge->pose (with the stereo bit) / edge->landmark of this and the previous set_graph
 	int topoSlot = 0;
@@ -1148,10 +1149,10 @@ struct cuba_hip_solver
 	{
 		need();
 		launch_residual_chi2(g, d_parts.data(), slotsDev + 2 * NSLOT, d_perEdge.data(), stream);
-		std::vector<double> sorted(E);
+		std::vector<double>& sorted = h_chiSorted; sorted.resize(E);
 		downloadAsDouble(d_perEdge.data(), sorted.data(), (size_t)E);
 		sync();
-		for (int i = 0; i < E; i++) out[perm[i]] = sorted[i];
+		parallelFor(E, [&](int i) { out[perm[i]] = sorted[i]; });     // back to the caller's edge order
 	}
 };
 

@@ -248,8 +248,14 @@ public:
 			for (int k = 0; k < 4; k++) qc[k] = q_[4 * i + k];
 			for (int k = 0; k < 3; k++) activePoses_[i]->t.data()[k] = t_[3 * i + k];
 		}
-		for (size_t i = 0; i < activeLandmarks_.size(); i++)
-			for (int k = 0; k < 3; k++) activeLandmarks_[i]->Xw.data()[k] = Xw_[3 * i + k];
+		{
+			const size_t nL = activeLandmarks_.size();
+			const unsigned T = hostThreads(nL);
+			forThreads(T, [&](unsigned t) {       // one scattered store per landmark object: split over the pool
+				for (size_t i = nL * t / T; i < nL * (t + 1) / T; i++)
+					for (int k = 0; k < 3; k++) activeLandmarks_[i]->Xw.data()[k] = Xw_[3 * i + k];
+			});
+		}
 
 		// per-edge chi2 (ref getChiSqs :528-543)
 		perEdgeChi_.resize(activeEdges_.size());
