@@ -1400,7 +1400,10 @@ __device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar
 	}
 }
 
-__global__ __launch_bounds__(128 * SPMV_ROWS) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+// MIN_WAVES = 4 caps the kernel at 128 VGPRs (a few spills): worth it only when the rows need more than one round of
+// waves at occupancy 3 -- at S2M / G4M size the kernel is bound by waves in flight x latency -- not at KITTI-00 size.
+template <int MIN_WAVES>
+__global__ __launch_bounds__(128 * SPMV_ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int half = wv & 1, lr = wv >> 1;          // the two waves of a row take 10 of its 20 entry slots each
@@ -1989,9 +1992,12 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 	hipLaunchKernelGGL(pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
+static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
+
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_spmv_kernel, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
+	if (spmv_wants_occupancy(g)) hipLaunchKernelGGL(pcg_spmv_kernel<4>, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
+	else hipLaunchKernelGGL(pcg_spmv_kernel<1>, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
 }
 
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -2050,7 +2056,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 	hipError_t e = hipSuccess;
 	for (int k = 0; k < chunk && e == hipSuccess; k++)
 	{
-		e = add_kernel_node(graph, last, (void*)pcg_spmv_kernel, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, g, st, sys, k, maxIter, tol2);
+		e = add_kernel_node(graph, last, spmv_wants_occupancy(g) ? (void*)pcg_spmv_kernel<4> : (void*)pcg_spmv_kernel<1>, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{
