@@ -496,12 +496,28 @@ struct cuba_hip_solver
 		// per free pose: its edges (sorted-edge ids, ascending = landmark order), over the whole graph
 		std::vector<int> peAllPtr(Pf + 1, 0);
 		std::vector<int>& peAll = h_work[5];
-		for (int i = 0; i < E; i++) if (h_epose[i] < Pf) peAllPtr[h_epose[i] + 1]++;
-		for (int i = 0; i < Pf; i++) peAllPtr[i + 1] += peAllPtr[i];
-		peAll.resize(peAllPtr[Pf]);
 		{
-			std::vector<int> cur(peAllPtr.begin(), peAllPtr.end() - 1);
-			for (int i = 0; i < E; i++) if (h_epose[i] < Pf) peAll[cur[h_epose[i]]++] = i;
+			// counting sort by pose, split over contiguous edge ranges: per-range histograms, offsets in (pose, range)
+			// order, then every range scatters its own edges -- the lists stay in ascending edge order
+			const int T = (int)std::min<long long>(HostPool::instance().maxThreads(), E / 50000 + 1);
+			std::vector<int> hist((size_t)T * Pf, 0);
+			auto range = [&](int t) { return std::make_pair((int)((long long)E * t / T), (int)((long long)E * (t + 1) / T)); };
+			HostPool::instance().run(T, [&](int t) {
+				int* h = hist.data() + (size_t)t * Pf;
+				for (int i = range(t).first; i < range(t).second; i++) if (h_epose[i] < Pf) h[h_epose[i]]++;
+			});
+			int run = 0;
+			for (int ps = 0; ps < Pf; ps++)
+			{
+				peAllPtr[ps] = run;
+				for (int t = 0; t < T; t++) { const int c = hist[(size_t)t * Pf + ps]; hist[(size_t)t * Pf + ps] = run; run += c; }
+			}
+			peAllPtr[Pf] = run;
+			peAll.resize(run);
+			HostPool::instance().run(T, [&](int t) {
+				int* cur = hist.data() + (size_t)t * Pf;
+				for (int i = range(t).first; i < range(t).second; i++) if (h_epose[i] < Pf) peAll[cur[h_epose[i]]++] = i;
+			});
 		}
 		lap("structure:   nfree + pose lists");
 		const std::vector<int>& slm = h_slm[topoSlot];          // sorted edge -> landmark (set_graph)
@@ -552,7 +568,26 @@ struct cuba_hip_solver
 		std::vector<long long> rowProducts(Pf + 1, 0);
 		parallelRows(Pf, rowStart, [&](int i) {
 			PatternEntry* e0 = ent.data() + rowStart[i]; PatternEntry* e1 = ent.data() + rowStart[i + 1];
-			std::sort(e0, e1, [](const PatternEntry& x, const PatternEntry& y) { return x.key < y.key; });
+			{
+				// order by (column, product id).  The entries were produced in product-id order, so a STABLE counting sort
+				// on the column does it in O(n + columns spanned); rows that span far more columns than they have
+				// entries (loop closures) fall back to a comparison sort
+				const size_t nEnt = (size_t)(e1 - e0);
+				uint32_t cmax = (uint32_t)i;
+				for (PatternEntry* e = e0; e < e1; e++) cmax = std::max(cmax, (uint32_t)(e->key >> 32));
+				const size_t span = (size_t)cmax - (size_t)i + 1;          // columns of an upper-triangular row start at the row
+				if (span <= 8 * nEnt + 64)
+				{
+					thread_local std::vector<PatternEntry> tmp;
+					thread_local std::vector<int> cnt;
+					tmp.assign(e0, e1);
+					cnt.assign(span + 1, 0);
+					for (const PatternEntry& x : tmp) cnt[(size_t)(x.key >> 32) - i + 1]++;
+					for (size_t c = 0; c < span; c++) cnt[c + 1] += cnt[c];
+					for (const PatternEntry& x : tmp) e0[cnt[(size_t)(x.key >> 32) - i]++] = x;
+				}
+				else std::sort(e0, e1, [](const PatternEntry& x, const PatternEntry& y) { return x.key < y.key; });
+			}
 			int u = 0; uint32_t last = 0xffffffffu; long long np = 0;
 			for (PatternEntry* e = e0; e < e1; e++)
 			{
@@ -611,9 +646,15 @@ struct cuba_hip_solver
 		lap("structure: adjacency");
 		g.e_begin = h_lmptr[lo]; g.e_end = h_lmptr[hi];
 		// blocks with products, longest lists first (the block pass takes them in this order)
-		for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k);
-		std::stable_sort(odBlocks.begin(), odBlocks.end(), [&](int x, int y) {
-			return prodPtr[x + 1] - prodPtr[x] > prodPtr[y + 1] - prodPtr[y]; });
+		{
+			int maxCnt = 0;
+			for (int k = 0; k < nblk; k++) maxCnt = std::max(maxCnt, prodPtr[k + 1] - prodPtr[k]);
+			std::vector<int> start(maxCnt + 2, 0);                 // stable counting sort by descending list length
+			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) start[maxCnt - c + 1]++; }
+			for (int c = 0; c <= maxCnt; c++) start[c + 1] += start[c];
+			odBlocks.resize(start[maxCnt + 1]);
+			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) odBlocks[start[maxCnt - c]++] = k; }
+		}
 		lap("structure: product lists");
 		// per free pose: its edges inside this handle's landmark range (a contiguous run of the global list)
 		std::vector<int> pePtr(Pf + 1, 0), peEdge;
