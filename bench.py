@@ -135,8 +135,7 @@ def main():
         solver.set_state(q0, t0, X0)
         kt = solver.time_kernels(reps=20)
         nblk = c1["hsc_blocks"]
-        agg = (max(12, (fp.Pf + 159) // 160) + 1) // 2 * 2           # the solver's automatic aggregate size
-        nc = 0 if kt["coarse_setup"] == 0 else (fp.Pf + agg - 1) // agg
+        nc = 0 if kt["coarse_setup"] == 0 else c1["coarse_dim"] / 6.0        # algorithmic_bytes() takes the coarse dimension / 6
         alg = algorithmic_bytes(fp, nblk, nc)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
                     "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials,

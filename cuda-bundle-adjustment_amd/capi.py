@@ -250,7 +250,7 @@ class HipSolver:
         c = (C.c_int64 * 8)()
         self._ck(self.lib.cuba_hip_get_counters(self.h, c))
         return dict(pcg_iterations=int(c[0]), lm_trials=int(c[1]), hsc_blocks=int(c[2]), schur_products=int(c[3]),
-                    coarse_refreshes=int(c[4]), pcg_host_looks=int(c[5]), pcg_iterations_enqueued=int(c[6]))
+                    coarse_refreshes=int(c[4]), pcg_host_looks=int(c[5]), pcg_iterations_enqueued=int(c[6]), coarse_dim=int(c[7]))
 
     def array(self, name):
         n = C.c_size_t()

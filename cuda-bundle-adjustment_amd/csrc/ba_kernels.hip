@@ -104,6 +104,21 @@ __device__ __forceinline__ Scalar fast_rcp(Scalar x)
 	return r;
 }
 
+// weight of pose `pose` in the linear coarse function of its aggregate: -1 .. 1 across the aggregate, 0 in the middle
+// (a trailing aggregate of a single pose has no linear function: weight 0 there, and coarse_assemble_kernel puts an
+// identity block on its diagonal so that the coarse matrix stays regular)
+__device__ __forceinline__ Scalar agg_weight(int pose, int agg, int Pf)
+{
+	if (pose == Pf - 1 && Pf % agg == 1) return Scalar(0);
+	return Scalar(2 * (pose % agg) + 1 - agg) / Scalar(agg);
+}
+// the same for a pose given by its position inside aggregate I (no integer division / modulo)
+__device__ __forceinline__ Scalar agg_weight_local(int I, int il, const DeviceSystem& sys, int Pf)
+{
+	if (I * sys.agg + il == Pf - 1 && il == 0) return Scalar(0);
+	return Scalar(2 * il + 1 - sys.agg) * sys.inv_agg;
+}
+
 // wave-uniform value -> scalar registers (frees the vector registers a long-lived uniform would occupy)
 __device__ __forceinline__ Scalar to_uniform(Scalar v)
 {
@@ -1488,12 +1503,14 @@ __global__ __launch_bounds__(128 * SPMV_ROWS, MIN_WAVES) void pcg_spmv_kernel(De
 		if (lane == 0) part[lr] = dot;
 	}
 	__syncthreads();
-	if (threadIdx.x < 6)         // row sums of q over this workgroup's rows: the two-level kernel builds P^T q from these
+	if (threadIdx.x < 6 * sys.cl)   // (weighted) row sums of q over this workgroup's rows: the two-level kernel builds P^T q from these
 	{
+		const int a = threadIdx.x / 6, c = threadIdx.x - 6 * a;
 		Scalar s2 = 0;
 #pragma unroll
-		for (int w = 0; w < SPMV_ROWS; w++) s2 += qrow[w][threadIdx.x];
-		if (sys.qpart) sys.qpart[6 * (size_t)blockIdx.x + threadIdx.x] = s2;
+		for (int w = 0; w < SPMV_ROWS; w++)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * SPMV_ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		if (sys.qpart) sys.qpart[6 * sys.cl * (size_t)blockIdx.x + threadIdx.x] = s2;
 	}
 	if (threadIdx.x == 64)
 	{
@@ -1562,33 +1579,53 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 // The coarse matrix is dense and small (6*nc <= ~1500), so its explicit inverse is formed on the device by
 // a blocked Gauss-Jordan sweep (SPD => no pivoting) and applied as a dense mat-vec inside the PCG.
 // ---------------------------------------------------------------------------------------------------
-// one 64-lane wave per non-empty coarse block (I,J): lanes 0..35 own one element each and add the fine blocks of the
-// list in a fixed order (no atomics => the coarse matrix, its inverse and hence the whole CG are reproducible)
-__global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st, DeviceSystem sys, Scalar* Ac)
+// one 64-lane wave per non-empty pair of aggregates (I,J): lanes 0..35 own one element of the 6x6 blocks and add the fine
+// blocks of the list in a fixed order (no atomics => the coarse matrix, its inverse and hence the whole CG are
+// reproducible).  With the linear coarse functions (cl = 2) a fine block (i,j) goes into four coarse blocks with the
+// weights 1, w_j, w_i, w_i w_j.
+__global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st, DeviceSystem sys, Scalar* Ac, int Pf)
 {
 	const int lane = threadIdx.x & 63;
 	const int cb = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (cb >= st.nCb || lane >= 36) return;
 	const int r = lane % 6, c = lane / 6;
-	const int Nc = 6 * sys.nc;
-	Scalar acc = 0;
+	const int CD = 6 * sys.cl, Nc = CD * sys.nc;
+	Scalar acc[2][2] = { { 0, 0 }, { 0, 0 } };
 	const int p1 = st.cb_ptr[cb + 1];
 	int p = st.cb_ptr[cb];
 	for (; p + 3 < p1; p += 4)
 	{
-		const int b0 = st.cb_blk[p], b1 = st.cb_blk[p + 1], b2 = st.cb_blk[p + 2], b3 = st.cb_blk[p + 3];
-		const Scalar v0 = sys.hsc[36 * (size_t)(b0 & 0x7fffffff) + (b0 < 0 ? r * 6 + c : c * 6 + r)];
-		const Scalar v1 = sys.hsc[36 * (size_t)(b1 & 0x7fffffff) + (b1 < 0 ? r * 6 + c : c * 6 + r)];
-		const Scalar v2 = sys.hsc[36 * (size_t)(b2 & 0x7fffffff) + (b2 < 0 ? r * 6 + c : c * 6 + r)];
-		const Scalar v3 = sys.hsc[36 * (size_t)(b3 & 0x7fffffff) + (b3 < 0 ? r * 6 + c : c * 6 + r)];
-		acc += (v0 + v1) + (v2 + v3);
+		int b[4]; Scalar v[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++) b[m] = st.cb_blk[p + m];
+#pragma unroll
+		for (int m = 0; m < 4; m++) v[m] = sys.hsc[36 * (size_t)(b[m] & 0x7fffffff) + (b[m] < 0 ? r * 6 + c : c * 6 + r)];
+		if (sys.cl == 2)
+		{
+#pragma unroll
+			for (int m = 0; m < 4; m++)
+			{
+				const Scalar wi = st.cb_wi[p + m], wj = st.cb_wj[p + m];
+				acc[0][0] += v[m]; acc[0][1] += v[m] * wj; acc[1][0] += wi * v[m]; acc[1][1] += wi * v[m] * wj;
+			}
+		}
+		else acc[0][0] += (v[0] + v[1]) + (v[2] + v[3]);
 	}
 	for (; p < p1; p++)
 	{
 		const int b0 = st.cb_blk[p];
-		acc += sys.hsc[36 * (size_t)(b0 & 0x7fffffff) + (b0 < 0 ? r * 6 + c : c * 6 + r)];
+		const Scalar v = sys.hsc[36 * (size_t)(b0 & 0x7fffffff) + (b0 < 0 ? r * 6 + c : c * 6 + r)];
+		acc[0][0] += v;
+		if (sys.cl == 2)
+		{
+			const Scalar wi = st.cb_wi[p], wj = st.cb_wj[p];
+			acc[0][1] += v * wj; acc[1][0] += wi * v; acc[1][1] += wi * v * wj;
+		}
 	}
-	Ac[(size_t)(st.cb_J[cb] * 6 + c) * Nc + st.cb_I[cb] * 6 + r] = acc;
+	if (sys.cl == 2 && st.cb_I[cb] == st.cb_J[cb] && st.cb_I[cb] == sys.nc - 1 && Pf % sys.agg == 1) acc[1][1] = r == c ? Scalar(1) : Scalar(0);
+	for (int a = 0; a < sys.cl; a++)
+		for (int bb = 0; bb < sys.cl; bb++)
+			Ac[(size_t)(st.cb_J[cb] * CD + 6 * bb + c) * Nc + st.cb_I[cb] * CD + 6 * a + r] = acc[a][bb];
 }
 
 constexpr int GJ_B = 32;      // pivot block width of the Gauss-Jordan sweep = output tile edge
@@ -1721,9 +1758,9 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 // Assemble P^T A P from the (already damped) reduced matrix and invert it; returns the buffer (work0 or work1) holding the inverse.
 Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled)
 {
-	const int Nc = 6 * sys.nc;
+	const int Nc = 6 * sys.cl * sys.nc;
 	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
-	hipLaunchKernelGGL(coarse_assemble_kernel, dim3((st.nCb + 3) / 4), dim3(256), 0, s, st, sys, work0);
+	hipLaunchKernelGGL(coarse_assemble_kernel, dim3((st.nCb + 3) / 4), dim3(256), 0, s, st, sys, work0, g.Pf);
 	if (assembled) (void)hipEventRecord(assembled, s);      // from here on the sweep no longer reads the reduced matrix
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (Nc + GJ_B - 1) / GJ_B;
@@ -1757,15 +1794,20 @@ __device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
 	return (v0 + e) + v1;
 }
 
+// CL = coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose index.  Coarse
+// unknown (aggregate J, function a, component c) has index (6 CL) J + 6 a + c.
+template <int CL>
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
+	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
+	constexpr int QV = 16;             // SpMV-workgroup partials prefetched per coarse unknown
 	extern __shared__ unsigned char pcg2_lds[];
-	const int Nc = 6 * sys.nc;
+	const int Nc = CD * sys.nc;
 	Scalar* sR = reinterpret_cast<Scalar*>(pcg2_lds);
 	Scalar* sQ = sR + Nc;
-	Scalar* part = sQ + Nc;
-	Scalar* yc = part + 48;
-	Scalar* wsum = yc + 6;            // [4][8]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
+	Scalar* part = sQ + Nc;           // [8 waves][CD], reused for the 8 x CD partial sums of P^T r_{k+1}
+	Scalar* yc = part + 8 * CD;
+	Scalar* wsum = yc + CD;           // [4][8]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
 	Scalar* rown = wsum + 32;
 	Scalar* qown = rown + 6 * sys.agg;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1785,12 +1827,19 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const int own0 = 6 * I * sys.agg;
 	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
 	const int per = sys.agg / SPMV_ROWS;                 // SpMV workgroups per aggregate
-	const int J = t / 6, cc = t - 6 * J;                 // first (usually only) coarse component of this thread
+	const int J = t / CD, cc = t - CD * J;               // first (usually only) coarse unknown of this thread: aggregate, 6 a + c
 	const int g0 = J * per, g1 = min(sys.npq, g0 + per);
 	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
 	Scalar pre_r = 0, pre_q = 0, pre_p = 0, pre_x = 0, pre_m[6] = { 0, 0, 0, 0, 0, 0 };   // own rows
-	Scalar sr = 0, qv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // restricted sums
-	Scalar ainv[6] = { 0, 0, 0, 0, 0, 0 };              // coarse inverse, columns 6I..6I+5 (symmetric: contiguous)
+	Scalar sr = 0, qv[QV];                               // restricted sums
+	// coarse inverse: rows CD I .. CD I + CD - 1 (= columns: symmetric, contiguous).  Wave w applies rows w, w + 8 (< CD) to
+	// the whole coarse vector -- lane l takes the columns l, l + 64, ... -- so that a row costs ONE wave reduction in one
+	// wave (a thread-per-column layout needs CD reductions in every wave plus a cross-wave stage).
+	constexpr int AR = (CD + 7) / 8;   // rows per wave
+	constexpr int AC = 8;              // prefetched column PAIRS per lane and row (coarse dimension <= 1024), the rest is read later
+	Scalar2 ainv[AR][AC];
+#pragma unroll
+	for (int m = 0; m < QV; m++) qv[m] = 0;
 	if (doUpdate)
 	{
 		if (t < sys.nrz) e_k = rz_slot(sys, k)[t];
@@ -1815,12 +1864,23 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			// unconditional loads from clamped addresses (selected below): a predicated load per element makes the
 			// compiler merge registers after each one and wait for it
 #pragma unroll
-			for (int m = 0; m < 8; m++) qv[m] = sys.qpart[6 * (size_t)max(0, min(g0 + m, g1 - 1)) + cc];
+			for (int m = 0; m < QV; m++)
+				if (m < per) qv[m] = sys.qpart[CD * (size_t)max(0, min(g0 + m, g1 - 1)) + cc];      // (m < per is uniform over the grid)
 		}
-#pragma unroll
-		for (int c = 0; c < 6; c++) ainv[c] = sys.acinv[(size_t)(6 * I + c) * Nc + t];
 	}
-	// ---- rare remainders (more partials / coarse components / own rows than threads) and the arithmetic ----------
+#pragma unroll
+	for (int a = 0; a < AR; a++)
+	{
+#pragma unroll
+		for (int m = 0; m < AC; m++) ainv[a][m] = Scalar2{ 0, 0 };
+		if (wv + 8 * a < CD)                               // wave-uniform
+		{
+			const Scalar* Arow = sys.acinv + (size_t)(CD * I + wv + 8 * a) * Nc;
+#pragma unroll
+			for (int m = 0; m < AC; m++) ainv[a][m] = *reinterpret_cast<const Scalar2*>(Arow + min(2 * lane + 128 * m, Nc - 2));   // Nc is even
+		}
+	}
+	// ---- rare remainders (more partials / coarse unknowns / own rows than threads) and the arithmetic ------------
 	Scalar a_k = e_k, a_0 = e_0, a_q = e_q0 + e_q1;
 	if (doUpdate)
 	{
@@ -1837,7 +1897,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	// restricted sums P^T r_k and P^T q_k (fixed summation order => reproducible)
 	for (int jc = t; jc < Nc; jc += PCG2_T)
 	{
-		const int Jj = jc / 6, c = jc - 6 * Jj;
+		const int Jj = jc / CD, rem = jc - CD * Jj;
 		Scalar s1 = 0, s2 = 0;
 		if (doUpdate)
 		{
@@ -1846,20 +1906,21 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			{
 				s1 = sr;
 #pragma unroll
-				for (int m = 0; m < 8; m++) s2 += h0 + m < h1 ? qv[m] : Scalar(0);
+				for (int m = 0; m < QV; m++) s2 += h0 + m < h1 ? qv[m] : Scalar(0);
 			}
 			else s1 = rcin[jc];
-			for (int gq = h0 + (jc == t ? 8 : 0); gq < h1; gq += 8)
+			for (int gq = h0 + (jc == t ? QV : 0); gq < h1; gq += 8)
 			{
 				Scalar q8[8];
 #pragma unroll
-				for (int m = 0; m < 8; m++) q8[m] = gq + m < h1 ? sys.qpart[6 * (size_t)(gq + m) + c] : Scalar(0);
+				for (int m = 0; m < 8; m++) q8[m] = gq + m < h1 ? sys.qpart[CD * (size_t)(gq + m) + rem] : Scalar(0);
 #pragma unroll
 				for (int m = 0; m < 8; m++) s2 += q8[m];
 			}
 		}
 		else
 		{
+			const int a = rem / 6, c = rem - 6 * a;
 			const int i0 = Jj * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
 			for (int i = i0; i < i1; i += 8)
 			{
@@ -1867,7 +1928,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 				for (int m = 0; m < 8; m++) rv[m] = i + m < i1 ? rin[6 * (size_t)(i + m) + c] : Scalar(0);
 #pragma unroll
-				for (int m = 0; m < 8; m++) s1 += rv[m];
+				for (int m = 0; m < 8; m++) s1 += (a == 0 ? Scalar(1) : agg_weight_local(Jj, i + m - i0, sys, g.Pf)) * rv[m];
 			}
 		}
 		sR[jc] = s1; sQ[jc] = s2;
@@ -1909,44 +1970,32 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			sys.xp[own0 + w] = (w == ow ? pre_x : sys.xp[own0 + w]) + alpha * (w == ow ? pre_p : p[own0 + w]);
 		}
 	}
-	// ---- yc = Ac^-1[6I..6I+5, :] (P^T r - alpha P^T q) ------------------------------------------------------------
-	Scalar acc[6] = { 0, 0, 0, 0, 0, 0 };
-	for (int j = threadIdx.x; j < Nc; j += PCG2_T)
+	// ---- yc = Ac^-1[CD I .. CD I + CD - 1, :] (P^T r - alpha P^T q) --------------------------------------------------
+#pragma unroll
+	for (int a = 0; a < AR; a++)
 	{
-		const Scalar rj = sR[j] - alpha * sQ[j];
-		if (j == threadIdx.x)
+		const int row = wv + 8 * a;
+		Scalar acc = 0;
+#pragma unroll
+		for (int m = 0; m < AC; m++)
 		{
-#pragma unroll
-			for (int c = 0; c < 6; c++) acc[c] += ainv[c] * rj;
+			const int j = 2 * lane + 128 * m;
+			if (j < Nc) acc += ainv[a][m].x * (sR[j] - alpha * sQ[j]) + ainv[a][m].y * (sR[j + 1] - alpha * sQ[j + 1]);
 		}
-		else
-		{
-#pragma unroll
-			for (int c = 0; c < 6; c++) acc[c] += sys.acinv[(size_t)(6 * I + c) * Nc + j] * rj;
-		}
-	}
-#pragma unroll
-	for (int c = 0; c < 6; c++)
-	{
-		acc[c] = wave_sum(acc[c]);
-		if (lane == 0) part[wv * 6 + c] = acc[c];
-	}
-	__syncthreads();
-	if (threadIdx.x < 6)
-	{
-		Scalar s2 = 0;
-#pragma unroll
-		for (int w = 0; w < PCG2_T / 64; w++) s2 += part[w * 6 + threadIdx.x];
-		yc[threadIdx.x] = s2;
+		if (row < CD)
+			for (int j = lane + 128 * AC; j < Nc; j += 64) acc += sys.acinv[(size_t)(CD * I + row) * Nc + j] * (sR[j] - alpha * sQ[j]);
+		acc = wave_sum(acc);
+		if (lane == 0 && row < CD) yc[row] = acc;
 	}
 	__syncthreads();
 	TRACE_MARK();
-	// ---- z = Minv r + yc for the poses of this aggregate; r.z --------------------------------------------------
+	// ---- z = Minv r + P yc for the poses of this aggregate; r.z ---------------------------------------------------
 	Scalar dot = 0;
 	for (int w = ow; w < ownN; w += PCG2_T)
 	{
 		const int il = w / 6, comp = w - 6 * il;
 		Scalar z = yc[comp];
+		if (CL == 2) z += agg_weight_local(I, il, sys, g.Pf) * yc[6 + comp];
 #pragma unroll
 		for (int c = 0; c < 6; c++)
 			z += (w == ow ? pre_m[c] : sys.minv[36 * ((size_t)I * sys.agg + il) + c * 6 + comp]) * rown[6 * il + c];
@@ -1956,22 +2005,23 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	dot = wave_sum(dot);
 	if (lane == 0) wsum[24 + wv] = dot;
 	// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves: 8 interleaved partial
-	// sums per component here, folded after the barrier (a single thread per component would chain `agg` LDS reads)
-	if (t < 48)
+	// sums per coarse unknown here, folded after the barrier (a single thread per unknown would chain `agg` LDS reads)
+	if (t < 8 * CD)
 	{
-		const int c = t % 6, h = t / 6;
+		const int u = t % CD, h = t / CD, a = u / 6, c = u - 6 * a;
 		Scalar s3 = 0;
-		for (int i = 6 * h + c; i < ownN; i += 48) s3 += rown[i];
+		for (int il = h; 6 * il + c < ownN; il += 8)
+			s3 += (a == 0 ? Scalar(1) : agg_weight_local(I, il, sys, g.Pf)) * rown[6 * il + c];
 		part[t] = s3;
 	}
 	__syncthreads();
-	if (t >= 64 && t < 70)
+	if (t >= 64 && t < 64 + CD)
 	{
-		const int c = t - 64;
+		const int u = t - 64;
 		Scalar s3 = 0;
 #pragma unroll
-		for (int h = 0; h < 8; h++) s3 += part[6 * h + c];
-		rcout[6 * I + c] = s3;
+		for (int h = 0; h < 8; h++) s3 += part[CD * h + u];
+		rcout[CD * I + u] = s3;
 	}
 	if (threadIdx.x == 0)
 	{
@@ -1986,10 +2036,17 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
 }
 
+static size_t pcg2_lds_bytes(const DeviceSystem& sys)
+{
+	const size_t cd = 6 * (size_t)sys.cl;
+	return sizeof(Scalar) * (2 * cd * sys.nc + 8 * cd + cd + 32 + 12 * (size_t)sys.agg);
+}
+
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
 {
-	const size_t lds = sizeof(Scalar) * (12 * (size_t)sys.nc + 48 + 6 + 32 + 12 * (size_t)sys.agg);
-	hipLaunchKernelGGL(pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
+	const size_t lds = pcg2_lds_bytes(sys);
+	if (sys.cl == 2) hipLaunchKernelGGL(pcg2_fused_kernel<2>, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
+	else hipLaunchKernelGGL(pcg2_fused_kernel<1>, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
 static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
@@ -2060,8 +2117,8 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{
-			const unsigned lds = (unsigned)(sizeof(Scalar) * (12 * (size_t)sys.nc + 48 + 6 + 32 + 12 * (size_t)sys.agg));
-			e = add_kernel_node(graph, last, (void*)pcg2_fused_kernel, dim3(sys.nc), dim3(PCG2_T), lds, g, sys, k, k + 1, maxIter, tol2, 1);
+			e = add_kernel_node(graph, last, sys.cl == 2 ? (void*)pcg2_fused_kernel<2> : (void*)pcg2_fused_kernel<1>, dim3(sys.nc), dim3(PCG2_T),
+				(unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
 		}
 		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
 	}

@@ -65,6 +65,7 @@ struct DeviceStructure
 	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
+	Scalar *cb_wi = nullptr, *cb_wj = nullptr;                                    // weights of the fine (row, column) poses of every list entry in the linear coarse functions
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo}
 };
 
@@ -99,7 +100,10 @@ struct DeviceSystem
 	                           // of `chunk` iterations be replayed: the graph's last node advances it by `chunk`)
 	// two-level preconditioner: aggregates of `agg` consecutive free poses, 6 coarse dof each
 	int agg = 0;               // 0 = block-Jacobi only
-	int nc = 0;                // number of aggregates (coarse dimension = 6*nc)
+	int nc = 0;                // number of aggregates
+	Scalar inv_agg = 0;        // 1 / agg
+	int cl = 1;                // coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose
+	                           // index (coarse dimension = 6*cl*nc)
 	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
 	Scalar* rc = nullptr;      // [2*6nc] restricted residual P^T r_k, ping-pong by the parity of k like r / r2 (each
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})

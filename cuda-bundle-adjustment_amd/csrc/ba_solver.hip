@@ -93,6 +93,7 @@ struct cuba_hip_solver
 	double pcgTol = sizeof(Scalar) == 8 ? 1e-7 : 1e-4;       // relative M^-1-norm residual; the objective is second-order in the solve error
 	int pcgMaxIter = 0;          // 0 = automatic
 	int pcgCheckEvery = 0;       // PCG iterations per host look at the device stop flag; 0 = adaptive (sized from the previous solve)
+	int coarseLinear = 1;        // 1: constant + linear coarse functions per aggregate (12 unknowns), 0: constant only (6)
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
 	int coarseMaxAge = 2;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
 	                             // changes the iteration count only); refreshed early when the count degrades
@@ -123,6 +124,7 @@ struct cuba_hip_solver
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
+	DevBuf<Scalar> d_cbWi, d_cbWj;
 	std::vector<int> h_rowptr, h_colind;
 	// Pinned, device-mapped host block: [0, 1024) the 4*NSLOT result slots the reduction kernels write DIRECTLY (the host
 	// reads them after a stream synchronisation: no copy kernel, no copy latency), [1024, 2048) PCG flags written by the
@@ -723,18 +725,26 @@ struct cuba_hip_solver
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
 		// coarse level of the preconditioner: aggregates of consecutive free poses
 		int agg = pcgAggregate;
-		if (agg < 0) agg = std::max(12, (Pf + 159) / 160);   // coarse dimension <= 960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
-		if (agg > 0) agg = (agg + SPMV_ROWS - 1) / SPMV_ROWS * SPMV_ROWS;   // aggregates = whole SpMV workgroups (sys.qpart)   // coarse dimension <= 768: the O(Nc^3) inverse stays below ~0.3 ms
+		const int cl = coarseLinear ? 2 : 1;
+		// automatic size: coarse dimension <= ~700-960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
+		if (agg < 0) agg = cl == 2 ? std::max(24, (Pf + 79) / 80) : std::max(12, (Pf + 159) / 160);
+		if (agg > 0) agg = (agg + SPMV_ROWS - 1) / SPMV_ROWS * SPMV_ROWS;   // aggregates = whole SpMV workgroups (sys.qpart)
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
-		// the two-level kernel keeps two coarse vectors in LDS (12 nc + 12 agg + 86 scalars, 64 KB without opting in to more)
-		// and the dense inverse costs O(nc^3): a user-chosen aggregate that small for this many poses is widened
-		while (agg > 0 && (nc > 600 || sizeof(Scalar) * (12 * (size_t)nc + 12 * (size_t)agg + 86) > 60 * 1024)) { agg *= 2; nc = (Pf + agg - 1) / agg; }
+		// the two-level kernel keeps two coarse vectors in LDS and the dense inverse costs O(Nc^3): a user-chosen aggregate
+		// that small for this many poses is widened
+		while (agg > 0 && (cl * nc > 600 || sizeof(Scalar) * (12 * (size_t)cl * nc + 12 * (size_t)agg + 200) > 60 * 1024)) { agg *= 2; nc = (Pf + agg - 1) / agg; }
 		if (nc < 2) { agg = 0; nc = 0; }
-		for (auto& b : d_coarse) b.resize((size_t)36 * nc * nc);
-		d_rc.resize((size_t)12 * nc); d_r2.resize((size_t)6 * Pf);
+		for (auto& b : d_coarse) b.resize((size_t)36 * cl * cl * nc * nc);
+		d_rc.resize((size_t)12 * cl * nc); d_r2.resize((size_t)6 * Pf);
 		lap("structure: uploads + allocs");
 		// coarse-matrix assembly lists: fine blocks grouped by the coarse block (I,J) they fall into (both triangles)
-		std::vector<int> cbI, cbJ, cbPtr(1, 0), cbBlk;
+		std::vector<int> cbI, cbJ, cbPtr(1, 0), cbBlk, adjRow(adjBlk.size());
+		std::vector<Scalar> cbWi, cbWj;
+		auto weight = [&](int pose) {     // same formula as agg_weight() on the device
+			if (pose == Pf - 1 && Pf % agg == 1) return Scalar(0);
+			return Scalar(2 * (pose % agg) + 1 - agg) / Scalar(agg);
+		};
+		for (int i = 0; i < Pf; i++) for (int a = adjPtr[i]; a < adjPtr[i + 1]; a++) adjRow[a] = i;
 		if (nc > 0)
 		{
 			std::vector<uint64_t> ck; ck.reserve(adjBlk.size());
@@ -751,10 +761,11 @@ struct cuba_hip_solver
 					cbI.push_back(cbid / nc); cbJ.push_back(cbid % nc);
 				}
 				cbBlk.push_back(adjBlk[(uint32_t)ck[x]]);
+				if (cl == 2) { cbWi.push_back(weight(adjRow[(uint32_t)ck[x]])); cbWj.push_back(weight(adjCol[(uint32_t)ck[x]])); }
 			}
 			cbPtr.push_back((int)cbBlk.size());
 		}
-		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream);
+		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream); d_cbWi.upload(cbWi, stream); d_cbWj.upload(cbWj, stream);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
 		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + SPMV_ROWS - 1) / SPMV_ROWS;
@@ -773,7 +784,7 @@ struct cuba_hip_solver
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = (int)odBlocks.size(); st.od_blocks = d_odBlocks.data();
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
-		st.nCb = (int)cbI.size(); st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data();
+		st.nCb = (int)cbI.size(); st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
 		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = slotsDev; sys.host_flags = flagsDev; sys.parts = d_parts.data();
@@ -784,9 +795,9 @@ struct cuba_hip_solver
 		sys.rzStride = rzStride; sys.pqStride = pqStride; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
-		d_qpart.resize((size_t)6 * gridSpmv); sys.qpart = d_qpart.data();
+		d_qpart.resize((size_t)6 * cl * gridSpmv); sys.qpart = d_qpart.data();
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
-		sys.agg = agg; sys.nc = nc; sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
+		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
 		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;   // pattern of Hsc doubles as the "symbolic" phase of the reduced solver
@@ -1282,6 +1293,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
+		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
 		else if (k == "schur_atomic") { s->schurAtomic = value != 0; s->haveStructure = false; }   // the product -> block map is built on demand
 		else if (k == "coarse_max_age") s->coarseMaxAge = std::max(0, (int)value);
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
@@ -1394,7 +1406,7 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t c[8])
 {
 	return guarded(s, [&] {
 		c[0] = s->cntPcgIters; c[1] = s->cntTrials; c[2] = s->st.nblk; c[3] = s->nmul;
-		c[4] = s->cntCoarseRefresh; c[5] = s->cntPcgLooks; c[6] = s->cntPcgEnqueued; c[7] = 0;
+		c[4] = s->cntCoarseRefresh; c[5] = s->cntPcgLooks; c[6] = s->cntPcgEnqueued; c[7] = 6 * (int64_t)s->sys.cl * s->sys.nc;
 	});
 }
 

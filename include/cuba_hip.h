@@ -83,7 +83,9 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 /* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
    (default 4*6*Pf capped at 32768), "pcg_check_every" (PCG iterations between host looks at the device stop flag; default 0 =
    batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
-   preconditioner; -1 = automatic: max(12, Pf/160), 0 = block-Jacobi only), "coarse_max_age" (default 2: the coarse
+   preconditioner; -1 = automatic: max(24, Pf/80) with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
+   only), "coarse_linear" (default 1: constant + linear-in-pose-index coarse functions per aggregate, 12 unknowns each;
+   0 = constant only, 6 unknowns), "coarse_max_age" (default 2: the coarse
    inverse of the two-level preconditioner is reused for up to two further solves of a run; 0 = rebuild it for every
    solve), "coarse_refresh_growth" (default 1.25: rebuild early once a solve needs that many times the iterations of
    the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
@@ -181,7 +183,8 @@ int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITE
 /* Counters of the last optimize / solve: [0] PCG iterations (total), [1] LM trials (total),
    [2] number of 6x6 blocks in upper-triangular Hsc, [3] number of Schur block products (nmul),
    [4] coarse-inverse refreshes of the two-level preconditioner, [5] host looks at the device stop flag,
-   [6] PCG iterations enqueued (>= [0]: launches after convergence return at once), [7] reserved. */
+   [6] PCG iterations enqueued (>= [0]: launches after convergence return at once), [7] dimension of the coarse
+   system of the two-level preconditioner. */
 int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
 
 /* ---- introspection (parity tests) and multi-GPU plumbing ------------------------------------------ */
