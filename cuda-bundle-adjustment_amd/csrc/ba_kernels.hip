@@ -1417,14 +1417,16 @@ __device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar
 
 // MIN_WAVES = 4 caps the kernel at 128 VGPRs (a few spills): worth it only when the rows need more than one round of
 // waves at occupancy 3 -- at S2M / G4M size the kernel is bound by waves in flight x latency -- not at KITTI-00 size.
-template <int MIN_WAVES>
-__global__ __launch_bounds__(128 * SPMV_ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+// ROWS = block rows per workgroup (2 or 4): more rows per workgroup mean fewer row-sum partials for the two-level kernel
+// to add up (large graphs), fewer rows mean more workgroups to spread over the CUs (small graphs).
+template <int ROWS, int MIN_WAVES>
+__global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int half = wv & 1, lr = wv >> 1;          // the two waves of a row take 10 of its 20 entry slots each
 	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
 	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
-	const int row = blockIdx.x * SPMV_ROWS + lr;
+	const int row = blockIdx.x * ROWS + lr;
 	TRACE_DECL
 	TRACE_MARK();
 	// scalar loads, consumed at the very end (k is chunk-local here; the absolute number only enters the tests)
@@ -1479,9 +1481,9 @@ __global__ __launch_bounds__(128 * SPMV_ROWS, MIN_WAVES) void pcg_spmv_kernel(De
 	tz += __shfl_down(accz, 12); tp += __shfl_down(accp, 12);
 	tz += __shfl_down(accz, 18); tp += __shfl_down(accp, 18);
 	tz += __shfl_down(accz, 24); tp += __shfl_down(accp, 24);
-	__shared__ Scalar other[SPMV_ROWS][12];
-	__shared__ Scalar qrow[SPMV_ROWS][6];
-	__shared__ Scalar part[SPMV_ROWS];
+	__shared__ Scalar other[ROWS][12];
+	__shared__ Scalar qrow[ROWS][6];
+	__shared__ Scalar part[ROWS];
 	if (half == 1 && lane < 6) { other[lr][lane] = tz; other[lr][6 + lane] = tp; }
 	__syncthreads();
 	TRACE_MARK();
@@ -1508,19 +1510,19 @@ __global__ __launch_bounds__(128 * SPMV_ROWS, MIN_WAVES) void pcg_spmv_kernel(De
 		const int a = threadIdx.x / 6, c = threadIdx.x - 6 * a;
 		Scalar s2 = 0;
 #pragma unroll
-		for (int w = 0; w < SPMV_ROWS; w++)
-			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * SPMV_ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		for (int w = 0; w < ROWS; w++)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
 		if (sys.qpart) sys.qpart[6 * sys.cl * (size_t)blockIdx.x + threadIdx.x] = s2;
 	}
 	if (threadIdx.x == 64)
 	{
 		Scalar s2 = 0;
 #pragma unroll
-		for (int w = 0; w < SPMV_ROWS; w++) s2 += part[w];
+		for (int w = 0; w < ROWS; w++) s2 += part[w];
 		pq_slot(sys, k)[blockIdx.x] = s2;
 	}
 	TRACE_MARK();
-	TRACE_FLUSH(0, blockIdx.x * 2 * SPMV_ROWS + wv);
+	TRACE_FLUSH(0, blockIdx.x * 2 * ROWS + wv);
 }
 
 // B(k): alpha = rz[k]/pq[k]; x += alpha p; r -= alpha q; z = Minv r; rz[k+1] += r.z
@@ -1826,7 +1828,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const int t = threadIdx.x;
 	const int own0 = 6 * I * sys.agg;
 	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
-	const int per = sys.agg / SPMV_ROWS;                 // SpMV workgroups per aggregate
+	const int per = sys.agg / sys.spmv_rows;             // SpMV workgroups per aggregate
 	const int J = t / CD, cc = t - CD * J;               // first (usually only) coarse unknown of this thread: aggregate, 6 a + c
 	const int g0 = J * per, g1 = min(sys.npq, g0 + per);
 	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
@@ -1836,7 +1838,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	// the whole coarse vector -- lane l takes the columns l, l + 64, ... -- so that a row costs ONE wave reduction in one
 	// wave (a thread-per-column layout needs CD reductions in every wave plus a cross-wave stage).
 	constexpr int AR = (CD + 7) / 8;   // rows per wave
-	constexpr int AC = 8;              // prefetched column PAIRS per lane and row (coarse dimension <= 1024), the rest is read later
+	constexpr int AC = 12;             // prefetched column PAIRS per lane and row (coarse dimension <= 1536), the rest is read later
 	Scalar2 ainv[AR][AC];
 #pragma unroll
 	for (int m = 0; m < QV; m++) qv[m] = 0;
@@ -2050,11 +2052,17 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 }
 
 static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
+int spmv_rows_for(int Pf) { return 2 * (long long)Pf > 3 * 1024 ? 4 : 2; }                            // (the 4-row workgroup needs the 128-VGPR instantiation)
+static void* spmv_kernel_for(const DeviceGraph& g, const DeviceSystem& sys)
+{
+	if (sys.spmv_rows == 4) return (void*)pcg_spmv_kernel<4, 4>;
+	return spmv_wants_occupancy(g) ? (void*)pcg_spmv_kernel<2, 4> : (void*)pcg_spmv_kernel<2, 1>;
+}
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	if (spmv_wants_occupancy(g)) hipLaunchKernelGGL(pcg_spmv_kernel<4>, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
-	else hipLaunchKernelGGL(pcg_spmv_kernel<1>, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, s, g, st, sys, k, maxIter, tol2);
+	const dim3 grid((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), block(128 * sys.spmv_rows);
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar))spmv_kernel_for(g, sys), grid, block, 0, s, g, st, sys, k, maxIter, tol2);
 }
 
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -2113,7 +2121,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 	hipError_t e = hipSuccess;
 	for (int k = 0; k < chunk && e == hipSuccess; k++)
 	{
-		e = add_kernel_node(graph, last, spmv_wants_occupancy(g) ? (void*)pcg_spmv_kernel<4> : (void*)pcg_spmv_kernel<1>, dim3((g.Pf + SPMV_ROWS - 1) / SPMV_ROWS), dim3(128 * SPMV_ROWS), 0, g, st, sys, k, maxIter, tol2);
+		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), dim3(128 * sys.spmv_rows), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{

@@ -69,7 +69,7 @@ struct DeviceStructure
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo}
 };
 
-constexpr int SPMV_ROWS = 2;    // block rows per SpMV workgroup (two waves each)
+int spmv_rows_for(int Pf);      // block rows per SpMV workgroup (two waves each): 2, or 4 for large graphs
 
 struct DeviceSystem
 {
@@ -108,8 +108,9 @@ struct DeviceSystem
 	Scalar* rc = nullptr;      // [2*6nc] restricted residual P^T r_k, ping-pong by the parity of k like r / r2 (each
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
 	Scalar* hrow = nullptr;    // [36 * 20 * ell_m * Pf] row-ordered copy of Hsc for the SpMV (launch_hsc_expand), entry (row, m, slot)
-	Scalar* qpart = nullptr;   // [6*npq] sum of q = A p over the SPMV_ROWS block rows of each SpMV workgroup (P^T q is
-	                           // summed from these: aggregates are whole multiples of SPMV_ROWS rows)
+	int spmv_rows = 2;         // block rows per SpMV workgroup
+	Scalar* qpart = nullptr;   // [6*cl*npq] (weighted) sums of q = A p over the block rows of each SpMV workgroup (P^T q is
+	                           // summed from these: aggregates are whole multiples of spmv_rows rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
 };
 

@@ -727,8 +727,9 @@ struct cuba_hip_solver
 		int agg = pcgAggregate;
 		const int cl = coarseLinear ? 2 : 1;
 		// automatic size: coarse dimension <= ~700-960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
-		if (agg < 0) agg = cl == 2 ? std::max(24, (Pf + 79) / 80) : std::max(12, (Pf + 159) / 160);
-		if (agg > 0) agg = (agg + SPMV_ROWS - 1) / SPMV_ROWS * SPMV_ROWS;   // aggregates = whole SpMV workgroups (sys.qpart)
+		if (agg < 0) agg = cl == 2 ? std::max(24, (Pf + 114) / 115) : std::max(12, (Pf + 159) / 160);
+		const int spmvRows = spmv_rows_for(Pf);
+		if (agg > 0) agg = (agg + spmvRows - 1) / spmvRows * spmvRows;   // aggregates = whole SpMV workgroups (sys.qpart)
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 		// the two-level kernel keeps two coarse vectors in LDS and the dense inverse costs O(Nc^3): a user-chosen aggregate
 		// that small for this many poses is widened
@@ -768,7 +769,7 @@ struct cuba_hip_solver
 		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream); d_cbWi.upload(cbWi, stream); d_cbWj.upload(cbWj, stream);
 		int mi = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		maxIterAlloc = mi;
-		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + SPMV_ROWS - 1) / SPMV_ROWS;
+		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + spmvRows - 1) / spmvRows;
 		const int rzStride = std::max(1, std::max(std::max(gridSetup, gridUpd), nc)), pqStride = std::max(1, gridSpmv);
 		d_rz.resize((size_t)5 * rzStride); d_pq.resize((size_t)4 * pqStride);
 		sync();
@@ -797,6 +798,7 @@ struct cuba_hip_solver
 		coarseValid = false;
 		d_qpart.resize((size_t)6 * cl * gridSpmv); sys.qpart = d_qpart.data();
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
+		sys.spmv_rows = spmvRows;
 		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		haveStructure = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
