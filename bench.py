@@ -153,11 +153,15 @@ def main():
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kitti00_pmc_traffic.json")))
         pmc_path = pmc_files[-1] if pmc_files else ""
         pmc_names = {"pcg_spmv": ["pcg_spmv_kernel"], "pcg_update": ["pcg2_fused_kernel"], "residual_chi2": ["residual_chi2_kernel"],
-                     "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1>", "pose_pass_kernel<1>", "block_pass_kernel"]}
+                     "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1>", "pose_pass_kernel<1>", "block_pass_kernel"]}   # (exact names match first)
         if args.shape == "kitti00" and os.path.exists(pmc_path) and dom in pmc_names:
             pk = json.load(open(pmc_path))["kernels"]
-            if all(n in pk for n in pmc_names[dom]):
-                traffic = sum(pk[n]["hbm_bytes_fetch_x2"] for n in pmc_names[dom])
+            def find(name):          # template instantiations carry their arguments in the name: match the exact name or "name<...>"
+                hits = [v for k, v in pk.items() if k == name or k.startswith(name + "<")]
+                return max(hits, key=lambda v: v["launches"]) if hits else None
+            found = [find(n) for n in pmc_names[dom]]
+            if all(f is not None for f in found):
+                traffic = sum(f["hbm_bytes_fetch_x2"] for f in found)
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "traffic_source": os.path.basename(pmc_path) if traffic else None,

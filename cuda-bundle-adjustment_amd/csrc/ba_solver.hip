@@ -95,7 +95,7 @@ struct cuba_hip_solver
 	int pcgCheckEvery = 0;       // PCG iterations per host look at the device stop flag; 0 = adaptive (sized from the previous solve)
 	int coarseLinear = 1;        // 1: constant + linear coarse functions per aggregate (12 unknowns), 0: constant only (6)
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
-	int coarseMaxAge = 2;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
+	int coarseMaxAge = 3;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
 	                             // changes the iteration count only); refreshed early when the count degrades
 	bool schurAtomic = false;    // true: first-generation landmark-major Schur kernel with fp64 atomics (A/B runs)
 	bool profile = false;
@@ -217,7 +217,7 @@ struct cuba_hip_solver
 		assemblePending = false;
 	}
 	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
-	double coarseGrowth = 1.25;  // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
+	double coarseGrowth = 1.6;   // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
 	struct PatternEntry { uint64_t key; int ea, eb; };   // (column << 32 | product id + 1), the product's two sorted-edge ids
 	std::vector<PatternEntry> h_ent; std::vector<int> h_work[6];   // work arrays of build_structure
 	std::vector<double> h_chiSorted;         // per-edge chi2 in sorted order (staging of chi_squares)

@@ -85,9 +85,9 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
    preconditioner; -1 = automatic: max(24, Pf/80) with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
    only), "coarse_linear" (default 1: constant + linear-in-pose-index coarse functions per aggregate, 12 unknowns each;
-   0 = constant only, 6 unknowns), "coarse_max_age" (default 2: the coarse
-   inverse of the two-level preconditioner is reused for up to two further solves of a run; 0 = rebuild it for every
-   solve), "coarse_refresh_growth" (default 1.25: rebuild early once a solve needs that many times the iterations of
+   0 = constant only, 6 unknowns), "coarse_max_age" (default 3: the coarse
+   inverse of the two-level preconditioner is reused for up to three further solves of a run; 0 = rebuild it for every
+   solve), "coarse_refresh_growth" (default 1.6: rebuild early once a solve needs that many times the iterations of
    the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
    the device writes into mapped host memory, not from hipStreamSynchronize), "speculate_tail" (default 0; 1 = optimize()
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
