@@ -1587,47 +1587,42 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 // weights 1, w_j, w_i, w_i w_j.
 __global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st, DeviceSystem sys, Scalar* Ac, int Pf)
 {
-	const int lane = threadIdx.x & 63;
-	const int cb = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (cb >= st.nCb || lane >= 36) return;
-	const int r = lane % 6, c = lane / 6;
+	// one workgroup per pair of aggregates: its four waves take every fourth entry of the list, the partial sums are
+	// added in wave order
+	__shared__ Scalar sh[4][4][36];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int cb = blockIdx.x;
+	const int r = lane % 6, c = (lane / 6) % 6;
 	const int CD = 6 * sys.cl, Nc = CD * sys.nc;
 	Scalar acc[2][2] = { { 0, 0 }, { 0, 0 } };
 	const int p1 = st.cb_ptr[cb + 1];
-	int p = st.cb_ptr[cb];
-	for (; p + 3 < p1; p += 4)
+	for (int p = st.cb_ptr[cb] + wv; p < p1; p += 16)
 	{
-		int b[4]; Scalar v[4];
+		int b[4]; Scalar v[4], wi[4], wj[4];
 #pragma unroll
-		for (int m = 0; m < 4; m++) b[m] = st.cb_blk[p + m];
-#pragma unroll
-		for (int m = 0; m < 4; m++) v[m] = sys.hsc[36 * (size_t)(b[m] & 0x7fffffff) + (b[m] < 0 ? r * 6 + c : c * 6 + r)];
-		if (sys.cl == 2)
+		for (int m = 0; m < 4; m++)
 		{
-#pragma unroll
-			for (int m = 0; m < 4; m++)
-			{
-				const Scalar wi = st.cb_wi[p + m], wj = st.cb_wj[p + m];
-				acc[0][0] += v[m]; acc[0][1] += v[m] * wj; acc[1][0] += wi * v[m]; acc[1][1] += wi * v[m] * wj;
-			}
+			const int q = min(p + 4 * m, p1 - 1);
+			b[m] = st.cb_blk[q];
+			wi[m] = sys.cl == 2 ? st.cb_wi[q] : Scalar(0); wj[m] = sys.cl == 2 ? st.cb_wj[q] : Scalar(0);
 		}
-		else acc[0][0] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+		for (int m = 0; m < 4; m++) v[m] = p + 4 * m < p1 ? sys.hsc[36 * (size_t)(b[m] & 0x7fffffff) + (b[m] < 0 ? r * 6 + c : c * 6 + r)] : Scalar(0);
+#pragma unroll
+		for (int m = 0; m < 4; m++) { acc[0][0] += v[m]; acc[0][1] += v[m] * wj[m]; acc[1][0] += wi[m] * v[m]; acc[1][1] += wi[m] * v[m] * wj[m]; }
 	}
-	for (; p < p1; p++)
+	if (lane < 36)
 	{
-		const int b0 = st.cb_blk[p];
-		const Scalar v = sys.hsc[36 * (size_t)(b0 & 0x7fffffff) + (b0 < 0 ? r * 6 + c : c * 6 + r)];
-		acc[0][0] += v;
-		if (sys.cl == 2)
-		{
-			const Scalar wi = st.cb_wi[p], wj = st.cb_wj[p];
-			acc[0][1] += v * wj; acc[1][0] += wi * v; acc[1][1] += wi * v * wj;
-		}
+		sh[wv][0][lane] = acc[0][0]; sh[wv][1][lane] = acc[0][1]; sh[wv][2][lane] = acc[1][0]; sh[wv][3][lane] = acc[1][1];
 	}
-	if (sys.cl == 2 && st.cb_I[cb] == st.cb_J[cb] && st.cb_I[cb] == sys.nc - 1 && Pf % sys.agg == 1) acc[1][1] = r == c ? Scalar(1) : Scalar(0);
-	for (int a = 0; a < sys.cl; a++)
-		for (int bb = 0; bb < sys.cl; bb++)
-			Ac[(size_t)(st.cb_J[cb] * CD + 6 * bb + c) * Nc + st.cb_I[cb] * CD + 6 * a + r] = acc[a][bb];
+	__syncthreads();
+	if (threadIdx.x >= 36 * 4) return;
+	const int ab = threadIdx.x / 36, el = threadIdx.x - 36 * ab, a = ab >> 1, bb = ab & 1;
+	if (a >= sys.cl || bb >= sys.cl) return;
+	Scalar v = ((sh[0][ab][el] + sh[1][ab][el]) + sh[2][ab][el]) + sh[3][ab][el];
+	const int rr = el % 6, cc = el / 6;
+	if (ab == 3 && st.cb_I[cb] == st.cb_J[cb] && st.cb_I[cb] == sys.nc - 1 && Pf % sys.agg == 1) v = rr == cc ? Scalar(1) : Scalar(0);
+	Ac[(size_t)(st.cb_J[cb] * CD + 6 * bb + cc) * Nc + st.cb_I[cb] * CD + 6 * a + rr] = v;
 }
 
 constexpr int GJ_B = 32;      // pivot block width of the Gauss-Jordan sweep = output tile edge
@@ -1762,7 +1757,7 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 {
 	const int Nc = 6 * sys.cl * sys.nc;
 	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
-	hipLaunchKernelGGL(coarse_assemble_kernel, dim3((st.nCb + 3) / 4), dim3(256), 0, s, st, sys, work0, g.Pf);
+	if (st.nCb) hipLaunchKernelGGL(coarse_assemble_kernel, dim3(st.nCb), dim3(256), 0, s, st, sys, work0, g.Pf);
 	if (assembled) (void)hipEventRecord(assembled, s);      // from here on the sweep no longer reads the reduced matrix
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (Nc + GJ_B - 1) / GJ_B;
@@ -2072,10 +2067,10 @@ void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const De
 
 // last node of an iteration graph: advance the iteration offset and report the solver's flags straight into the
 // device-mapped host block the host looks at after synchronising (no copy kernels on the way)
-__global__ void pcg_advance_kernel(DeviceSystem sys, int n)
+__global__ void pcg_advance_kernel(DeviceSystem sys, int n, int report)
 {
 	*sys.kbase += n;
-	if (sys.host_flags)
+	if (report && sys.host_flags)
 	{
 		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
 		__threadfence_system();
@@ -2085,12 +2080,12 @@ __global__ void pcg_advance_kernel(DeviceSystem sys, int n)
 
 void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, 0);
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, 0, 1);
 }
 
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, n);
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, n, 1);
 }
 
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -2115,7 +2110,7 @@ static hipError_t add_kernel_node(hipGraph_t graph, hipGraphNode_t& last, void* 
 	return e;
 }
 
-hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2)
+hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2, int report)
 {
 	hipGraphNode_t last = nullptr;
 	hipError_t e = hipSuccess;
@@ -2130,7 +2125,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		}
 		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
 	}
-	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(1), 0, sys, chunk);
+	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(1), 0, sys, chunk, report);
 	return e;
 }
 

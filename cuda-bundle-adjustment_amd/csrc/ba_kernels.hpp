@@ -151,7 +151,9 @@ void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
 // Adds `chunk` PCG iterations (chunk-local k = 0..chunk-1) and the kbase advance to `graph` as a chain of kernel nodes.
-hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2);
+// report != 0: the last node also copies the solver's flags and a ticket into the mapped host block (only the last graph of a
+// batch needs that: the write to host memory costs several microseconds)
+hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2, int report);
 
 // hsc (damped, after pcg_setup) -> sys.hrow
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);

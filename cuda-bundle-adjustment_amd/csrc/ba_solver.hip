@@ -167,16 +167,16 @@ struct cuba_hip_solver
 		else launch_pcg_iteration(g, st, sys, k, maxIter, tol2, s);
 	}
 
-	hipGraphExec_t pcgGraph(int chunk, int maxIter, Scalar tol2)
+	hipGraphExec_t pcgGraph(int chunk, int maxIter, Scalar tol2, bool report)
 	{
 		if (pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter) dropPcgGraph();   // baked-in arguments
-		const auto key = std::make_pair(chunk, (const Scalar*)sys.acinv);
+		const auto key = std::make_pair(report ? -chunk : chunk, (const Scalar*)sys.acinv);
 		auto it = pcgGraphs.find(key);
 		if (it != pcgGraphs.end()) return it->second;
 		hipGraph_t graph = nullptr;
 		hipGraphExec_t exec = nullptr;
 		HIP_TRY(hipGraphCreate(&graph, 0));
-		HIP_TRY(graph_add_pcg_chunk(graph, g, st, sys, chunk, maxIter, tol2));
+		HIP_TRY(graph_add_pcg_chunk(graph, g, st, sys, chunk, maxIter, tol2, report ? 1 : 0));
 		if (std::getenv("CUBA_HIP_DEBUG"))
 		{
 			size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn);
@@ -980,7 +980,8 @@ struct cuba_hip_solver
 			{
 				int c = fixedChunk;
 				if (!c) for (c = 256; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
-				if (useGraph) { HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2), stream)); noteReport(); }
+				const bool last = todo - c <= 0;          // only the last graph of the batch reports to the host
+				if (useGraph) { HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2, last), stream)); if (last) noteReport(); }
 				else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				k0 += c; todo -= c;
 			}

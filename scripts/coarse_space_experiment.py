@@ -43,16 +43,20 @@ def prolong(weights):
 
 idx = np.arange(P)
 def spaces():
-    for g in (12, 16, 24):
+    for g in (12,):
         yield f"constant, {g} poses/aggregate", prolong([(idx, idx // g, np.ones(P))])
     for g in (24, 32):
         J = idx // g; mid = J * g + (np.minimum((J + 1) * g, P) - J * g - 1) / 2.0
         yield f"constant + linear, {g} poses/aggregate", prolong([(idx, 2 * J, np.ones(P)), (idx, 2 * J + 1, (idx - mid) / (g / 2.0))])
+    for g in (36, 48):
+        J = idx // g; mid = J * g + (np.minimum((J + 1) * g, P) - J * g - 1) / 2.0
+        u = (idx - mid) / (g / 2.0)
+        yield f"constant + linear + quadratic, {g} poses/aggregate", prolong([(idx, 3 * J, np.ones(P)), (idx, 3 * J + 1, u), (idx, 3 * J + 2, 1.5 * u * u - 0.5)])
     for g in (12, 16, 24):
         s = idx / g; left = np.floor(s).astype(int); w = s - left
         yield f"linear hats, nodes every {g} poses", prolong([(idx, left, 1 - w), (idx, left + 1, w)])
 
-for it in (3, 6, 9):
+for it in ((3, 6, 9) if len(sys.argv) < 3 else [int(a) for a in sys.argv[2].split(',')]):
     A, b = system(it)
     Dinv = np.linalg.inv(np.stack([A[6*j:6*j+6, 6*j:6*j+6].toarray() for j in range(P)]))
     jac = lambda r: np.einsum("nij,nj->ni", Dinv, r.reshape(P, 6)).ravel()
