@@ -80,14 +80,14 @@ public:
 
 	void addMonocularEdge(MonoEdge* e) override
 	{
-		mono_.insert(e);
+		mono_.insert(e); edgesDirty_ = true;
 		e->vertexP->edges.insert(e);
 		e->vertexL->edges.insert(e);
 	}
 
 	void addStereoEdge(StereoEdge* e) override
 	{
-		stereo_.insert(e);
+		stereo_.insert(e); edgesDirty_ = true;
 		e->vertexP->edges.insert(e);
 		e->vertexL->edges.insert(e);
 	}
@@ -119,6 +119,7 @@ public:
 	{
 		if (PoseVertex* p = e->poseVertex()) p->edges.erase(e);
 		if (LandmarkVertex* l = e->landmarkVertex()) l->edges.erase(e);
+		edgesDirty_ = true;
 		if (e->dim() == 2) mono_.erase(static_cast<MonoEdge*>(e));
 		else if (e->dim() == 3) stereo_.erase(static_cast<StereoEdge*>(e));
 	}
@@ -139,11 +140,14 @@ public:
 	void initialize() override
 	{
 		const auto t0 = std::chrono::steady_clock::now();
-		// results of the previous optimize() stay queryable: they refer to the old edge list, which is set aside (a
-		// move) instead of being indexed here -- the index over 561 k edges costs more than the rest of initialize()
-		if (!chiIndexBuilt_ && chiEdges_.empty()) chiEdges_ = std::move(activeEdges_);
-		activePoses_.clear(); activeLandmarks_.clear(); activeEdges_.clear();
-		edgePose_.clear(); edgeLandmark_.clear(); edgeDim_.clear(); meas_.clear(); omega_.clear();
+		// (results of the previous optimize() stay queryable: when the edge list is rebuilt below, the old one is set aside
+		// -- a move -- instead of being indexed here: the index over 561 k edges costs more than the rest of initialize())
+		// the previous flattening is kept for comparison: when neither the edge set nor the active vertices (and their
+		// free / fixed split) changed, the edge -> vertex indices are still right and only the values are read again
+		std::vector<PoseVertex*> prevPoses;
+		std::vector<LandmarkVertex*> prevLandmarks;
+		prevPoses.swap(activePoses_); prevLandmarks.swap(activeLandmarks_);
+		const int prevFreeP = numFreePoses_, prevFreeL = numFreeLandmarks_;
 
 		// vertices in id order (the reference walks its std::maps), free ones first, vertices without edges left out
 		// (ref :128-200).  The id-ordered pointer lists are cached between calls as long as no vertex was added or
@@ -167,6 +171,32 @@ public:
 		// edges: mono first, then stereo, insertion order inside each type; edges with both ends fixed are inactive
 		// (ref :204-243).  561 k edges mean 561 k dependent pointer loads (edge -> vertex -> index), so the sweep is
 		// split over a few host threads: count the active edges per chunk, prefix-sum, fill.
+		const bool sameTopology = !edgesDirty_ && !activeEdges_.empty() && prevFreeP == numFreePoses_ && prevFreeL == numFreeLandmarks_ &&
+			prevPoses == activePoses_ && prevLandmarks == activeLandmarks_;
+		if (sameTopology)
+		{
+			const size_t nAct = activeEdges_.size();
+			const unsigned T = hostThreads(nAct);
+			forThreads(T, [&](unsigned t) {
+				for (size_t o = nAct * t / T; o < nAct * (t + 1) / T; o++)
+				{
+					if (edgeDim_[o] == 2)
+					{
+						const MonoEdge* m = static_cast<const MonoEdge*>(activeEdges_[o]);
+						meas_[3 * o] = m->measurement[0]; meas_[3 * o + 1] = m->measurement[1]; meas_[3 * o + 2] = 0.0;
+						omega_[o] = m->information;
+					}
+					else
+					{
+						const StereoEdge* m = static_cast<const StereoEdge*>(activeEdges_[o]);
+						meas_[3 * o] = m->measurement[0]; meas_[3 * o + 1] = m->measurement[1]; meas_[3 * o + 2] = m->measurement[2];
+						omega_[o] = m->information;
+					}
+				}
+			});
+		}
+		else
+		{
 		const auto& ms = mono_.slots();
 		const auto& ss = stereo_.slots();
 		const size_t nM = ms.size(), nAll = nM + ss.size();
@@ -182,6 +212,7 @@ public:
 		});
 		for (unsigned t = 0; t < T; t++) cnt[t + 1] += cnt[t];
 		const size_t nAct = cnt[T];
+		if (!chiIndexBuilt_ && chiEdges_.empty()) chiEdges_ = std::move(activeEdges_);   // pending per-edge results refer to the old list
 		activeEdges_.resize(nAct); edgePose_.resize(nAct); edgeLandmark_.resize(nAct); edgeDim_.resize(nAct);
 		meas_.resize(3 * nAct); omega_.resize(nAct);
 		forThreads(T, [&](unsigned t) {
@@ -208,6 +239,8 @@ public:
 				o++;
 			}
 		});
+		}
+		edgesDirty_ = false;
 
 		stats_.clear();
 		graphDirty_ = true;
@@ -275,6 +308,7 @@ public:
 	void clear() override
 	{
 		poses_.clear(); landmarks_.clear(); mono_.clear(); stereo_.clear(); stats_.clear();
+		posesDirty_ = landmarksDirty_ = edgesDirty_ = true;
 		initialized_ = false;
 	}
 
@@ -360,6 +394,7 @@ private:
 	std::vector<PoseVertex*> poseList_;           // the maps' values in id order, rebuilt when a vertex was added / removed
 	std::vector<LandmarkVertex*> landmarkList_;
 	bool posesDirty_ = true, landmarksDirty_ = true;
+	bool edgesDirty_ = true;                      // an edge was added / removed since the last initialize()
 	OrderedSet<MonoEdge> mono_;
 	OrderedSet<StereoEdge> stereo_;
 	int robustKind_[2] = { 0, 0 };
