@@ -2047,7 +2047,11 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 }
 
 static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
-int spmv_rows_for(int Pf) { return 2 * (long long)Pf > 3 * 1024 ? 4 : 2; }                            // (the 4-row workgroup needs the 128-VGPR instantiation)
+int spmv_rows_for(int Pf)
+{
+	if (const char* e = std::getenv("CUBA_HIP_SPMV_ROWS")) return std::atoi(e) == 4 ? 4 : 2;     // A/B knob
+	return 2 * (long long)Pf > 3 * 1024 ? 4 : 2;
+}                            // (the 4-row workgroup needs the 128-VGPR instantiation)
 static void* spmv_kernel_for(const DeviceGraph& g, const DeviceSystem& sys)
 {
 	if (sys.spmv_rows == 4) return (void*)pcg_spmv_kernel<4, 4>;
