@@ -83,5 +83,13 @@ int main(int argc, char** argv)
 	ba->initialize();
 	ba->optimize(iters2);
 	for (const auto& s : ba->batchStatistics()) std::printf("stage2 iter: %2d, chi2: %.6f\n", s.iteration + 1, s.chi2);
+
+	// stage 3: the same graph with new values -- every measurement moves by a quarter pixel, every information halves --
+	// and no vertex or edge added or removed: initialize() and the device library keep what depends on the topology
+	for (auto& e : mono) { e->measurement[0] += 0.25; e->measurement[1] -= 0.25; e->information *= 0.5; }
+	for (auto& e : stereo) { e->measurement[0] += 0.25; e->measurement[1] -= 0.25; e->measurement[2] += 0.25; e->information *= 0.5; }
+	ba->initialize();
+	ba->optimize(3);
+	for (const auto& s : ba->batchStatistics()) std::printf("stage3 iter: %2d, chi2: %.6f\n", s.iteration + 1, s.chi2);
 	return 0;
 }

@@ -84,8 +84,14 @@ def _local_ba_flow(g, make_solver, fix_every=3, iters1=5, iters2=10):
     g.stereo_vp, g.stereo_vl, g.stereo_meas, g.stereo_info = (g.stereo_vp[keep_s], g.stereo_vl[keep_s], g.stereo_meas[keep_s],
                                                               g.stereo_info[keep_s])
     fp2 = flatten(g)
-    chi_b = make_solver(fp2, RK_NONE).optimize(iters2)["chi2"]
-    return chi_a, removed, chi_b
+    s2 = make_solver(fp2, RK_NONE)
+    chi_b = s2.optimize(iters2)["chi2"]
+    # stage 3: same graph, new values (every measurement moves by a quarter pixel, every information halves)
+    write_back(g, fp2, *s2.state())
+    g.mono_meas = g.mono_meas + np.array([0.25, -0.25]); g.mono_info = g.mono_info * 0.5
+    g.stereo_meas = g.stereo_meas + np.array([0.25, -0.25, 0.25]); g.stereo_info = g.stereo_info * 0.5
+    chi_c = make_solver(flatten(g), RK_NONE).optimize(3)["chi2"]
+    return chi_a, removed, chi_b, chi_c
 
 
 @pytest.mark.gpu
@@ -103,10 +109,14 @@ def test_local_ba_flow_cpp_api_vs_c_abi_vs_oracle(tmp_path):
     got_a = np.array([float(m) for m in re.findall(r"stage1 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
     got_b = np.array([float(m) for m in re.findall(r"stage2 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
     got_removed = int(re.search(r"removed (\d+) of", out.stdout).group(1))
-    hip_a, hip_removed, hip_b = _local_ba_flow(g, lambda fp, rk: HipSolver(fp, rk))
-    ora_a, ora_removed, ora_b = _local_ba_flow(g, lambda fp, rk: OracleSolver(fp, rk))
+    got_c = np.array([float(m) for m in re.findall(r"stage3 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
+    hip_a, hip_removed, hip_b, hip_c = _local_ba_flow(g, lambda fp, rk: HipSolver(fp, rk))
+    ora_a, ora_removed, ora_b, ora_c = _local_ba_flow(g, lambda fp, rk: OracleSolver(fp, rk))
     assert got_removed == hip_removed == ora_removed and got_removed > 100
     assert len(got_a) == len(hip_a) and np.all(np.abs(got_a - hip_a) <= 1e-9 * hip_a)      # C++ API == C ABI path (bitwise in practice)
     assert len(got_b) == len(hip_b) and np.all(np.abs(got_b - hip_b) <= 1e-9 * hip_b)
     assert np.all(np.abs(hip_a - ora_a) <= 1e-6 * ora_a) and np.all(np.abs(hip_b - ora_b) <= 1e-6 * ora_b)   # vs exact-solve oracle
+    # stage 3 re-initialises an unchanged topology with new values: the cached paths of the C++ layer and of set_graph
+    # must give what fresh solvers give
+    assert len(got_c) == 3 and np.all(np.abs(got_c - hip_c) <= 1e-9 * hip_c) and np.all(np.abs(hip_c - ora_c) <= 1e-6 * ora_c)
     assert got_b[-1] < 0.5 * got_a[-1]                  # the outliers carried most of the robust objective
