@@ -1115,6 +1115,7 @@ struct cuba_hip_solver
 			}
 			if (chi2Out) chi2Out[it] = F;
 			done = it + 1;
+			(void)hipStreamQuery(stream);      // non-blocking; the ticket waits never enter the runtime, this lets it retire finished commands
 			if (qn == maxq || rho <= 0 || !std::isfinite(lam)) break;
 		}
 		lambda = lam;
