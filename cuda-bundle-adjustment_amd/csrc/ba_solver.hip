@@ -674,6 +674,7 @@ struct cuba_hip_solver
 			for (int c = 0; c <= maxCnt; c++) start[c + 1] += start[c];
 			odBlocks.resize(start[maxCnt + 1]);
 			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) odBlocks[start[maxCnt - c]++] = k; }
+			if (std::getenv("CUBA_HIP_BLOCK_ORDER_ROW")) { odBlocks.clear(); for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k); }   // A/B: row order (measured slower: 174 vs 135 us at KITTI-00, the long lists must start first)
 		}
 		lap("structure: product lists");
 		// per free pose: its edges inside this handle's landmark range (a contiguous run of the global list)
