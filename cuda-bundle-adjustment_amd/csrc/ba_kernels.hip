@@ -1906,13 +1906,13 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 				for (int m = 0; m < QV; m++) s2 += h0 + m < h1 ? qv[m] : Scalar(0);
 			}
 			else s1 = rcin[jc];
-			for (int gq = h0 + (jc == t ? QV : 0); gq < h1; gq += 8)
+			for (int gq = h0 + (jc == t ? QV : 0); gq < h1; gq += QV)      // further unknowns of this thread (large graphs): QV loads per trip
 			{
-				Scalar q8[8];
+				Scalar qx[QV];
 #pragma unroll
-				for (int m = 0; m < 8; m++) q8[m] = gq + m < h1 ? sys.qpart[CD * (size_t)(gq + m) + rem] : Scalar(0);
+				for (int m = 0; m < QV; m++) qx[m] = sys.qpart[CD * (size_t)min(gq + m, h1 - 1) + rem];
 #pragma unroll
-				for (int m = 0; m < 8; m++) s2 += q8[m];
+				for (int m = 0; m < QV; m++) s2 += gq + m < h1 ? qx[m] : Scalar(0);
 			}
 		}
 		else
