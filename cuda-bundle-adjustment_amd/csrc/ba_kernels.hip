@@ -1512,7 +1512,13 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 #pragma unroll
 		for (int w = 0; w < ROWS; w++)
 			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
-		if (sys.qpart) sys.qpart[6 * sys.cl * (size_t)blockIdx.x + threadIdx.x] = s2;
+		if (sys.qpart && sys.agg > 0)
+		{
+			// layout [m][coarse unknown], m = position of this workgroup inside its aggregate: the two-level kernel then reads
+			// consecutive addresses across a wave for every m
+			const int per = sys.agg / ROWS, J = blockIdx.x / per, m = blockIdx.x - J * per;
+			sys.qpart[(size_t)m * (6 * sys.cl * sys.nc) + 6 * sys.cl * J + threadIdx.x] = s2;
+		}
 	}
 	if (threadIdx.x == 64)
 	{
@@ -1824,7 +1830,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const int own0 = 6 * I * sys.agg;
 	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
 	const int per = sys.agg / sys.spmv_rows;             // SpMV workgroups per aggregate
-	const int J = t / CD, cc = t - CD * J;               // first (usually only) coarse unknown of this thread: aggregate, 6 a + c
+	const int J = t / CD;                               // aggregate of the first (usually only) coarse unknown of this thread
 	const int g0 = J * per, g1 = min(sys.npq, g0 + per);
 	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
 	Scalar pre_r = 0, pre_q = 0, pre_p = 0, pre_x = 0, pre_m[6] = { 0, 0, 0, 0, 0, 0 };   // own rows
@@ -1862,7 +1868,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			// compiler merge registers after each one and wait for it
 #pragma unroll
 			for (int m = 0; m < QV; m++)
-				if (m < per) qv[m] = sys.qpart[CD * (size_t)max(0, min(g0 + m, g1 - 1)) + cc];      // (m < per is uniform over the grid)
+				if (m < per) qv[m] = sys.qpart[(size_t)max(0, min(m, g1 - g0 - 1)) * Nc + t];      // (m < per is uniform over the grid)
 		}
 	}
 #pragma unroll
@@ -1910,7 +1916,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			{
 				Scalar qx[QV];
 #pragma unroll
-				for (int m = 0; m < QV; m++) qx[m] = sys.qpart[CD * (size_t)min(gq + m, h1 - 1) + rem];
+				for (int m = 0; m < QV; m++) qx[m] = sys.qpart[(size_t)min(gq + m - h0, h1 - h0 - 1) * Nc + jc];
 #pragma unroll
 				for (int m = 0; m < QV; m++) s2 += gq + m < h1 ? qx[m] : Scalar(0);
 			}

@@ -109,8 +109,9 @@ struct DeviceSystem
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
 	Scalar* hrow = nullptr;    // [36 * 20 * ell_m * Pf] row-ordered copy of Hsc for the SpMV (launch_hsc_expand), entry (row, m, slot)
 	int spmv_rows = 2;         // block rows per SpMV workgroup
-	Scalar* qpart = nullptr;   // [6*cl*npq] (weighted) sums of q = A p over the block rows of each SpMV workgroup (P^T q is
-	                           // summed from these: aggregates are whole multiples of spmv_rows rows)
+	Scalar* qpart = nullptr;   // [agg/spmv_rows][6*cl*nc] (weighted) sums of q = A p over the block rows of each SpMV workgroup,
+	                           // indexed by the workgroup's position inside its aggregate (P^T q is summed from these:
+	                           // aggregates are whole multiples of spmv_rows rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
 };
 
