@@ -41,6 +41,20 @@ int main()
 	REQUIRE(ba->chiSquared(&m2) == 0.0);     // inactive edge (both ends fixed)
 	REQUIRE(ba->batchStatistics().empty());
 
+	// re-initialisation: nothing changed -> same indices (the cached path); a vertex that becomes fixed without any edge
+	// or vertex being added or removed must still be re-indexed (free before fixed)
+	ba->initialize();
+	REQUIRE(p5.iP == 0 && p7.iP == 1 && p3.iP == 2 && l20.iL == 0 && l30.iL == 1 && l10.iL == 2);
+	p5.fixed = true;
+	ba->initialize();
+	REQUIRE(p7.iP == 0 && p3.iP == 1 && p5.iP == 2);
+	l30.fixed = true;                        // s2 (p5 - l30) now has both ends fixed: inactive, reports 0
+	ba->initialize();
+	REQUIRE(l20.iL == 0 && l10.iL == 1 && l30.iL == 2 && ba->chiSquared(&s2) == 0.0);
+	p5.fixed = false; l30.fixed = false;
+	ba->initialize();
+	REQUIRE(p5.iP == 0 && p7.iP == 1 && p3.iP == 2 && l20.iL == 0 && l30.iL == 1 && l10.iL == 2);
+
 	ba->removeEdge(&s3);
 	REQUIRE(ba->nedges() == 4 && p7.edges.size() == 1 && l30.edges.size() == 1);
 	ba->removePoseVertex(&p7);               // removes its remaining edge m1 too (no iteration-while-erasing UB)
