@@ -60,8 +60,14 @@ for it in ((3, 6, 9) if len(sys.argv) < 3 else [int(a) for a in sys.argv[2].spli
     A, b = system(it)
     Dinv = np.linalg.inv(np.stack([A[6*j:6*j+6, 6*j:6*j+6].toarray() for j in range(P)]))
     jac = lambda r: np.einsum("nij,nj->ni", Dinv, r.reshape(P, 6)).ravel()
+    Dblk = sp.block_diag([Dinv[j] for j in range(P)], format="csr")
     for name, Pm in spaces():
-        Ac = (Pm.T @ A @ Pm).toarray()
-        Aci = np.linalg.inv(Ac)
-        k = pcg(A, b, lambda r: jac(r) + Pm @ (Aci @ (Pm.T @ r)))
-        print(f"LM iteration {it}: {name:42s} coarse dim {Ac.shape[0]:5d}  iterations {k}", flush=True)
+        variants = [(name, Pm)]
+        if "constant + linear, 24" in name or "constant + linear, 32" in name:
+            for om in (0.3, 0.6):       # smoothed prolongator (smoothed aggregation): P_s = (I - omega D^-1 A) P -- costs two more SpMVs per iteration
+                variants.append((name + f", smoothed omega={om}", (Pm - om * (Dblk @ (A @ Pm))).tocsr()))
+        for nm, Pv in variants:
+            Ac = (Pv.T @ A @ Pv).toarray()
+            Aci = np.linalg.inv(Ac)
+            k = pcg(A, b, lambda r: jac(r) + Pv @ (Aci @ (Pv.T @ r)))
+            print(f"LM iteration {it}: {nm:62s} coarse dim {Ac.shape[0]:5d}  iterations {k}", flush=True)
