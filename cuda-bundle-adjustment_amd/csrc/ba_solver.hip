@@ -679,8 +679,8 @@ struct cuba_hip_solver
 		lap("structure: product lists");
 		// per free pose: its edges inside this handle's landmark range (a contiguous run of the global list)
 		std::vector<int> pePtr(Pf + 1, 0), peEdge;
-		if (g.e_begin == 0 && g.e_end == E) { pePtr = peAllPtr; peEdge = peAll; }
-		else
+		const bool wholeGraph = g.e_begin == 0 && g.e_end == E;      // then the global lists are the lists (no copy)
+		if (!wholeGraph)
 		{
 			for (int i = g.e_begin; i < g.e_end; i++) if (h_epose[i] < Pf) pePtr[h_epose[i] + 1]++;
 			for (int i = 0; i < Pf; i++) pePtr[i + 1] += pePtr[i];
@@ -734,7 +734,7 @@ struct cuba_hip_solver
 			d_ell.upload(ell, stream);
 		}
 		d_blkrow.upload(blkRow, stream); d_odBlocks.upload(odBlocks, stream); d_prodPtr.upload(prodPtr, stream);
-		d_prodEa.upload(prodEa, stream); d_prodEb.upload(prodEb, stream); d_pePtr.upload(pePtr, stream); d_peEdge.upload(peEdge, stream);
+		d_prodEa.upload(prodEa, stream); d_prodEb.upload(prodEb, stream); d_pePtr.upload(wholeGraph ? peAllPtr : pePtr, stream); d_peEdge.upload(wholeGraph ? peAll : peEdge, stream);
 		d_erec.resize((size_t)8 * E);
 
 		d_red.resize((size_t)36 * nblk + (size_t)12 * Pf);
