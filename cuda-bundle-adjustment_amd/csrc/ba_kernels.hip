@@ -1337,11 +1337,12 @@ __device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int m
 	return on;
 }
 
-// A(k): p_k = z_k + beta p_{k-1} (recomputed on the fly for the neighbour rows), q = A p_k, pq[k] += p.q
-// Latency structure: everything that does not need the reduction scalars is issued first -- A p_k is formed as
-// A z_k + beta A p_{k-1} from two accumulators, so beta (and the stop test) are only needed after the last FMA and
-// their loads (slots written by atomics of the previous kernel => memory-side latency) overlap the matrix sweep.
-// k's parity equals the parity of the chunk-local argument (chunks are even), so the p ping-pong needs no load either.
+// A(k): p_k = z_k + beta p_{k-1} (recomputed on the fly for the neighbour rows), q = A p_k, pq slot k = p.q partials.
+// A p_k is formed as A z_k + beta A p_{k-1} from two accumulators, so beta enters only after the last FMA.  The kernel has
+// two memory round trips: (1) the fixed-width index rows and the reduction partials (addresses known at launch: slots
+// depend on the chunk-local k & 3), (2) all operands of the row in one batch.  k's parity equals the parity of the
+// chunk-local argument (chunk lengths are multiples of 4), so the p ping-pong needs no load either.
+// spmv_entry: rows wider than the fixed-width part read their remaining entries from the upper-triangular storage.
 __device__ __forceinline__ void spmv_entry(const DeviceStructure& st, const DeviceSystem& sys, const Scalar* pold, int a, int rr,
 	Scalar& accz, Scalar& accp)
 {

@@ -96,7 +96,7 @@ struct DeviceSystem
 	int* host_flags = nullptr; // device-mapped host ints: {fail, iterations done, stop flag, ticket}, refreshed by the last node of every
 	                           // iteration graph and by launch_pcg_report
 	int* ticket = nullptr;     // device counter of those reports
-	int* kbase = nullptr;      // iteration offset added to the k / kOut kernel arguments (lets one captured hipGraph
+	int* kbase = nullptr;      // iteration offset added to the k / kOut kernel arguments (lets one hipGraph
 	                           // of `chunk` iterations be replayed: the graph's last node advances it by `chunk`)
 	// two-level preconditioner: aggregates of `agg` consecutive free poses, 6 coarse dof each
 	int agg = 0;               // 0 = block-Jacobi only

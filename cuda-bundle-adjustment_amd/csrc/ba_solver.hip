@@ -138,12 +138,13 @@ struct cuba_hip_solver
 	DeviceStructure st;
 	DeviceSystem sys;
 
-	// one captured hipGraph = `pcgGraphChunk` PCG iterations (kernel arguments are chunk-local, the device-side
+	// one hipGraph = `chunk` PCG iterations (kernel arguments are chunk-local, the device-side
 	// kbase counter supplies the offset): replaying it costs one host call instead of 2-3 launches per iteration
-	// (graphs are kept per chunk length: 4, 8, 16, 32 and whatever pcg_check_every asks for)
-	std::map<std::pair<int, const Scalar*>, hipGraphExec_t> pcgGraphs;   // key: chunk length, coarse inverse the kernels read
+	// (graphs are kept per chunk length -- 4, 8, ..., 256 and whatever pcg_check_every asks for --, with and without the
+	// report to the host in the last node)
+	std::map<std::pair<int, const Scalar*>, hipGraphExec_t> pcgGraphs;   // key: +-chunk length (negative = reporting), coarse inverse the kernels read
 	bool useGraph = true;
-	hipStream_t captureStream = nullptr;   // private stream used only to record graphs (the work stream may be the
+	hipStream_t captureStream = nullptr;   // private stream used only by time_kernels to record timing graphs (the work stream may be the
 	                                       // legacy default stream, which cannot be captured)
 	hipStream_t capStream()
 	{
