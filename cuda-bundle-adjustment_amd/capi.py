@@ -92,6 +92,7 @@ def load_library(precision="f64"):
         "cuba_hip_get_profile": [H, _dp],
         "cuba_hip_get_counters": [H, C.POINTER(C.c_int64)],
         "cuba_hip_get_hsc_structure": [H, _ip, _ip, C.POINTER(C.c_int)],
+        "cuba_hip_get_pcg_history": [H, _ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
         "cuba_hip_get_array": [H, C.c_int, _dp, C.POINTER(C.c_size_t)],
         "cuba_hip_time_kernels": [H, C.c_int, _dp],
         "cuba_hip_set_partition": [H, C.c_int, C.c_int],
@@ -251,6 +252,14 @@ class HipSolver:
         self._ck(self.lib.cuba_hip_get_counters(self.h, c))
         return dict(pcg_iterations=int(c[0]), lm_trials=int(c[1]), hsc_blocks=int(c[2]), schur_products=int(c[3]),
                     coarse_refreshes=int(c[4]), pcg_host_looks=int(c[5]), pcg_iterations_enqueued=int(c[6]), coarse_dim=int(c[7]))
+
+    def pcg_history(self):
+        """(iterations per reduced solve since set_graph [negative = stopped at max_iter], number of unconverged solves)."""
+        n, bad = C.c_int(), C.c_int64()
+        self._ck(self.lib.cuba_hip_get_pcg_history(self.h, None, 0, C.byref(n), C.byref(bad)))
+        it = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._ck(self.lib.cuba_hip_get_pcg_history(self.h, it.ctypes.data_as(_ip), n.value, C.byref(n), C.byref(bad)))
+        return it[:n.value], int(bad.value)
 
     def array(self, name):
         n = C.c_size_t()

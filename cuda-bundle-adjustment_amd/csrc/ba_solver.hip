@@ -133,6 +133,7 @@ struct cuba_hip_solver
 	Scalar* slotsDev = nullptr;   // device-side address of h_pinned
 	int* flagsDev = nullptr;
 	Scalar* hostStage() const { return (Scalar*)((char*)h_pinned + 2048); }
+	Scalar slot(int i) const { return ((const volatile Scalar*)h_pinned)[i]; }   // device-written: never cached in a register across a wait
 
 	DeviceGraph g;
 	DeviceStructure st;
@@ -232,7 +233,9 @@ struct cuba_hip_solver
 	double lambda = 0;
 	int maxIterAlloc = 0;
 	long long nmul = 0;
-	int64_t cntPcgIters = 0, cntTrials = 0, cntCoarseRefresh = 0, cntPcgLooks = 0, cntPcgEnqueued = 0;
+	int64_t cntPcgIters = 0, cntTrials = 0, cntCoarseRefresh = 0, cntPcgLooks = 0, cntPcgEnqueued = 0, cntPcgUnconverged = 0;
+	bool acceptUnconverged = false;   // true: a solve that hits max_iter hands back its best iterate as a success (inexact LM step)
+	std::vector<int> pcgHistory;      // PCG iterations of every reduced solve since set_graph (negative = stopped at max_iter)
 	double prof[CUBA_HIP_PROFILE_ITEMS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 
 	~cuba_hip_solver()
@@ -261,9 +264,16 @@ struct cuba_hip_solver
 			const auto t0 = Clock::now();
 			for (long spins = 0; flags[3] != expectedTicket; spins++)
 				if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(Clock::now() - t0).count() > 2.0) break;   // hung or failed launch: let the runtime say so
-			if (flags[3] == expectedTicket) return;
+			if (flags[3] == expectedTicket)
+			{
+				// the results were written by kernels that precede the ticket write in stream order: order the (non-volatile)
+				// reads of the result slots after the ticket read
+				std::atomic_thread_fence(std::memory_order_acquire);
+				return;
+			}
 		}
 		sync();
+		std::atomic_thread_fence(std::memory_order_acquire);
 		expectedTicket = flags[3];
 	}
 
@@ -353,6 +363,8 @@ struct cuba_hip_solver
 	{
 		if (Pt_ < 0 || Lt_ < 0 || E_ < 0 || Pf_ < 0 || Pf_ > Pt_ || Lf_ < 0 || Lf_ > Lt_) throw ArgError{ "bad vertex counts" };
 		if (Pt_ >= STEREO_BIT) throw ArgError{ "too many poses" };
+		// the per-edge linearisation record carries 2*landmark+stereo in a Scalar slot: exact in fp32 only below 2^24
+		if (sizeof(Scalar) == 4 && Lt_ >= (1 << 23)) throw ArgError{ "fp32 build: at most 2^23 - 1 landmarks" };
 		if ((Pt_ && (!q || !t || !cam)) || (Lt_ && !Xw) || (E_ && (!ep || !el || !edim || !meas || !omega))) throw ArgError{ "null array" };
 		const auto t0 = Clock::now();
 		static const bool noCache = std::getenv("CUBA_HIP_NO_STRUCTURE_CACHE") != nullptr;   // A/B knob for set-up timings
@@ -366,20 +378,23 @@ struct cuba_hip_solver
 			parallelFor(E_, [&](int e) { if (h_inEp[e] != ep[e] || h_inEl[e] != el[e] || h_inDim[e] != edim[e]) diff.store(1, std::memory_order_relaxed); });
 			sameInput = diff == 0;
 		}
-		Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
-		haveStructure = false;
+		// validate BEFORE any member changes: a rejected call must leave the previous graph fully usable
 		if (!sameInput)
 		{
 			std::atomic<int> bad{ 0 };
-			parallelFor(E, [&](int e) {
-				if (ep[e] < 0 || ep[e] >= Pt || el[e] < 0 || el[e] >= Lt) bad.store(1, std::memory_order_relaxed);
+			parallelFor(E_, [&](int e) {
+				if (ep[e] < 0 || ep[e] >= Pt_ || el[e] < 0 || el[e] >= Lt_) bad.store(1, std::memory_order_relaxed);
 				else if (edim[e] != 2 && edim[e] != 3) bad.store(2, std::memory_order_relaxed);
-				else if (ep[e] >= Pf && el[e] >= Lf) bad.store(3, std::memory_order_relaxed);
+				else if (ep[e] >= Pf_ && el[e] >= Lf_) bad.store(3, std::memory_order_relaxed);
 			});
 			if (bad == 1) throw ArgError{ "edge index out of range" };
 			if (bad == 2) throw ArgError{ "edge_dim must be 2 or 3" };
 			if (bad == 3) throw ArgError{ "edge with both ends fixed (must be dropped by the caller)" };
 		}
+		// from here on the old graph is being replaced: a failure below (allocation, upload) leaves NO graph
+		haveGraph = false;
+		haveStructure = false;
+		Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
 		lap(nullptr);
 		if (!sameInput)
 		{
@@ -442,7 +457,9 @@ struct cuba_hip_solver
 		d_perEdge.resize(E);
 		if (!h_pinned)
 		{
-			HIP_TRY(hipHostMalloc((void**)&h_pinned, 4096, hipHostMallocMapped));
+			// Coherent (fine-grained) mapping: the spin-wait protocol below reads device-written results without a stream
+			// synchronisation, which is only defined for coherent host memory (HIP_HOST_COHERENT defaults to 0).
+			HIP_TRY(hipHostMalloc((void**)&h_pinned, 4096, hipHostMallocMapped | hipHostMallocCoherent));
 			std::memset(h_pinned, 0, 4096);
 			void* dev = nullptr;
 			HIP_TRY(hipHostGetDevicePointer(&dev, h_pinned, 0));
@@ -475,7 +492,8 @@ struct cuba_hip_solver
 		haveGraph = true;
 		lambda = 0;
 		for (double& v : prof) v = 0;
-		cntPcgIters = cntTrials = cntCoarseRefresh = cntPcgLooks = cntPcgEnqueued = 0;
+		cntPcgIters = cntTrials = cntCoarseRefresh = cntPcgLooks = cntPcgEnqueued = cntPcgUnconverged = 0;
+		pcgHistory.clear();
 		prof[0] += std::chrono::duration<double>(Clock::now() - t0).count();
 	}
 
@@ -831,7 +849,7 @@ struct cuba_hip_solver
 	{
 		sync();
 		double s = 0;
-		for (int i = 0; i < NSLOT; i++) s += h_pinned[which * NSLOT + i];
+		for (int i = 0; i < NSLOT; i++) s += slot(which * NSLOT + i);
 		return s;
 	}
 
@@ -888,7 +906,7 @@ struct cuba_hip_solver
 		launch_landmark_scale(g, sys, lam, slotsDev + 2 * NSLOT, stream);
 		sync();
 		double a = 0, b = 0;
-		for (int i = 0; i < NSLOT; i++) { b += h_pinned[2 * NSLOT + i]; a += h_pinned[3 * NSLOT + i]; }
+		for (int i = 0; i < NSLOT; i++) { b += slot(2 * NSLOT + i); a += slot(3 * NSLOT + i); }
 		*posePart = a; *lmPart = b;
 	}
 
@@ -1026,7 +1044,21 @@ struct cuba_hip_solver
 		runIters.push_back(itersDone);
 		lastSolveIters = itersDone;
 		if (coarseFresh) itersAtRefresh = itersDone;
-		return true;   // hitting max_iter returns the best iterate, like an inexact LM step
+		pcgHistory.push_back(converged ? itersDone : -itersDone);
+		if (!converged)
+		{
+			// max_iter reached with the stop test still unsatisfied: never silent.  Reported like the reference's
+			// failed factorisation (src/cuda_linear_solver.cpp:406-410 -> CudaBlockSolver::solve returns false ->
+			// the LM loop rejects the trial and raises lambda, which also makes the next system easier), unless the
+			// caller asked for the best iterate ("pcg_accept_unconverged").
+			cntPcgUnconverged++;
+			char buf[160];
+			std::snprintf(buf, sizeof buf, "PCG stopped at max_iter = %d without reaching pcg_tol = %g", maxIter, pcgTol);
+			lastError = buf;
+			coarseValid = false;
+			return acceptUnconverged;
+		}
+		return true;
 	}
 
 	void backSubstitute()
@@ -1134,8 +1166,8 @@ struct cuba_hip_solver
 	void readEvaluate(bool withScale, double* Fhat, double* scale)
 	{
 		waitReport();
-		*Fhat = (double)h_pinned[0];
-		*scale = withScale ? (double)h_pinned[NSLOT] + (double)h_pinned[3 * NSLOT] : 0.0;   // landmark part (back_substitute) + pose part
+		*Fhat = (double)slot(0);
+		*scale = withScale ? (double)slot(NSLOT) + (double)slot(3 * NSLOT) : 0.0;   // landmark part (back_substitute) + pose part
 	}
 	void evaluateTrial(double lam, bool withScale, double* Fhat, double* scale)
 	{
@@ -1151,7 +1183,7 @@ struct cuba_hip_solver
 		launch_pose_scale(g, sys, lam, slotsDev + 3 * NSLOT, stream);
 		sync();
 		double v = 0;
-		for (int i = 0; i < NSLOT; i++) v += h_pinned[NSLOT + i] + h_pinned[3 * NSLOT + i];
+		for (int i = 0; i < NSLOT; i++) v += slot(NSLOT + i) + slot(3 * NSLOT + i);
 		return v;
 	}
 
@@ -1315,6 +1347,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
+		else if (k == "pcg_accept_unconverged") s->acceptUnconverged = value != 0;
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
@@ -1431,6 +1464,16 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t c[8])
 	return guarded(s, [&] {
 		c[0] = s->cntPcgIters; c[1] = s->cntTrials; c[2] = s->st.nblk; c[3] = s->nmul;
 		c[4] = s->cntCoarseRefresh; c[5] = s->cntPcgLooks; c[6] = s->cntPcgEnqueued; c[7] = 6 * (int64_t)s->sys.cl * s->sys.nc;
+	});
+}
+
+int cuba_hip_get_pcg_history(cuba_hip_solver* s, int32_t* iterations, int capacity, int* n_solves, int64_t* n_unconverged)
+{
+	return guarded(s, [&] {
+		const int n = (int)s->pcgHistory.size();
+		if (n_solves) *n_solves = n;
+		if (n_unconverged) *n_unconverged = s->cntPcgUnconverged;
+		if (iterations) for (int i = 0; i < std::min(n, capacity); i++) iterations[i] = s->pcgHistory[i];
 	});
 }
 

@@ -187,6 +187,14 @@ int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITE
    system of the two-level preconditioner. */
 int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
 
+/* PCG iteration count of every reduced solve since cuba_hip_set_graph, oldest first (at most `capacity` are written,
+   *n_solves receives their number); a NEGATIVE entry is a solve that stopped at pcg_max_iter with the stop test
+   unsatisfied, *n_unconverged counts those.  Such a solve is reported as a failure (*ok = 0 from
+   cuba_hip_solve_reduced / cuba_hip_solve; cuba_hip_optimize rejects the trial and raises lambda) -- the role of
+   the reference's "factorize failed" path, src/cuda_linear_solver.cpp:406-410 -- unless the option
+   "pcg_accept_unconverged" = 1 asks for the best iterate to be used as an inexact step. */
+int cuba_hip_get_pcg_history(cuba_hip_solver* s, int32_t* iterations, int capacity, int* n_solves, int64_t* n_unconverged);
+
 /* ---- introspection (parity tests) and multi-GPU plumbing ------------------------------------------ */
 
 /* Structure of the reduced system: upper-triangular BSR (replaces the accessors of

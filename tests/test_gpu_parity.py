@@ -47,8 +47,12 @@ def compare_lm(HipSolver, OracleSolver, fp, rk, iters, tol=CHI2_TOL):
     hip = HipSolver(fp, rk); h = hip.optimize(iters)
     assert len(h["chi2"]) == len(r["chi2"])
     assert rel(h["chi2"], r["chi2"]) < tol and np.all(np.abs(h["chi2"] - r["chi2"]) <= tol * r["chi2"])
-    for a, b in zip(hip.state(), ref.state()):
+    # stated fp64 tolerance on the final estimates at the default pcg_tol (tests/test_gpu_configs.py header):
+    # RMSE over the vertices <= 1e-8 (quaternion coefficients), 1e-6 m (translations, landmarks); worst vertex 1e-5
+    for a, b, lim in zip(hip.state(), ref.state(), (1e-8, 1e-6, 1e-6)):
+        assert np.sqrt(((a - b) ** 2).sum(1).mean()) <= lim if len(a) else True
         assert np.abs(a - b).max() < 1e-5
+    assert hip.pcg_history()[1] == 0                                # every reduced solve met its tolerance
     return hip, ref, h, r
 
 
@@ -347,9 +351,9 @@ def test_kitti00_shape_properties(solvers):
     assert len(res) == 10 and np.all(np.diff(res) < 0)
     ref = OracleSolver(fp, RK_HUBER).optimize(10)["chi2"]
     assert np.all(np.abs(res - ref) <= CHI2_TOL * ref)
-    # determinism up to atomic summation order: a second run from the same start agrees to ~1e-9
+    # no atomics on the default path: a second run from the same start is bit-identical
     h.set_state(q0, t0, X0)
     res2 = h.optimize(10)["chi2"]
-    assert rel(res2, res) < 1e-8
+    assert np.array_equal(res2, res)
     kt = h.time_kernels(5)
     assert all(v > 0 for k, v in kt.items() if k != "pcg_precond")   # merged into pcg_update in the two-level path
