@@ -29,6 +29,24 @@
 #include <set>
 #include <vector>
 
+// Optional OpenMP build (libba_oracle_omp.so, -fopenmp -DORACLE_OMP): the edge / landmark loops run on all host
+// cores the way g2o's G2O_OPENMP build runs its linearisation, with atomic accumulation into shared blocks; the
+// sparse factorisation stays sequential (as g2o's linear solvers are).  Used ONLY for bench.py's all-core CPU
+// baseline -- every parity check uses the single-thread library, whose summation order is fixed.
+#ifdef ORACLE_OMP
+#include <omp.h>
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PARALLEL_FOR ORC_PRAGMA(omp parallel for schedule(static))
+#define ORC_PARALLEL_FOR_DYN ORC_PRAGMA(omp parallel for schedule(dynamic, 256))
+#define ORC_PARALLEL_SUM(v) ORC_PRAGMA(omp parallel for schedule(static) reduction(+ : v))
+#define ORC_ATOMIC ORC_PRAGMA(omp atomic)
+#else
+#define ORC_PARALLEL_FOR
+#define ORC_PARALLEL_FOR_DYN
+#define ORC_PARALLEL_SUM(v)
+#define ORC_ATOMIC
+#endif
+
 namespace {
 
 constexpr int PD = 6;  // pose block dimension     (src/constants.h:26)
@@ -488,6 +506,10 @@ struct Problem
 	std::vector<int> hscRowPtr, hscColInd;
 	std::vector<double> hscVal;
 	std::vector<std::vector<int>> lmEdges;       // per free landmark: edges with a free pose, sorted by pose
+#ifdef ORACLE_OMP
+	std::vector<std::vector<int>> lmAll;         // per landmark: all its edges, ascending edge index (OpenMP build only)
+	std::vector<double> ompHpp, ompBp;           // per-thread pose-side accumulators
+#endif
 	bool structureBuilt = false;
 	BlockCholesky chol;
 	double lambda = 0;
@@ -508,6 +530,10 @@ struct Problem
 		lmEdges.assign(Lf, {});
 		for (int e = 0; e < E; e++)
 			if (eP[e] < Pf && eL[e] < Lf) lmEdges[eL[e]].push_back(e);
+#ifdef ORACLE_OMP
+		lmAll.assign(Lt, {});
+		for (int e = 0; e < E; e++) lmAll[eL[e]].push_back(e);
+#endif
 		std::vector<std::set<int>> cols(Pf);
 		for (int i = 0; i < Pf; i++) cols[i].insert(i);
 		for (int l = 0; l < Lf; l++)
@@ -542,6 +568,7 @@ struct Problem
 	{
 		if (!structureBuilt) buildStructure();
 		double chi = 0;
+		ORC_PARALLEL_SUM(chi)
 		for (int e = 0; e < E; e++)
 		{
 			const int iP = eP[e], iL = eL[e], md = eDim[e];
@@ -581,59 +608,86 @@ struct Problem
 	{
 		std::fill(Hpp.begin(), Hpp.end(), 0.0); std::fill(bp.begin(), bp.end(), 0.0);
 		std::fill(Hll.begin(), Hll.end(), 0.0); std::fill(bl.begin(), bl.end(), 0.0);
+#ifndef ORACLE_OMP
 		std::fill(Hpl.begin(), Hpl.end(), 0.0);
-		for (int e = 0; e < E; e++)
+		for (int e = 0; e < E; e++) accumulateEdge(e, Hpp.data(), bp.data());
+#else
+		// All-core variant: landmarks are spread over the threads (every landmark's Hll / bl / Hpl blocks have a single
+		// writer, edges of a landmark are taken in ascending edge order like the sequential loop), the pose-side sums go
+		// to per-thread copies of Hpp / bp that are added up afterwards.  Hpl blocks of edges with a fixed end are never
+		// written and stay zero from buildStructure().
+		const int T = omp_get_max_threads();
+		const size_t nH = Hpp.size(), nb = bp.size();
+		if (ompHpp.size() != (size_t)T * nH) { ompHpp.assign((size_t)T * nH, 0.0); ompBp.assign((size_t)T * nb, 0.0); }
+		#pragma omp parallel
 		{
-			const int iP = eP[e], iL = eL[e], md = eDim[e];
-			const double* r = &err[3 * e];
-			const double ee = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * omega[e];
-			const double w = omega[e] * robust_weight(rkType[rkOf(e)], rkDelta[rkOf(e)], ee);
-			double JP[18], JL[9];
-			jacobians(&Xc[3 * e], &q[4 * iP], &cam[5 * iP], md, JP, JL);
-			const bool freeP = iP < Pf, freeL = iL < Lf;
-			if (freeP)
+			const int tid = omp_get_thread_num();
+			double* H = &ompHpp[(size_t)tid * nH]; double* b = &ompBp[(size_t)tid * nb];
+			std::fill(H, H + nH, 0.0); std::fill(b, b + nb, 0.0);
+			#pragma omp for schedule(dynamic, 64)
+			for (int l = 0; l < Lt; l++)
+				for (int e : lmAll[l]) accumulateEdge(e, H, b);
+			#pragma omp for schedule(static)
+			for (long i = 0; i < (long)nH; i++) { double s = 0; for (int t2 = 0; t2 < T; t2++) s += ompHpp[(size_t)t2 * nH + i]; Hpp[i] = s; }
+			#pragma omp for schedule(static)
+			for (long i = 0; i < (long)nb; i++) { double s = 0; for (int t2 = 0; t2 < T; t2++) s += ompBp[(size_t)t2 * nb + i]; bp[i] = s; }
+		}
+#endif
+	}
+
+	// one edge's contribution to the normal equations (body of constructQuadraticFormKernel, :788-839); the pose-side
+	// sums go to the arrays passed in (the shared ones, or a thread's private copy in the OpenMP build)
+	void accumulateEdge(int e, double* HppOut, double* bpOut)
+	{
+		const int iP = eP[e], iL = eL[e], md = eDim[e];
+		const double* r = &err[3 * e];
+		const double ee = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * omega[e];
+		const double w = omega[e] * robust_weight(rkType[rkOf(e)], rkDelta[rkOf(e)], ee);
+		double JP[18], JL[9];
+		jacobians(&Xc[3 * e], &q[4 * iP], &cam[5 * iP], md, JP, JL);
+		const bool freeP = iP < Pf, freeL = iL < Lf;
+		if (freeP)
+		{
+			double* H = &HppOut[(size_t)iP * 36];
+			for (int c = 0; c < 6; c++)
 			{
-				double* H = &Hpp[(size_t)iP * 36];
-				for (int c = 0; c < 6; c++)
+				for (int rr = 0; rr < 6; rr++)
 				{
-					for (int rr = 0; rr < 6; rr++)
-					{
-						double s = 0;
-						for (int m = 0; m < md; m++) s += JP[rr * md + m] * JP[c * md + m];
-						H[c * 6 + rr] += w * s;
-					}
 					double s = 0;
-					for (int m = 0; m < md; m++) s += JP[c * md + m] * r[m];
-					bp[(size_t)iP * 6 + c] += w * s;
+					for (int m = 0; m < md; m++) s += JP[rr * md + m] * JP[c * md + m];
+					H[c * 6 + rr] += w * s;
 				}
+				double s = 0;
+				for (int m = 0; m < md; m++) s += JP[c * md + m] * r[m];
+				bpOut[(size_t)iP * 6 + c] += w * s;
 			}
-			if (freeL)
+		}
+		if (freeL)
+		{
+			double* H = &Hll[(size_t)iL * 9];
+			for (int c = 0; c < 3; c++)
 			{
-				double* H = &Hll[(size_t)iL * 9];
-				for (int c = 0; c < 3; c++)
+				for (int rr = 0; rr < 3; rr++)
 				{
-					for (int rr = 0; rr < 3; rr++)
-					{
-						double s = 0;
-						for (int m = 0; m < md; m++) s += JL[rr * md + m] * JL[c * md + m];
-						H[c * 3 + rr] += w * s;
-					}
 					double s = 0;
-					for (int m = 0; m < md; m++) s += JL[c * md + m] * r[m];
-					bl[(size_t)iL * 3 + c] += w * s;
+					for (int m = 0; m < md; m++) s += JL[rr * md + m] * JL[c * md + m];
+					H[c * 3 + rr] += w * s;
 				}
+				double s = 0;
+				for (int m = 0; m < md; m++) s += JL[c * md + m] * r[m];
+				bl[(size_t)iL * 3 + c] += w * s;
 			}
-			if (freeP && freeL)
-			{
-				double* H = &Hpl[(size_t)e * 18];  // 6x3 col-major
-				for (int c = 0; c < 3; c++)
-					for (int rr = 0; rr < 6; rr++)
-					{
-						double s = 0;
-						for (int m = 0; m < md; m++) s += JP[rr * md + m] * JL[c * md + m];
-						H[c * 6 + rr] = w * s;
-					}
-			}
+		}
+		if (freeP && freeL)
+		{
+			double* H = &Hpl[(size_t)e * 18];  // 6x3 col-major
+			for (int c = 0; c < 3; c++)
+				for (int rr = 0; rr < 6; rr++)
+				{
+					double s = 0;
+					for (int m = 0; m < md; m++) s += JP[rr * md + m] * JL[c * md + m];
+					H[c * 6 + rr] = w * s;
+				}
 		}
 	}
 
@@ -680,6 +734,7 @@ struct Problem
 		std::fill(hscVal.begin(), hscVal.end(), 0.0);
 		for (int i = 0; i < Pf; i++)
 			std::memcpy(&hscVal[(size_t)hscFind(i, i) * 36], &Hpp[(size_t)i * 36], 36 * sizeof(double));
+		ORC_PARALLEL_FOR_DYN
 		for (int l = 0; l < Lf; l++)
 		{
 			double* iH = &invHll[(size_t)l * 9];
@@ -693,7 +748,11 @@ struct Problem
 					for (int r = 0; r < 6; r++)
 						W[c * 6 + r] = A[0 * 6 + r] * iH[c * 3 + 0] + A[1 * 6 + r] * iH[c * 3 + 1] + A[2 * 6 + r] * iH[c * 3 + 2];
 				for (int r = 0; r < 6; r++)
-					bsc[(size_t)eP[e] * 6 + r] -= W[0 * 6 + r] * bl[(size_t)l * 3 + 0] + W[1 * 6 + r] * bl[(size_t)l * 3 + 1] + W[2 * 6 + r] * bl[(size_t)l * 3 + 2];
+				{
+					const double d = W[0 * 6 + r] * bl[(size_t)l * 3 + 0] + W[1 * 6 + r] * bl[(size_t)l * 3 + 1] + W[2 * 6 + r] * bl[(size_t)l * 3 + 2];
+					ORC_ATOMIC
+					bsc[(size_t)eP[e] * 6 + r] -= d;
+				}
 			}
 			for (size_t a = 0; a < v.size(); a++)
 				for (size_t b = a; b < v.size(); b++)
@@ -703,7 +762,11 @@ struct Problem
 					double* T = &hscVal[(size_t)hscFind(eP[v[a]], eP[v[b]]) * 36];
 					for (int c = 0; c < 6; c++)
 						for (int r = 0; r < 6; r++)
-							T[c * 6 + r] -= W[0 * 6 + r] * B[0 * 6 + c] + W[1 * 6 + r] * B[1 * 6 + c] + W[2 * 6 + r] * B[2 * 6 + c];
+						{
+							const double d = W[0 * 6 + r] * B[0 * 6 + c] + W[1 * 6 + r] * B[1 * 6 + c] + W[2 * 6 + r] * B[2 * 6 + c];
+							ORC_ATOMIC
+							T[c * 6 + r] -= d;
+						}
 				}
 		}
 	}
@@ -711,6 +774,7 @@ struct Problem
 	// Back-substitution xl = invHll (bl - Hpl^T xp).  schurComplementPostKernel, :1029-1043.
 	void backSubstitute()
 	{
+		ORC_PARALLEL_FOR_DYN
 		for (int l = 0; l < Lf; l++)
 		{
 			double cl[3] = { bl[(size_t)l * 3], bl[(size_t)l * 3 + 1], bl[(size_t)l * 3 + 2] };
@@ -770,6 +834,7 @@ struct Problem
 	void update()
 	{
 		for (int i = 0; i < Pf; i++) pose_update(&xp[(size_t)i * 6], &q[(size_t)i * 4], &t[(size_t)i * 3]);
+		ORC_PARALLEL_FOR
 		for (int i = 0; i < Lf * 3; i++) Xw[i] += xl[i];
 	}
 
@@ -778,7 +843,8 @@ struct Problem
 	{
 		double s = 0;
 		for (size_t i = 0; i < xp.size(); i++) s += xp[i] * (lam * xp[i] + bp[i]);
-		for (size_t i = 0; i < xl.size(); i++) s += xl[i] * (lam * xl[i] + bl[i]);
+		ORC_PARALLEL_SUM(s)
+		for (long i = 0; i < (long)xl.size(); i++) s += xl[i] * (lam * xl[i] + bl[i]);
 		return s;
 	}
 
@@ -842,6 +908,26 @@ struct Problem
 // C ABI (ctypes-friendly).  All matrices column-major, quaternions (x,y,z,w).
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+// threads the OpenMP build will use (1 in the plain build); orc_set_threads(0) = all cores
+int orc_max_threads(void)
+{
+#ifdef ORACLE_OMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+int orc_set_threads(int n)
+{
+#ifdef ORACLE_OMP
+	omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+	return omp_get_max_threads();
+#else
+	(void)n;
+	return 1;
+#endif
+}
 
 void orc_project(const double* q, const double* t, const double* cam, const double* Xw, int mdim, double* Xc, double* proj)
 {

@@ -10,23 +10,28 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libba_oracle.so")
+_LIB_OMP = os.path.join(_HERE, "libba_oracle_omp.so")     # same source with OpenMP edge/landmark loops: CPU-baseline timing only
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
 
-def build(force=False):
+def build(force=False, omp=False):
     src = os.path.join(_HERE, "ba_oracle.cpp")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libba_oracle.so"])
-    return _LIB
+    lib = _LIB_OMP if omp else _LIB
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(lib)])
+    return lib
 
 
 def _d(a):
     return a.ctypes.data_as(_dp)
 
 
-def _load():
-    lib = C.CDLL(build())
+def _load(omp=False):
+    lib = C.CDLL(build(omp=omp))
+    lib.orc_max_threads.restype = C.c_int
+    lib.orc_set_threads.restype = C.c_int
+    lib.orc_set_threads.argtypes = [C.c_int]
     lib.orc_create.restype = C.c_void_p
     lib.orc_create.argtypes = [C.c_int] * 4 + [_dp] * 4 + [C.c_int, _ip, _ip, C.POINTER(C.c_uint8), _dp, _dp]
     for name in ("orc_compute_errors", "orc_max_diagonal"):
@@ -68,6 +73,7 @@ def _load():
 
 
 _lib = None
+_lib_omp = None
 
 
 def lib():
@@ -75,6 +81,14 @@ def lib():
     if _lib is None:
         _lib = _load()
     return _lib
+
+
+def lib_omp():
+    """OpenMP build (timing baseline only; parity checks use lib())."""
+    global _lib_omp
+    if _lib_omp is None:
+        _lib_omp = _load(omp=True)
+    return _lib_omp
 
 
 # ---- unit-level helpers -------------------------------------------------------------------------
@@ -158,9 +172,11 @@ class OracleSolver:
     """Mirror of CudaBlockSolver's stage methods on the CPU oracle; takes a FlatProblem."""
     ARR = dict(Hpp=0, bp=1, Hll=2, bl=3, Hpl=4, bsc=5, xp=6, xl=7, invHll=8, err=9, Xc=10)
 
-    def __init__(self, fp, robust=((0, 0.0), (0, 0.0))):
+    def __init__(self, fp, robust=((0, 0.0), (0, 0.0)), threads=1):
+        """threads = 1: the single-thread checker.  threads = 0 (all cores) or > 1: the OpenMP build, for timing only."""
         self.fp = fp
-        L = lib()
+        self.L = L = lib() if threads == 1 else lib_omp()
+        self.threads = 1 if threads == 1 else L.orc_set_threads(int(threads))
         self._keep = [np.ascontiguousarray(a) for a in (fp.q, fp.t, fp.cam, fp.Xw, fp.eP, fp.eL, fp.eDim, fp.meas, fp.omega)]
         q, t, cam, Xw, eP, eL, eDim, meas, omega = self._keep
         self.h = C.c_void_p(L.orc_create(fp.Pt, fp.Pf, fp.Lt, fp.Lf, _d(q), _d(t), _d(cam), _d(Xw), fp.E,
@@ -171,67 +187,67 @@ class OracleSolver:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_destroy(self.h)
+            self.L.orc_destroy(self.h)
             self.h = None
 
-    def build_structure(self): lib().orc_build_structure(self.h)
-    def compute_errors(self): return lib().orc_compute_errors(self.h)
-    def build_system(self): lib().orc_build_system(self.h)
-    def max_diagonal(self): return lib().orc_max_diagonal(self.h)
-    def set_lambda(self, lam): lib().orc_set_lambda(self.h, float(lam))
-    def restore_diagonal(self): lib().orc_restore_diagonal(self.h)
-    def solve(self): return bool(lib().orc_solve(self.h))
-    def schur(self): lib().orc_schur(self.h)
-    def solve_reduced(self): return bool(lib().orc_solve_reduced(self.h))
-    def back_substitute(self): lib().orc_back_substitute(self.h)
+    def build_structure(self): self.L.orc_build_structure(self.h)
+    def compute_errors(self): return self.L.orc_compute_errors(self.h)
+    def build_system(self): self.L.orc_build_system(self.h)
+    def max_diagonal(self): return self.L.orc_max_diagonal(self.h)
+    def set_lambda(self, lam): self.L.orc_set_lambda(self.h, float(lam))
+    def restore_diagonal(self): self.L.orc_restore_diagonal(self.h)
+    def solve(self): return bool(self.L.orc_solve(self.h))
+    def schur(self): self.L.orc_schur(self.h)
+    def solve_reduced(self): return bool(self.L.orc_solve_reduced(self.h))
+    def back_substitute(self): self.L.orc_back_substitute(self.h)
 
     def set_array(self, name, values):
         ids = dict(self.ARR, hsc=11)
         v = np.ascontiguousarray(values, dtype=np.float64)
-        n = lib().orc_set_array(self.h, ids[name], _d(v))
+        n = self.L.orc_set_array(self.h, ids[name], _d(v))
         assert n == v.size, (name, n, v.size)
 
     def hsc_values_raw(self):
         """Hsc values exactly as stored (col-major 6x6 blocks, flattened)."""
-        nb = lib().orc_hsc_nblocks(self.h)
+        nb = self.L.orc_hsc_nblocks(self.h)
         rp, ci = np.zeros(self.fp.Pf + 1, dtype=np.int32), np.zeros(nb, dtype=np.int32)
         v = np.zeros(nb * 36)
-        lib().orc_get_hsc(self.h, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), _d(v))
+        self.L.orc_get_hsc(self.h, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), _d(v))
         return rp, ci, v
-    def update(self): lib().orc_update(self.h)
-    def compute_scale(self, lam): return lib().orc_compute_scale(self.h, float(lam))
-    def push(self): lib().orc_push(self.h)
-    def pop(self): lib().orc_pop(self.h)
+    def update(self): self.L.orc_update(self.h)
+    def compute_scale(self, lam): return self.L.orc_compute_scale(self.h, float(lam))
+    def push(self): self.L.orc_push(self.h)
+    def pop(self): self.L.orc_pop(self.h)
 
     def optimize(self, niter):
         chi2, lam, trials = np.zeros(niter), np.zeros(niter), np.zeros(niter, dtype=np.int32)
-        n = lib().orc_optimize(self.h, niter, _d(chi2), _d(lam), trials.ctypes.data_as(_ip))
+        n = self.L.orc_optimize(self.h, niter, _d(chi2), _d(lam), trials.ctypes.data_as(_ip))
         return dict(chi2=chi2[:n], lambdas=lam[:n], trials=trials[:n])
 
     def chi_squares(self):
         out = np.zeros(self.fp.E)
-        lib().orc_chi_squares(self.h, _d(out))
+        self.L.orc_chi_squares(self.h, _d(out))
         return out
 
     def state(self):
         q, t, X = np.zeros((self.fp.Pt, 4)), np.zeros((self.fp.Pt, 3)), np.zeros((self.fp.Lt, 3))
-        lib().orc_get_state(self.h, _d(q), _d(t), _d(X))
+        self.L.orc_get_state(self.h, _d(q), _d(t), _d(X))
         return q, t, X
 
     def set_state(self, q, t, X):
         q, t, X = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, t, X))
-        lib().orc_set_state(self.h, _d(q), _d(t), _d(X))
+        self.L.orc_set_state(self.h, _d(q), _d(t), _d(X))
 
     def array(self, name):
-        n = lib().orc_get_array(self.h, self.ARR[name], None)
+        n = self.L.orc_get_array(self.h, self.ARR[name], None)
         out = np.zeros(n)
-        lib().orc_get_array(self.h, self.ARR[name], _d(out))
+        self.L.orc_get_array(self.h, self.ARR[name], _d(out))
         return out
 
     def hsc(self):
         """Upper-triangular BSR of the reduced system: (rowptr, colind, values[nblk,6,6] row-major view)."""
-        nb = lib().orc_hsc_nblocks(self.h)
+        nb = self.L.orc_hsc_nblocks(self.h)
         rp, ci = np.zeros(self.fp.Pf + 1, dtype=np.int32), np.zeros(nb, dtype=np.int32)
         v = np.zeros(nb * 36)
-        lib().orc_get_hsc(self.h, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), _d(v))
+        self.L.orc_get_hsc(self.h, rp.ctypes.data_as(_ip), ci.ctypes.data_as(_ip), _d(v))
         return rp, ci, v.reshape(nb, 6, 6).transpose(0, 2, 1).copy()   # col-major blocks -> [blk][row][col]

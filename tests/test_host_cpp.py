@@ -120,3 +120,32 @@ def test_local_ba_flow_cpp_api_vs_c_abi_vs_oracle(tmp_path):
     # must give what fresh solvers give
     assert len(got_c) == 3 and np.all(np.abs(got_c - hip_c) <= 1e-9 * hip_c) and np.all(np.abs(hip_c - ora_c) <= 1e-6 * ora_c)
     assert got_b[-1] < 0.5 * got_a[-1]                  # the outliers carried most of the robust objective
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["kitti07", "kitti00"])
+def test_cpp_comparison_harness_prints_rmse_within_tolerance(tmp_path, shape):
+    """tests/cpp/compare_with_oracle -- the reference's sample_comparison_with_g2o.cpp protocol and output format with
+    the oracle in g2o's seat: warm-up on both sides, timed initialize + optimize(10), chi2
+    table, RMSE of the estimates.  The harness itself enforces the stated tolerances (exit code); the printed numbers
+    are parsed and asserted again here."""
+    from cuba_amd.synth import synth_named
+    exe = os.path.join(ROOT, "tests", "cpp", "compare_with_oracle")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "all"])
+    path = str(tmp_path / "graph.json")
+    synth_named(shape).to_json(path)
+    out = subprocess.run([exe, path, "10"], capture_output=True, text=True, timeout=900)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = re.findall(r"^\s*(\d+)\|\s*([0-9.]+)\|\s*([0-9.]+)\s*$", out.stdout, re.M)
+    assert len(rows) == 10
+    cpu = np.array([float(r[1]) for r in rows]); gpu = np.array([float(r[2]) for r in rows])
+    assert np.all(np.abs(cpu - gpu) <= 0.11 + 1e-6 * cpu)                      # printed with %.1f
+    rm = {k: float(v) for k, v in re.findall(r"^(Rotation|Translation|Landmark)\s*:\s*([0-9.eE+-]+)", out.stdout, re.M)}
+    assert rm["Rotation"] <= 1e-8 and rm["Translation"] <= 1e-6 and rm["Landmark"] <= 1e-6
+    assert "PASS" in out.stdout
+    if shape == "kitti00":
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "compare_with_oracle_cpp_kitti00.txt"), "w") as f:
+            f.write(out.stdout)
