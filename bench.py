@@ -2,9 +2,20 @@
 """bench.py -- headline benchmark: Levenberg-Marquardt bundle adjustment on a KITTI-00-shaped graph.
 
 A "step" is one LM iteration (linearise + Schur + reduced solve + back-substitution + update +
-re-evaluation) over the whole graph; `value` = edges x steps / wall  (edge-iterations per second, the
-reading under which the reference's README numbers give 4.56 M/s on a GTX 1080 and 0.47 M/s for g2o).
-The stricter reading (edges / wall of a 10-iteration run) is reported next to it.
+re-evaluation) over the whole graph, with the graph resident in HBM; `value` = edges x steps / wall
+(edge-iterations per second, the reading under which the reference's README numbers give 4.56 M/s on a GTX 1080
+and 0.47 M/s for g2o).  Steps are taken as the reference's protocol takes them
+(samples/sample_comparison_with_g2o.cpp:74-79, 303-307): a 1-iteration warm-up moves the estimates, then runs of
+optimize(10) start from that state.
+
+Next to `value` the line carries
+  contract_wall  the SURVEY section 8(d) wall: initialize() + optimize(10) after the 1-iteration warm-up through the
+                 C++ API (host flattening, PCIe upload, structure analysis and write-back inside), for an unchanged
+                 and for a new topology, with E/wall (strict) and E x 10/wall;
+  roofline       the dominant kernel against the 8 TB/s HBM peak, and `roofline.path`: the whole hot path,
+                 B_alg(trial) x trials / t_hot against 8.0 and 6.3 TB/s (SURVEY section 8d);
+  cpu_baseline   the CPU oracle (our g2o-faithful restatement -- "port", not g2o itself) on the host cores:
+                 all cores (OpenMP build) and single thread, nproc printed.
 
 N = 1 : BASELINE.json configs[1] -- ba_kitti_00 shape (1332 poses / 133383 landmarks / 561116 edges,
         synthetic stand-in, seed 0), fp64, Huber kernels as in samples/sample_comparison_with_g2o.cpp:195-200.
@@ -43,7 +54,11 @@ def algorithmic_bytes(fp, nblk, nc):
     }
 
 
-def end_to_end_leg(shape, E):
+def contract_wall_leg(shape, E, runs=5):
+    """wall of initialize() + optimize(10) after a 1-iteration warm-up, through the C++ API
+    (libcuda_bundle_adjustment.so -> C ABI), measured by the sample binary itself exactly where the reference's samples
+    put their clock (samples/sample_comparison_with_g2o.cpp:74-79).  Host flattening, PCIe upload, structure analysis
+    and write-back are inside."""
     import re
     import subprocess
     import tempfile
@@ -51,28 +66,32 @@ def end_to_end_leg(shape, E):
     if not os.path.exists(exe):
         return None
     from cuba_amd.synth import synth_named
-    res = {"protocol": "warm-up initialize()+optimize(1), then wall of initialize()+optimize(10) through libcuda_bundle_adjustment.so"}
+    res = {"protocol": "warm-up initialize()+optimize(1), then wall of initialize()+optimize(10) through the C++ API "
+                       "(sample_ba_from_file); min and median of %d process runs" % runs, "iterations": LM_RUN}
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "graph.json")
         synth_named(shape).to_json(path)
-        for key, env in (("unchanged_topology_ms", {}), ("new_topology_ms", {"CUBA_HIP_NO_STRUCTURE_CACHE": "1"})):
-            best = None
-            for _ in range(3):
-                r = subprocess.run([exe, path, "10", "1"], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+        for key, env in (("unchanged_topology", {}), ("new_topology", {"CUBA_HIP_NO_STRUCTURE_CACHE": "1"})):
+            walls = []
+            for _ in range(runs):
+                r = subprocess.run([exe, path, str(LM_RUN), "1"], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
                 m = re.search(r"BA total\s*:\s*([0-9.eE+-]+)\s*\[sec\]", r.stdout)
                 if r.returncode == 0 and m:
-                    best = float(m.group(1)) if best is None else min(best, float(m.group(1)))
-            res[key] = None if best is None else best * 1e3
-            if best:
-                res[key.replace("_ms", "_edges_per_s_strict")] = E / best
+                    walls.append(float(m.group(1)))
+            if not walls:
+                res[key] = None
+                continue
+            best, med = min(walls), float(np.median(walls))
+            res[key] = {"wall_ms": best * 1e3, "wall_ms_median": med * 1e3, "edges_per_s_strict": E / best,
+                        "edge_iterations_per_s": E * LM_RUN / best}
     return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shape", default="kitti00")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the C++-API leg (the reference's sample protocol)")
@@ -116,6 +135,12 @@ def main():
         backend = HipPartitionBackend(solver, fp, rank, world)
         comm = TorchComm()
     solver.build_structure()
+    # the reference protocol's warm-up: one LM iteration from the initial guess moves the estimates; the timed runs of
+    # optimize(10) start from there (sample_comparison_with_g2o.cpp:303-307)
+    if partitioned:
+        partitioned_optimize(backend, comm, 1)
+    else:
+        solver.optimize(1)
     q0, t0, X0 = solver.state()
 
     def run_steps(k):
@@ -188,12 +213,22 @@ def main():
             found = [find(n) for n in pmc_names[dom]]
             if all(f is not None for f in found):
                 traffic = sum(f["hbm_bytes_fetch_x2"] for f in found)
+        # whole hot path: B_alg(trial) = 120 E3 + 96 E2 + 288 L + 2 * 288 nblk, achieved = B_alg x trials / t_hot.
+        # The PCG's re-reads of the (L2 / Infinity-Cache resident) reduced matrix are deliberately NOT counted as HBM bytes.
+        b_trial = 120 * fp.E3 + 96 * fp.E2 + 288 * fp.Lt + 2 * 288 * nblk
+        path_gbs = b_trial * trials / elapsed / 1e9
+        path = {"B_alg_per_trial": b_trial, "trials": trials, "t_hot_ms": elapsed * 1e3, "GBs": path_gbs,
+                "frac_8.0": path_gbs / 8000.0, "frac_6.3": path_gbs / 6300.0,
+                "pcg_iterations_per_trial": pcg_iters / max(trials, 1),
+                "note": "latency-bound path: ~%d dependent kernel launches per trial, HBM roofline wall of the run would be %.2f ms"
+                        % (round(2 * pcg_iters / max(trials, 1)) + 12, b_trial * trials / 6.3e12 * 1e3)}
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "traffic_source": os.path.basename(pmc_path) if traffic else None,
-                "kernels": kernels}
+                "kernels": kernels, "path": path}
         out = {
-            "metric": "edges/sec (edge-iterations/s = E x LM iterations / wall) on KITTI-00-shaped graph, fp64, chi2 vs g2o-faithful oracle",
+            "metric": "edges/sec (edge-iterations/s = E x LM iterations / wall, graph resident in HBM) + 10-iter LM wall-clock "
+                      "(contract_wall: initialize()+optimize(10) after warm-up, C++ API) on KITTI-00-shaped graph; per-iter chi2 vs g2o-faithful oracle",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if partitioned else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -214,23 +249,35 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import OracleSolver
             n = min(LM_RUN, args.steps)
-            orc = OracleSolver(fp, rk)
-            orc.build_structure()
-            tc = time.perf_counter()
-            ref = orc.optimize(n)
-            tc = time.perf_counter() - tc
+            base = {}
+            ref = None
+            for label, threads in (("single_thread", 1), ("all_cores", 0)):
+                orc = OracleSolver(fp, rk, threads=threads)
+                orc.build_structure()
+                orc.set_state(q0, t0, X0)
+                tc = time.perf_counter()
+                r = orc.optimize(n)
+                tc = time.perf_counter() - tc
+                if threads == 1:
+                    ref = r                       # the single-thread library is the parity checker (fixed summation order)
+                base[label] = {"value": E * len(r["chi2"]) / tc, "unit": "edges/s", "cores": orc.threads, "seconds": tc}
             solver.set_state(q0, t0, X0)
             got = solver.optimize(n)["chi2"]
             m = min(len(got), len(ref["chi2"]))
-            out["cpu_baseline"] = {"value": E * len(ref["chi2"]) / tc, "unit": "edges/s", "cores": 1, "kind": "port",
-                                   "sample": f"same graph, {len(ref['chi2'])} LM iterations, oracle/ba_oracle.cpp single thread, "
-                                             f"{tc:.2f} s (structure analysis excluded, as for the GPU)"}
+            best = max(base.values(), key=lambda b: b["value"])
+            out["cpu_baseline"] = {"value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port",
+                                   "nproc": os.cpu_count(),
+                                   "sample": f"same graph and start as the GPU run, {len(ref['chi2'])} LM iterations of oracle/ba_oracle.cpp "
+                                             "(our g2o-faithful CPU restatement with an exact sparse block Cholesky -- NOT g2o itself, "
+                                             "which is not installable here); all_cores = OpenMP over edges/landmarks with a sequential "
+                                             "factorisation (as g2o's OpenMP build); structure analysis excluded, as for the GPU",
+                                   "single_thread": base["single_thread"], "all_cores": base["all_cores"]}
             out["chi2_max_rel_diff_vs_oracle"] = float(np.max(np.abs(got[:m] - ref["chi2"][:m]) / ref["chi2"][:m]))
         # ---- end-to-end leg (rank 0, N = 1): the reference's own protocol through the C++ API -- warm-up initialize() +
         # optimize(1), then wall of initialize() + optimize(10) with host flattening, upload and write-back inside
         # (samples/sample_comparison_with_g2o.cpp:74-79, 303-307).  Reported next to `value`, never as `value`.
         if world == 1 and not args.no_end_to_end:
-            out["end_to_end"] = end_to_end_leg(args.shape, E)
+            out["contract_wall"] = contract_wall_leg(args.shape, E)
         print(json.dumps(out), flush=True)
     solver.close()
     if dist is not None:
