@@ -251,7 +251,11 @@ def main():
             n = min(LM_RUN, args.steps)
             base = {}
             ref = None
-            for label, threads in (("single_thread", 1), ("all_cores", 0)):
+            # all-core leg: the atomic accumulation into shared Hsc blocks stops scaling (and on a two-socket host turns
+            # negative) long before 256 threads, so a few thread counts are tried and the fastest is the one reported
+            ncpu = os.cpu_count() or 1
+            sweep = sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)} - {1})
+            for label, threads in [("single_thread", 1)] + [("threads_%d" % c, c) for c in sweep]:
                 orc = OracleSolver(fp, rk, threads=threads)
                 orc.build_structure()
                 orc.set_state(q0, t0, X0)
@@ -264,7 +268,10 @@ def main():
             solver.set_state(q0, t0, X0)
             got = solver.optimize(n)["chi2"]
             m = min(len(got), len(ref["chi2"]))
-            best = max(base.values(), key=lambda b: b["value"])
+            multi = {k: v for k, v in base.items() if k != "single_thread"}
+            base["all_cores"] = max(multi.values(), key=lambda b: b["value"]) if multi else base["single_thread"]
+            base["all_cores"]["thread_sweep_edges_per_s"] = {k: v["value"] for k, v in multi.items()}
+            best = max(base["single_thread"], base["all_cores"], key=lambda b: b["value"])
             out["cpu_baseline"] = {"value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port",
                                    "nproc": os.cpu_count(),
                                    "sample": f"same graph and start as the GPU run, {len(ref['chi2'])} LM iterations of oracle/ba_oracle.cpp "

@@ -1800,7 +1800,7 @@ __device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
 
 // CL = coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose index.  Coarse
 // unknown (aggregate J, function a, component c) has index (6 CL) J + 6 a + c.
-template <int CL>
+template <int CL, int AC>
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
@@ -1840,7 +1840,9 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	// the whole coarse vector -- lane l takes the columns l, l + 64, ... -- so that a row costs ONE wave reduction in one
 	// wave (a thread-per-column layout needs CD reductions in every wave plus a cross-wave stage).
 	constexpr int AR = (CD + 7) / 8;   // rows per wave
-	constexpr int AC = 12;             // prefetched column PAIRS per lane and row (coarse dimension <= 1536), the rest is read later
+	// AC = prefetched column PAIRS per lane and row (covers a coarse dimension of 128 AC; the rest is read later): 6 for
+	// coarse dimensions up to 768 (KITTI-00: 672), 12 beyond -- every prefetch slot past the row's end is still a load
+	// instruction on the workgroup's one CU, which is what bounds this kernel
 	Scalar2 ainv[AR][AC];
 #pragma unroll
 	for (int m = 0; m < QV; m++) qv[m] = 0;
@@ -2040,6 +2042,13 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
 }
 
+static void* pcg2_kernel_for(const DeviceSystem& sys)
+{
+	const bool small = 6 * sys.cl * sys.nc <= 768;
+	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6> : (void*)pcg2_fused_kernel<2, 12>;
+	return small ? (void*)pcg2_fused_kernel<1, 6> : (void*)pcg2_fused_kernel<1, 12>;
+}
+
 static size_t pcg2_lds_bytes(const DeviceSystem& sys)
 {
 	const size_t cd = 6 * (size_t)sys.cl;
@@ -2049,18 +2058,18 @@ static size_t pcg2_lds_bytes(const DeviceSystem& sys)
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
 {
 	const size_t lds = pcg2_lds_bytes(sys);
-	if (sys.cl == 2) hipLaunchKernelGGL(pcg2_fused_kernel<2>, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
-	else hipLaunchKernelGGL(pcg2_fused_kernel<1>, dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
 static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
 int spmv_rows_for(int Pf)
 {
-	if (const char* e = std::getenv("CUBA_HIP_SPMV_ROWS")) return std::atoi(e) == 4 ? 4 : 2;     // A/B knob
+	if (const char* e = std::getenv("CUBA_HIP_SPMV_ROWS")) { const int r = std::atoi(e); return r == 8 ? 8 : r == 4 ? 4 : 2; }     // A/B knob
 	return 2 * (long long)Pf > 3 * 1024 ? 4 : 2;
 }                            // (the 4-row workgroup needs the 128-VGPR instantiation)
 static void* spmv_kernel_for(const DeviceGraph& g, const DeviceSystem& sys)
 {
+	if (sys.spmv_rows == 8) return (void*)pcg_spmv_kernel<8, 1>;
 	if (sys.spmv_rows == 4) return (void*)pcg_spmv_kernel<4, 4>;
 	return spmv_wants_occupancy(g) ? (void*)pcg_spmv_kernel<2, 4> : (void*)pcg_spmv_kernel<2, 1>;
 }
@@ -2131,7 +2140,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{
-			e = add_kernel_node(graph, last, sys.cl == 2 ? (void*)pcg2_fused_kernel<2> : (void*)pcg2_fused_kernel<1>, dim3(sys.nc), dim3(PCG2_T),
+			e = add_kernel_node(graph, last, pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T),
 				(unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
 		}
 		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);

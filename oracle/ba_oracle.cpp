@@ -37,7 +37,7 @@
 #include <omp.h>
 #define ORC_PRAGMA(x) _Pragma(#x)
 #define ORC_PARALLEL_FOR ORC_PRAGMA(omp parallel for schedule(static))
-#define ORC_PARALLEL_FOR_DYN ORC_PRAGMA(omp parallel for schedule(dynamic, 256))
+#define ORC_PARALLEL_FOR_DYN ORC_PRAGMA(omp parallel for schedule(static))   /* contiguous landmark ranges per thread: neighbouring landmarks share Hsc blocks */
 #define ORC_PARALLEL_SUM(v) ORC_PRAGMA(omp parallel for schedule(static) reduction(+ : v))
 #define ORC_ATOMIC ORC_PRAGMA(omp atomic)
 #else

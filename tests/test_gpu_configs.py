@@ -292,8 +292,7 @@ def test_duplicate_observations_of_one_pose(solvers):
                 j = ci[k]
                 blk = S[6 * i:6 * i + 6, 6 * j:6 * j + 6].copy()
                 got = v[k].copy()
-                if i == j:
-                    got[np.diag_indices(6)] += lam                    # HIP adds lambda in the PCG set-up
+                if i == j:                                             # (the PCG set-up of solve() has already added lambda in place)
                     iu = np.triu_indices(6)
                     assert np.abs(got[iu] - blk[iu]).max() <= 1e-9 * md
                 else:
