@@ -129,11 +129,22 @@ def main():
     seed = SHAPES[args.shape]["seed"] if (world == 1 or partitioned) else 100 + rank
     fp = flatten(synth_named(args.shape, seed=seed))
     solver = HipSolver(fp, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
-    backend = comm = None
+    comm = None
+    native = None
     if partitioned:
-        from cuba_amd.dist import HipPartitionBackend, TorchComm, partitioned_optimize
-        backend = HipPartitionBackend(solver, fp, rank, world)
-        comm = TorchComm()
+        # native driver (libcuba_hip_dist.so): the LM loop in C++, RCCL collectives on the solver's stream; its communicator
+        # is created from a unique id that rank 0 hands out through the torch process group.  CUBA_BENCH_BACKEND=gloo (dry
+        # runs on a box with fewer GPUs than ranks) uses the torch group for the collectives instead.
+        from cuba_amd.dist import NativeDist, TorchComm, rccl_unique_id
+        if backend == "nccl":
+            ids = [rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            native = NativeDist(solver, fp, rank, world, unique_id=ids[0])
+        else:
+            native = NativeDist(solver, fp, rank, world, comm=TorchComm())
+
+        def partitioned_optimize(_backend, _comm, n):
+            return native.optimize(n)
     solver.build_structure()
     # the reference protocol's warm-up: one LM iteration from the initial guess moves the estimates; the timed runs of
     # optimize(10) start from there (sample_comparison_with_g2o.cpp:303-307)

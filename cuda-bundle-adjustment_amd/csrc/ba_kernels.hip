@@ -2098,6 +2098,18 @@ __global__ void pcg_advance_kernel(DeviceSystem sys, int n, int report)
 	}
 }
 
+// {chi2, landmark part of the gain-ratio denominator, pose part} of the evaluation just enqueued -> three device scalars
+// (the multi-GPU driver all-reduces the first two in-stream instead of reading them back rank by rank)
+__global__ void collect_eval_kernel(const Scalar* slots, Scalar* out)
+{
+	if (threadIdx.x == 0) { out[0] = slots[0]; out[1] = slots[NSLOT]; out[2] = slots[3 * NSLOT]; }
+}
+
+void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s)
+{
+	hipLaunchKernelGGL(collect_eval_kernel, dim3(1), dim3(64), 0, s, sys.slots, out3);
+}
+
 void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
 {
 	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, 0, 1);

@@ -120,6 +120,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
+	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
 	DevBuf<Scalar> d_coarse[3], d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
@@ -1555,6 +1556,32 @@ int cuba_hip_device_pointer(cuba_hip_solver* s, int which, void** device_ptr, si
 		}
 		if (device_ptr) *device_ptr = p;
 		if (count) *count = n;
+	});
+}
+
+int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5])
+{
+	return guarded(s, [&] {
+		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		sizes[0] = s->Pt; sizes[1] = s->Pf; sizes[2] = s->Lt; sizes[3] = s->Lf; sizes[4] = s->E;
+	});
+}
+
+int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream)
+{
+	return guarded(s, [&] { if (!hip_stream) throw ArgError{ "null output" }; *hip_stream = (void*)s->stream; });
+}
+
+int cuba_hip_evaluate_device(cuba_hip_solver* s, double lambda, int with_scale, void** device_scalars3)
+{
+	return guarded(s, [&] {
+		s->need();
+		if (!device_scalars3) throw ArgError{ "null output" };
+		s->d_eval.resize(4);
+		launch_residual_chi2(s->g, s->d_parts.data(), s->slotsDev, nullptr, s->stream);
+		if (with_scale) launch_pose_scale(s->g, s->sys, lambda, s->slotsDev + 3 * NSLOT, s->stream);
+		launch_collect_eval(s->sys, s->d_eval.data(), s->stream);
+		*device_scalars3 = s->d_eval.data();
 	});
 }
 

@@ -70,6 +70,13 @@ class TorchComm:
             self._unstage(a, t)
         return a
 
+    def allreduce_max_(self, a):
+        t, back = self._stage(a)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        if back:
+            self._unstage(a, t)
+        return a
+
     def bcast_(self, a, root=0):
         t, back = self._stage(a)
         self.dist.broadcast(t, src=root, group=self.group)
@@ -133,6 +140,26 @@ class ThreadComm:
         self.s.barrier.wait()
         if self.rank != root:
             src = self.s.slots[root]
+            if isinstance(a, np.ndarray):
+                a[...] = src
+            else:
+                a.copy_(src)
+        self.s.barrier.wait()
+        return a
+
+    def allreduce_max_(self, a):
+        self.s.slots[self.rank] = a
+        self.s.barrier.wait()
+        if self.rank == 0:
+            import torch
+            for other in self.s.slots[1:]:
+                if isinstance(a, np.ndarray):
+                    np.maximum(self.s.slots[0], other, out=self.s.slots[0])
+                else:
+                    torch.maximum(self.s.slots[0], other, out=self.s.slots[0])
+        self.s.barrier.wait()
+        if self.rank != 0:
+            src = self.s.slots[0]
             if isinstance(a, np.ndarray):
                 a[...] = src
             else:
@@ -246,3 +273,121 @@ def partitioned_optimize(backend, comm, niterations, maxq=10, tau=1e-5):
         if q == maxq or rho <= 0 or not np.isfinite(lam):
             break
     return np.array(stats)
+
+
+# ---------------------------------------------------------------------------------------------------
+# native driver (libcuba_hip_dist.so, include/cuba_hip_dist.h): the same loop in C++, RCCL collectives enqueued on the
+# solver's stream.  This class is ctypes plumbing only.
+# ---------------------------------------------------------------------------------------------------
+_dist_libs = {}
+
+
+def load_dist_library(precision="f64"):
+    import ctypes as C
+    import os
+    from . import capi
+    capi.load_library(precision)                     # the solver library (and torch's HIP runtime) first
+    path = os.path.join(capi.CSRC, "libcuba_hip_dist.so" if precision == "f64" else "libcuba_hip_dist_f32.so")
+    if path in _dist_libs:
+        return _dist_libs[path]
+    if not os.path.exists(path):
+        raise capi.CubaHipError(f"{path} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(path)
+    H, D = C.c_void_p, C.c_void_p
+    lib.cuba_hip_dist_unique_id.argtypes = [C.c_void_p]
+    lib.cuba_hip_dist_create_rccl.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
+    lib.cuba_hip_dist_attach_rccl.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
+    lib.cuba_hip_dist_create_custom.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(D)]
+    lib.cuba_hip_dist_optimize.argtypes = [D, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.cuba_hip_dist_complete_solution.argtypes = [D]
+    lib.cuba_hip_dist_get_counters.argtypes = [D, C.POINTER(C.c_longlong)]
+    lib.cuba_hip_dist_destroy.argtypes = [D]
+    lib.cuba_hip_dist_last_error.argtypes = [D]
+    lib.cuba_hip_dist_last_error.restype = C.c_char_p
+    _dist_libs[path] = lib
+    return lib
+
+
+def rccl_unique_id(precision="f64"):
+    """128-byte RCCL unique id (rank 0 makes it, every rank passes it to NativeDist)."""
+    import ctypes as C
+    buf = C.create_string_buffer(128)
+    rc = load_dist_library(precision).cuba_hip_dist_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"cuba_hip_dist_unique_id failed with status {rc}")
+    return bytes(buf.raw)
+
+
+class NativeDist:
+    """Landmark-partitioned LM through the native driver.  Exactly one of `unique_id` (a new RCCL communicator) or `comm`
+    (an object with allreduce_sum_ / allreduce_max_ on torch device tensors: ThreadComm for ranks-as-threads on one GPU,
+    TorchComm for a torch.distributed group) selects the collectives."""
+
+    def __init__(self, solver, fp, rank, world, unique_id=None, comm=None, precision="f64"):
+        import ctypes as C
+        self.lib = load_dist_library(precision)
+        self.solver, self.rank, self.world = solver, rank, world
+        self.range = landmark_ranges(fp.eL, fp.Lt, world)[rank]
+        self.h = C.c_void_p()
+        self._keep = None
+        if (unique_id is None) == (comm is None):
+            raise ValueError("pass either unique_id or comm")
+        if unique_id is not None:
+            buf = C.create_string_buffer(bytes(unique_id), 128)
+            rc = self.lib.cuba_hip_dist_create_rccl(solver.h, buf, rank, world, self.range[0], self.range[1], C.byref(self.h))
+        else:
+            import torch
+            FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+            def make(op):
+                def fn(ctx, buf, count, scalar_size, stream):
+                    try:
+                        torch.cuda.synchronize()                      # everything the solver enqueued so far
+                        t = torch.as_tensor(_DeviceArray(buf, count, scalar_size), device="cuda")
+                        getattr(comm, op)(t)
+                        torch.cuda.synchronize()
+                        return 0
+                    except Exception:                                 # pragma: no cover
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                return FN(fn)
+
+            class Ops(C.Structure):
+                _fields_ = [("ctx", C.c_void_p), ("allreduce_sum", FN), ("allreduce_max", FN)]
+            cb_sum, cb_max = make("allreduce_sum_"), make("allreduce_max_")
+            ops = Ops(None, cb_sum, cb_max)
+            self._keep = (cb_sum, cb_max, ops)                       # the C side calls these for the driver's lifetime
+            rc = self.lib.cuba_hip_dist_create_custom(solver.h, C.byref(ops), rank, world, self.range[0], self.range[1], C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise RuntimeError(f"native multi-GPU driver: create failed with status {rc} ({solver.lib.cuba_hip_last_error(solver.h).decode()})")
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"native multi-GPU driver: status {rc}: {self.lib.cuba_hip_dist_last_error(self.h).decode()}")
+
+    def optimize(self, niter):
+        import ctypes as C
+        chi2 = np.zeros(max(niter, 1))
+        n = C.c_int()
+        self._ck(self.lib.cuba_hip_dist_optimize(self.h, int(niter), chi2.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)))
+        return chi2[:n.value]
+
+    def complete_solution(self):
+        """Afterwards solver.state() is the full solution on every rank."""
+        self._ck(self.lib.cuba_hip_dist_complete_solution(self.h))
+        return self.solver.state()
+
+    def counters(self):
+        import ctypes as C
+        c = (C.c_longlong * 4)()
+        self._ck(self.lib.cuba_hip_dist_get_counters(self.h, c))
+        return dict(large_allreduces=int(c[0]), small_allreduces=int(c[1]), large_elements=int(c[2]), lm_trials=int(c[3]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cuba_hip_dist_destroy(self.h)
+            self.h = None
+
+    __del__ = close

@@ -229,6 +229,18 @@ int cuba_hip_compute_scale_parts(cuba_hip_solver* s, double lambda, double* pose
 /* Device address of an internal array (ids as for cuba_hip_get_array) for zero-copy collectives. */
 int cuba_hip_device_pointer(cuba_hip_solver* s, int which, void** device_ptr, size_t* count);
 
+/* {Pt, Pf, Lt, Lf, E} of the uploaded graph. */
+int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5]);
+
+/* The HIP stream the handle enqueues on (a collective library must order its operations with the solver's kernels). */
+int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream);
+
+/* Enqueue (no host synchronisation) the evaluation of the current estimate over this handle's landmark range and leave
+   three device scalars (element size cuba_hip_scalar_size()) at *device_scalars3:
+     [0] robust chi2 of the local edges, [1] landmark part of sum x (lambda x + b) from the last cuba_hip_back_substitute,
+     [2] pose part (only if with_scale != 0).  A multi-GPU driver sums [0..1] over the ranks in-stream. */
+int cuba_hip_evaluate_device(cuba_hip_solver* s, double lambda, int with_scale, void** device_scalars3);
+
 /* Device address + length (in doubles) of the contiguous buffer [Hsc values | bsc | bp] that a
    landmark-partitioned multi-GPU driver must sum across ranks between cuba_hip_schur and
    cuba_hip_solve_reduced (RCCL all-reduce over xGMI; no equivalent in the single-GPU reference). */

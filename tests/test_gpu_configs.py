@@ -120,10 +120,10 @@ def test_float32_variant_at_size(solvers, name):
 
 
 def test_g4m_eight_emulated_ranks(solvers):
-    """BASELINE configs[4] on one device: 8 solver handles act as the 8 ranks of the landmark-partitioned mode
-    (in-process communicator) and must reproduce the single-handle / oracle trajectory."""
+    """BASELINE configs[4] on one device: 8 solver handles + 8 native drivers (cuba_hip_dist_optimize) act as the 8 ranks
+    of the landmark-partitioned mode (in-process communicator instead of RCCL) and must reproduce the oracle trajectory."""
     import threading
-    from cuba_amd.dist import HipPartitionBackend, ThreadComm, partitioned_optimize
+    from cuba_amd.dist import NativeDist, ThreadComm
     HipSolver, _ = solvers
     fp, ref_chi2, ref_state = named_case("g4m")
     world, iters = 8, 4
@@ -132,19 +132,18 @@ def test_g4m_eight_emulated_ranks(solvers):
 
     def work(c):
         try:
-            be = HipPartitionBackend(HipSolver(fp, RK_HUBER), fp, c.rank, world)
-            chi2 = partitioned_optimize(be, c, iters)
-            out[c.rank] = (chi2, be.gather_solution(c) if c.rank == 0 else None)
-            if c.rank != 0:
-                be.gather_solution(c)
+            d = NativeDist(HipSolver(fp, RK_HUBER), fp, c.rank, world, comm=c)
+            out[c.rank] = (d.optimize(iters), d.counters())
+            d.close()
         except Exception as e:   # pragma: no cover
             err.append(e)
             c.s.barrier.abort()
     th = [threading.Thread(target=work, args=(c,)) for c in comms]
     [t.start() for t in th]; [t.join() for t in th]
     assert not err, err
-    for chi2, _ in out:
+    for chi2, c in out:
         assert len(chi2) == iters and np.all(np.abs(chi2 - ref_chi2[:iters]) <= CHI2_TOL * ref_chi2[:iters])
+        assert c["large_allreduces"] == iters + 1 and c["lm_trials"] == iters
     assert all(np.array_equal(out[0][0], o[0]) for o in out[1:])    # replicas stay bit-identical
 
 
