@@ -173,13 +173,19 @@ def main():
 
     if args.warmup > 0:
         run_steps(args.warmup)
-    c0 = solver.counters()
+    def counters():
+        c = solver.counters()
+        if native is not None:
+            c["lm_trials"] = native.counters()["lm_trials"]      # the native driver runs the trial loop, not the solver handle
+        return c
+
+    c0 = counters()
     fence()
     t_start = time.perf_counter()
     chi2 = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t_start
-    c1 = solver.counters()
+    c1 = counters()
     if dist is not None:
         tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
