@@ -676,19 +676,48 @@ void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const Dev
 //                         records (no Hpl tile is ever stored), reduced over the 16 lanes, one plain store.
 // Every output has exactly one writer and a fixed summation order => results are reproducible bit for bit.
 // ===================================================================================================
-constexpr int REC = 8;   // doubles per edge record
+constexpr int REC = 8;   // numbers per edge record
 
-__device__ __forceinline__ void rec_jacobians(const Scalar* rec, const Rot3& R, const Scalar cam[5], EdgeLin& L, Scalar& wr, int& il, Scalar Xc[3])
+// Record element type ET = the arithmetic type of the pose / block passes: Scalar, or float for the mixed-precision mode
+// of the fp64 library (option "mixed_precision": records and per-edge Jacobian arithmetic in fp32, every accumulation that
+// crosses edges and the whole reduced system in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29, applied only
+// where it is safe).  The landmark / stereo tag travels as an integer bit pattern, exact for any landmark count.
+__device__ __forceinline__ double tag_encode(long long tag, double) { return __longlong_as_double(tag); }
+__device__ __forceinline__ float tag_encode(long long tag, float) { return __int_as_float((int)tag); }
+__device__ __forceinline__ long long tag_decode(double v) { return __double_as_longlong(v); }
+__device__ __forceinline__ long long tag_decode(float v) { return (long long)__float_as_int(v); }
+
+template <typename ET>
+__device__ __forceinline__ void write_record(Scalar* base, size_t e, const Scalar Xc[3], Scalar wr, const Scalar r[3], int il, bool stereo)
 {
+	ET* rec = reinterpret_cast<ET*>(base) + REC * e;
+	rec[0] = (ET)Xc[0]; rec[1] = (ET)Xc[1]; rec[2] = (ET)Xc[2]; rec[3] = (ET)wr;
+	rec[4] = (ET)r[0]; rec[5] = (ET)r[1]; rec[6] = (ET)r[2];
+	rec[7] = tag_encode(2 * (long long)il + (stereo ? 1 : 0), ET());
+}
+
+template <typename ET>
+__device__ __forceinline__ void rec_jacobians(const Scalar* base, size_t e, const Rot3T<ET>& R, const ET cam[5], EdgeLinT<ET>& L, ET& wr, int& il, ET Xc[3])
+{
+	const ET* rec = reinterpret_cast<const ET*>(base) + REC * e;
 	Xc[0] = rec[0]; Xc[1] = rec[1]; Xc[2] = rec[2];
 	wr = rec[3];
 	L.r[0] = rec[4]; L.r[1] = rec[5]; L.r[2] = rec[6];
-	const long long tag = (long long)rec[7];
+	const long long tag = tag_decode(rec[7]);
 	il = (int)(tag >> 1);
 	edge_jacobians(Xc, R, cam, (tag & 1) != 0, L);
 }
 
-template <int MODE>
+template <typename ET>
+__device__ __forceinline__ void load_pose_as(const DeviceGraph& g, int ip, ET q[4], ET cam[5])
+{
+#pragma unroll
+	for (int i = 0; i < 4; i++) q[i] = (ET)g.q[4 * (size_t)ip + i];
+#pragma unroll
+	for (int i = 0; i < 5; i++) cam[i] = (ET)g.cam[5 * (size_t)ip + i];
+}
+
+template <int MODE, typename ET>
 __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
 {
 	__shared__ Scalar lds_all[(LIN_BLOCK / WAVE) * WAVE * 9];
@@ -720,9 +749,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		const int kind = stereo ? g.rk[1].kind : g.rk[0].kind;
 		const Scalar delta = stereo ? g.rk[1].delta : g.rk[0].delta;
 		const Scalar wr = w * robust_weight(kind, delta, w * ss);
-		Scalar* rec = st.e_rec + REC * (size_t)e;
-		rec[0] = Xc[0]; rec[1] = Xc[1]; rec[2] = Xc[2]; rec[3] = wr;
-		rec[4] = L.r[0]; rec[5] = L.r[1]; rec[6] = L.r[2]; rec[7] = (Scalar)(2 * (long long)il + (stereo ? 1 : 0));
+		write_record<ET>(st.e_rec, (size_t)e, Xc, wr, L.r, il, stereo);
 		if (il < g.Lf)
 		{
 			const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
@@ -776,7 +803,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 }
 
 // landmarks with more than 64 observations: one workgroup each
-template <int MODE>
+template <int MODE, typename ET>
 __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
 {
 	__shared__ Scalar red[4][9];
@@ -793,9 +820,8 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 #pragma unroll
 		for (int i = 0; i < 3; i++) Xw[i] = g.Xw[3 * (size_t)il + i];
 		quat_rotate(q, Xw, Xc);
-		Scalar* rec = st.e_rec + REC * (size_t)e;
-		rec[0] = Xc[0] + t[0]; rec[1] = Xc[1] + t[1]; rec[2] = Xc[2] + t[2]; rec[3] = le.wr;
-		rec[4] = le.lin.r[0]; rec[5] = le.lin.r[1]; rec[6] = le.lin.r[2]; rec[7] = (Scalar)(2 * (long long)il + (le.stereo ? 1 : 0));
+		Xc[0] += t[0]; Xc[1] += t[1]; Xc[2] += t[2];
+		write_record<ET>(st.e_rec, (size_t)e, Xc, le.wr, le.lin.r, il, le.stereo);
 		if (il < g.Lf)
 		{
 			const EdgeLin& L = le.lin;
@@ -840,16 +866,17 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 	}
 }
 
-// wave = free pose: diagonal block (upper triangle), bp, bsc
-template <int MODE>
+// wave = free pose: diagonal block (upper triangle), bp, bsc.  ET = record / per-edge arithmetic type; sums over edges are
+// always accumulated in Scalar.
+template <int MODE, typename ET>
 __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
 {
 	const int lane = threadIdx.x & 63;
 	const int ip = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (ip >= g.Pf) return;
-	Scalar q[4], t[3], cam[5];
-	load_pose(g, ip, q, t, cam);
-	const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
+	ET q[4], cam[5];
+	load_pose_as<ET>(g, ip, q, cam);
+	const Rot3T<ET> R = quat_to_rot(q[0], q[1], q[2], q[3]);
 	Scalar acc[33];
 #pragma unroll
 	for (int k = 0; k < 33; k++) acc[k] = 0;
@@ -857,9 +884,9 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 	for (int p = st.pe_ptr[ip] + lane; p < p1; p += 64)
 	{
 		const int e = st.pe_edge[p];
-		EdgeLin L; Scalar wr, Xc[3]; int il;
-		rec_jacobians(st.e_rec + REC * (size_t)e, R, cam, L, wr, il, Xc);
-		Scalar hpl[6][3], W[6][3], ibl[3] = { 0, 0, 0 };
+		EdgeLinT<ET> L; ET wr, Xc[3]; int il;
+		rec_jacobians<ET>(st.e_rec, (size_t)e, R, cam, L, wr, il, Xc);
+		ET hpl[6][3], W[6][3], ibl[3] = { 0, 0, 0 };
 		const bool lmFree = MODE == 1 && il < g.Lf;
 #pragma unroll
 		for (int c = 0; c < 6; c++)
@@ -869,11 +896,11 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 		if (lmFree)
 		{
 			const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
-			Scalar inv[6], bl[3];
+			ET inv[6], bl[3];
 #pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = ls[k];
+			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
 #pragma unroll
-			for (int k = 0; k < 3; k++) bl[k] = ls[6 + k];
+			for (int k = 0; k < 3; k++) bl[k] = (ET)ls[6 + k];
 #pragma unroll
 			for (int i = 0; i < 3; i++)
 				ibl[i] = inv[sym3_idx(i, 0)] * bl[0] + inv[sym3_idx(i, 1)] * bl[1] + inv[sym3_idx(i, 2)] * bl[2];
@@ -893,11 +920,11 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 		{
 #pragma unroll
 			for (int r = 0; r <= c; r++)
-				acc[c * (c + 1) / 2 + r] += wr * (L.JP[0][r] * L.JP[0][c] + L.JP[1][r] * L.JP[1][c] + L.JP[2][r] * L.JP[2][c])
-					- (W[r][0] * hpl[c][0] + W[r][1] * hpl[c][1] + W[r][2] * hpl[c][2]);
-			const Scalar b = wr * (L.JP[0][c] * L.r[0] + L.JP[1][c] * L.r[1] + L.JP[2][c] * L.r[2]);
-			acc[21 + c] += b;
-			acc[27 + c] += b - (hpl[c][0] * ibl[0] + hpl[c][1] * ibl[1] + hpl[c][2] * ibl[2]);
+				acc[c * (c + 1) / 2 + r] += (Scalar)(wr * (L.JP[0][r] * L.JP[0][c] + L.JP[1][r] * L.JP[1][c] + L.JP[2][r] * L.JP[2][c])
+					- (W[r][0] * hpl[c][0] + W[r][1] * hpl[c][1] + W[r][2] * hpl[c][2]));
+			const ET b = wr * (L.JP[0][c] * L.r[0] + L.JP[1][c] * L.r[1] + L.JP[2][c] * L.r[2]);
+			acc[21 + c] += (Scalar)b;
+			acc[27 + c] += (Scalar)(b - (hpl[c][0] * ibl[0] + hpl[c][1] * ibl[1] + hpl[c][2] * ibl[2]));
 		}
 	}
 #pragma unroll
@@ -916,9 +943,12 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 	}
 }
 
-// 16 lanes = one block (a,b) of Hsc with a != b (or a == b for the rare duplicate-observation products)
+// 16 lanes = one block (a,b) of Hsc with a != b (or a == b for the rare duplicate-observation products).
+// ET = record / per-product arithmetic type: a lane's own partial sum (its every 16th product) is kept in ET, the sum across
+// the 16 lanes and the stored block are Scalar.
 constexpr int BP_GROUP = 16;
 
+template <typename ET>
 __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
 {
 	const int gl = threadIdx.x & (BP_GROUP - 1);
@@ -926,12 +956,12 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 	const bool on = grp < st.nOd;
 	const int blk = on ? st.od_blocks[grp] : 0;
 	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
-	Scalar qa[4], ta[3], cama[5], qb[4], tb[3], camb[5];
-	load_pose(g, a, qa, ta, cama);
-	load_pose(g, b, qb, tb, camb);
-	const Rot3 Ra = quat_to_rot(qa[0], qa[1], qa[2], qa[3]);
-	const Rot3 Rb = quat_to_rot(qb[0], qb[1], qb[2], qb[3]);
-	Scalar T[6][6];
+	ET qa[4], cama[5], qb[4], camb[5];
+	load_pose_as<ET>(g, a, qa, cama);
+	load_pose_as<ET>(g, b, qb, camb);
+	const Rot3T<ET> Ra = quat_to_rot(qa[0], qa[1], qa[2], qa[3]);
+	const Rot3T<ET> Rb = quat_to_rot(qb[0], qb[1], qb[2], qb[3]);
+	ET T[6][6];
 #pragma unroll
 	for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -939,21 +969,21 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 	const int p1 = on ? st.prod_ptr[blk + 1] : 0;
 	for (int p = (on ? st.prod_ptr[blk] : 0) + gl; p < p1; p += BP_GROUP)
 	{
-		EdgeLin La, Lb; Scalar wa, wb, Xa[3], Xb[3]; int il, il2;
-		rec_jacobians(st.e_rec + REC * (size_t)st.prod_ea[p], Ra, cama, La, wa, il, Xa);
-		rec_jacobians(st.e_rec + REC * (size_t)st.prod_eb[p], Rb, camb, Lb, wb, il2, Xb);
+		EdgeLinT<ET> La, Lb; ET wa, wb, Xa[3], Xb[3]; int il, il2;
+		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_ea[p], Ra, cama, La, wa, il, Xa);
+		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_eb[p], Rb, camb, Lb, wb, il2, Xb);
 		const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
-		Scalar inv[6];
+		ET inv[6];
 #pragma unroll
-		for (int k = 0; k < 6; k++) inv[k] = ls[k];
+		for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
 		// S = wa wb JL_a inv JL_b^T  (measurement x measurement)
-		Scalar M1[3][3], S[3][3];
+		ET M1[3][3], S[3][3];
 #pragma unroll
 		for (int m = 0; m < 3; m++)
 #pragma unroll
 			for (int k = 0; k < 3; k++)
 				M1[m][k] = La.JL[m][0] * inv[sym3_idx(0, k)] + La.JL[m][1] * inv[sym3_idx(1, k)] + La.JL[m][2] * inv[sym3_idx(2, k)];
-		const Scalar ww = wa * wb;
+		const ET ww = wa * wb;
 #pragma unroll
 		for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -963,22 +993,23 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 #pragma unroll
 		for (int c = 0; c < 6; c++)
 		{
-			const Scalar u0 = S[0][0] * Lb.JP[0][c] + S[0][1] * Lb.JP[1][c] + S[0][2] * Lb.JP[2][c];
-			const Scalar u1 = S[1][0] * Lb.JP[0][c] + S[1][1] * Lb.JP[1][c] + S[1][2] * Lb.JP[2][c];
-			const Scalar u2 = S[2][0] * Lb.JP[0][c] + S[2][1] * Lb.JP[1][c] + S[2][2] * Lb.JP[2][c];
+			const ET u0 = S[0][0] * Lb.JP[0][c] + S[0][1] * Lb.JP[1][c] + S[0][2] * Lb.JP[2][c];
+			const ET u1 = S[1][0] * Lb.JP[0][c] + S[1][1] * Lb.JP[1][c] + S[1][2] * Lb.JP[2][c];
+			const ET u2 = S[2][0] * Lb.JP[0][c] + S[2][1] * Lb.JP[1][c] + S[2][2] * Lb.JP[2][c];
 #pragma unroll
 			for (int r = 0; r < 6; r++) T[r][c] += La.JP[0][r] * u0 + La.JP[1][r] * u1 + La.JP[2][r] * u2;
 		}
 	}
-	// reduce over the 16 lanes of the group
+	// reduce over the 16 lanes of the group (in Scalar)
+	Scalar Ts[6][6];
 #pragma unroll
 	for (int r = 0; r < 6; r++)
 #pragma unroll
 		for (int c = 0; c < 6; c++)
 		{
-			Scalar v = T[r][c];
+			Scalar v = (Scalar)T[r][c];
 			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-			T[r][c] = v;
+			Ts[r][c] = v;
 		}
 	if (!on) return;
 	Scalar* dst = sys.hsc + 36 * (size_t)blk;
@@ -988,7 +1019,7 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 		for (int c = 0; c < 6; c++)
 #pragma unroll
 			for (int r = 0; r < 6; r++)
-				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -T[r][c];
+				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
 	}
 	else if (gl == 0)
 	{
@@ -996,30 +1027,37 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 #pragma unroll
 		for (int c = 0; c < 6; c++)
 #pragma unroll
-			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= T[r][c] + T[c][r];
+			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= Ts[r][c] + Ts[c][r];
 	}
 }
 
-void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
+template <typename ET>
+static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
 {
 	if (st.nWaves > 0)
 	{
 		const int grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
-		if (mode == 0) hipLaunchKernelGGL(lm_pass_kernel<0>, dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
-		else hipLaunchKernelGGL(lm_pass_kernel<1>, dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
+		if (mode == 0) hipLaunchKernelGGL((lm_pass_kernel<0, ET>), dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
+		else hipLaunchKernelGGL((lm_pass_kernel<1, ET>), dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
 	}
 	if (st.nBig > 0)
 	{
-		if (mode == 0) hipLaunchKernelGGL(big_lm_pass_kernel<0>, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
-		else hipLaunchKernelGGL(big_lm_pass_kernel<1>, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+		if (mode == 0) hipLaunchKernelGGL((big_lm_pass_kernel<0, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 	}
 	if (g.Pf > 0)
 	{
-		if (mode == 0) hipLaunchKernelGGL(pose_pass_kernel<0>, dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
-		else hipLaunchKernelGGL(pose_pass_kernel<1>, dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
+		if (mode == 0) hipLaunchKernelGGL((pose_pass_kernel<0, ET>), dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
+		else hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
 	}
 	if (mode == 1 && st.nOd > 0)
-		hipLaunchKernelGGL(block_pass_kernel, dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		hipLaunchKernelGGL((block_pass_kernel<ET>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+}
+
+void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
+{
+	if (st.mixed && sizeof(Scalar) == 8) launch_linearize_dm_t<float>(g, st, sys, mode, lambda, s);
+	else launch_linearize_dm_t<Scalar>(g, st, sys, mode, lambda, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

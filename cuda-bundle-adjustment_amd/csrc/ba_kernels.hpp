@@ -66,7 +66,8 @@ struct DeviceStructure
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
 	Scalar *cb_wi = nullptr, *cb_wj = nullptr;                                    // weights of the fine (row, column) poses of every list entry in the linear coarse functions
-	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo}
+	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo (integer bits)}
+	int mixed = 0;                     // fp64 library only: 1 = records and the per-edge arithmetic of the pose / block passes in fp32
 };
 
 int spmv_rows_for(int Pf);      // block rows per SpMV workgroup (two waves each): 2, or 4 for large graphs

@@ -54,15 +54,18 @@ __device__ __forceinline__ Scalar robust_weight(int kind, Scalar delta, Scalar e
 }
 
 // Unit quaternion (x,y,z,w) -> rotation matrix, rows r0,r1,r2.  Ref: cuda_block_solver.cu:292-321.
-struct Rot3 { Scalar m[3][3]; };
+// (templated on the arithmetic type: the mixed-precision Schur passes of the fp64 library linearise in float)
+template <typename T> struct Rot3T { T m[3][3]; };
+using Rot3 = Rot3T<Scalar>;
 
-__device__ __forceinline__ Rot3 quat_to_rot(Scalar x, Scalar y, Scalar z, Scalar w)
+template <typename T>
+__device__ __forceinline__ Rot3T<T> quat_to_rot(T x, T y, T z, T w)
 {
-	const Scalar tx = 2 * x, ty = 2 * y, tz = 2 * z;
-	const Scalar twx = tx * w, twy = ty * w, twz = tz * w;
-	const Scalar txx = tx * x, txy = ty * x, txz = tz * x;
-	const Scalar tyy = ty * y, tyz = tz * y, tzz = tz * z;
-	Rot3 R;
+	const T tx = 2 * x, ty = 2 * y, tz = 2 * z;
+	const T twx = tx * w, twy = ty * w, twz = tz * w;
+	const T txx = tx * x, txy = ty * x, txz = tz * x;
+	const T tyy = ty * y, tyz = tz * y, tzz = tz * z;
+	Rot3T<T> R;
 	R.m[0][0] = 1 - (tyy + tzz); R.m[0][1] = txy - twz;       R.m[0][2] = txz + twy;
 	R.m[1][0] = txy + twz;       R.m[1][1] = 1 - (txx + tzz); R.m[1][2] = tyz - twx;
 	R.m[2][0] = txz - twy;       R.m[2][1] = tyz + twx;       R.m[2][2] = 1 - (txx + tyy);
@@ -82,12 +85,14 @@ __device__ __forceinline__ void quat_rotate(const Scalar q[4], const Scalar v[3]
 }
 
 // One observation: everything an edge contributes to the normal equations.
-struct EdgeLin
+template <typename T>
+struct EdgeLinT
 {
-	Scalar r[3];        // residual proj - meas (r[2] = 0 for monocular)
-	Scalar JP[3][6];    // d err / d [omega; upsilon]  (row 2 zero for monocular)
-	Scalar JL[3][3];    // d err / d Xw
+	T r[3];        // residual proj - meas (r[2] = 0 for monocular)
+	T JP[3][6];    // d err / d [omega; upsilon]  (row 2 zero for monocular)
+	T JL[3][3];    // d err / d Xw
 };
+using EdgeLin = EdgeLinT<Scalar>;
 
 // Residual only.  Ref: computeActiveErrorsKernel, cuda_block_solver.cu:733-786 (projectW2C/projectC2I :262-290).
 // Returns squared residual norm (unweighted).
@@ -106,12 +111,13 @@ __device__ __forceinline__ Scalar edge_residual(const Scalar q[4], const Scalar 
 }
 
 // Analytic Jacobians at camera-frame point Xc.  Ref: computeJacobians<2>/<3>, cuda_block_solver.cu:329-415.
-__device__ __forceinline__ void edge_jacobians(const Scalar Xc[3], const Rot3& R, const Scalar cam[5], bool stereo, EdgeLin& L)
+template <typename T>
+__device__ __forceinline__ void edge_jacobians(const T Xc[3], const Rot3T<T>& R, const T cam[5], bool stereo, EdgeLinT<T>& L)
 {
-	const Scalar X = Xc[0], Y = Xc[1];
-	const Scalar invZ = 1 / Xc[2], invZZ = invZ * invZ;
-	const Scalar fu = cam[0], fv = cam[1], bf = stereo ? cam[4] : Scalar(0);
-	const Scalar s = stereo ? Scalar(1) : Scalar(0);
+	const T X = Xc[0], Y = Xc[1];
+	const T invZ = 1 / Xc[2], invZZ = invZ * invZ;
+	const T fu = cam[0], fv = cam[1], bf = stereo ? cam[4] : T(0);
+	const T s = stereo ? T(1) : T(0);
 #pragma unroll
 	for (int j = 0; j < 3; j++)
 	{

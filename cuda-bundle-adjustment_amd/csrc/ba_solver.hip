@@ -97,6 +97,7 @@ struct cuba_hip_solver
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
 	int coarseMaxAge = 3;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
 	                             // changes the iteration count only); refreshed early when the count degrades
+	bool mixedPrecision = false; // fp64 library: records + per-edge arithmetic of the pose / block passes in fp32 (sums, reduced system, PCG in fp64)
 	bool schurAtomic = false;    // true: first-generation landmark-major Schur kernel with fp64 atomics (A/B runs)
 	bool profile = false;
 
@@ -844,7 +845,7 @@ struct cuba_hip_solver
 		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;   // pattern of Hsc doubles as the "symbolic" phase of the reduced solver
 	}
 
-	void need() { if (!haveGraph) throw StateError{ "set_graph must be called first" }; buildStructure(); g.rk[0] = rk[0]; g.rk[1] = rk[1]; }
+	void need() { if (!haveGraph) throw StateError{ "set_graph must be called first" }; buildStructure(); g.rk[0] = rk[0]; g.rk[1] = rk[1]; st.mixed = mixedPrecision ? 1 : 0; }
 
 	double readSlots(int which)
 	{
@@ -1348,6 +1349,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
+		else if (k == "mixed_precision") s->mixedPrecision = value != 0 && sizeof(Scalar) == 8;
 		else if (k == "pcg_accept_unconverged") s->acceptUnconverged = value != 0;
 		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }

@@ -93,7 +93,10 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
    was too short -- measured slightly slower), "coarse_overlap" (default 0; 1 = invert every trial's coarse matrix on a second
    stream under the PCG of that trial, for use by the next one -- measured slower, kept for A/B runs), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "schur_atomic"
-   (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "profile" (0/1: per-stage
+   (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "mixed_precision" (fp64 library
+   only, default 0; 1 = the per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in
+   fp32, every sum over edges, the reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29,
+   applied where it is second-order for the objective), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history), "profile" (0/1: per-stage
    synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */
 int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value);
 
