@@ -11,11 +11,16 @@
 // (src/cuda_block_solver.cu compiled in place through a CUDA->HIP name shim, oracle/ref_build/) runs one LM
 // trial on the MI355X and tests/test_ref_kernels.py requires this file to reproduce every stage output
 // (chi2, Hpp/bp/Hll/bl, max diagonal, bsc, Hsc, Hll^-1, xl, scale, updated estimates, per-edge chi2).
-// Two parts of the path remain UNPINNED against the reference because they cannot run here:
+// The LM CONTROLLER is pinned the same way: oracle/_ref/libcuba_ref_lm.so is the reference's whole optimiser
+// (src/cuda_bundle_adjustment.cpp: CudaBundleAdjustmentImpl::optimize + CudaBlockSolver, src/sparse_block_matrix.cpp and
+// src/cuda_block_solver.cu, compiled in place) and tests/test_ref_lm.py requires this file's optimize() to reproduce its
+// chi2 trajectories (<= 1e-9 relative), iteration counts, final estimates and per-edge chi2, including the pose-only /
+// landmark-only modes (the reference's gpu::solveDiagonalSystem) and runs with rejected trials.
+// One part of the path remains UNPINNED against the reference because it cannot run here:
 //   * the reduced-system solve -- NVIDIA cuSOLVER sparse Cholesky (src/cuda_linear_solver.cpp:147-232, closed
 //     source), restated as an exact sparse block Cholesky with min-degree ordering (any exact SPD solve is
-//     equivalent up to rounding; pinned against numpy dense solves instead);
-//   * the host LM controller (src/cuda_bundle_adjustment.cpp:793-857, needs Eigen) -- restated line by line.
+//     equivalent up to rounding; pinned against numpy dense solves instead; in libcuba_ref_lm.so a dense host
+//     Cholesky stands in for it).
 // Further independent pins in tests/: finite-difference Jacobians, mpmath exp-map, dense full-system solves.
 //
 // Every function cites the reference lines (under /root/reference/) it follows.

@@ -1,0 +1,95 @@
+"""LM-level pin against the REFERENCE ITSELF: the reference's own optimiser -- CudaBundleAdjustmentImpl::optimize,
+CudaBlockSolver and all kernels, compiled from /root/reference/src in place (oracle/ref_build, only the closed-source
+cuSOLVER step is a stand-in exact Cholesky) -- runs whole Levenberg-Marquardt trajectories on the MI355X.  The CPU oracle
+and the HIP path must follow them: chi2 per iteration, number of executed iterations, final estimates, per-edge chi2,
+including the degenerate modes that go through the reference's gpu::solveDiagonalSystem (pose-only, landmark-only) and a
+start that makes the reference reject trials.  Skipped when oracle/_ref was not built (needs the reference checkout)."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import RK_HUBER, RK_NONE, RK_TUKEY, with_fixed
+from cuba_amd.graph import flatten, write_back
+from cuba_amd.synth import synth_ba
+from oracle import ref_lm
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_lm.available(), reason="oracle/_ref/libcuba_ref_lm.so not built")]
+
+ORACLE_TOL = 1e-9     # same algorithm, exact solves on both sides: summation-order noise only (the reference sums with atomics)
+HIP_TOL = 1e-8        # HIP path at pcg_tol = 1e-11; at the default pcg_tol the bar is the north star's 1e-6
+
+
+def rough_start(g, seed=1, sx=3.0, st=0.6):
+    h = copy.deepcopy(g)
+    rng = np.random.default_rng(seed)
+    h.lm_X = h.lm_X + rng.normal(0, sx, h.lm_X.shape)
+    free = ~h.pose_fixed
+    h.pose_t = h.pose_t.copy(); h.pose_t[free] += rng.normal(0, st, (int(free.sum()), 3))
+    return h
+
+
+def cases():
+    g = synth_ba(40, 600, 2400, seed=1)
+    yield "huber", g, RK_HUBER, 10
+    yield "none", g, RK_NONE, 8
+    yield "fixed_vertices", with_fixed(g, fixed_pose_rows=[3, 4, 20], fixed_lm_rows=list(range(0, 300, 7))), RK_HUBER, 8
+    yield "pose_only", with_fixed(g, fixed_lm_rows=range(g.nlandmarks)), RK_HUBER, 6            # ref: solveDiagonalSystem(Hpp)
+    yield "landmark_only", with_fixed(g, fixed_pose_rows=range(g.nposes)), RK_HUBER, 6           # ref: solveDiagonalSystem(Hll)
+    yield "tukey_rejected_trials", rough_start(synth_ba(60, 1500, 6000, seed=3)), RK_TUKEY, 12
+    yield "kitti07_like", synth_ba(120, 6000, 24000, seed=9), RK_HUBER, 10
+
+
+def in_graph_order(fp, g, state):
+    """solver-order (q, t, X) -> the graph's row order (vertices the solver left out keep the graph's values)"""
+    h = copy.deepcopy(g)
+    write_back(h, fp, *state)
+    return h.pose_q, h.pose_t, h.lm_X
+
+
+@pytest.mark.parametrize("name,g,rk,iters", list(cases()), ids=[c[0] for c in cases()])
+def test_lm_trajectory_follows_the_reference(name, g, rk, iters):
+    from cuba_amd.capi import HipSolver
+    from oracle.oracle import OracleSolver
+    ref = ref_lm.run(g, rk, iters)
+    fp = flatten(g)
+    o = OracleSolver(fp, rk); ro = o.optimize(iters)
+    assert len(ro["chi2"]) == len(ref["chi2"]), (len(ro["chi2"]), len(ref["chi2"]))
+    # (the non-convex Tukey run from a rough start amplifies summation-order noise along its rejected / re-tried steps:
+    # measured 2.3e-9 there, <= 1e-10 everywhere else)
+    otol = 1e-7 if name == "tukey_rejected_trials" else ORACLE_TOL
+    assert np.all(np.abs(ro["chi2"] - ref["chi2"]) <= otol * ref["chi2"]), np.abs(ro["chi2"] / ref["chi2"] - 1).max()
+    if name == "tukey_rejected_trials":
+        assert ro["trials"].max() > 1                                  # the reference rejected the same trials
+    h = HipSolver(fp, rk, pcg_tol=1e-11); rh = h.optimize(iters)["chi2"]
+    htol = 1e-7 if name == "tukey_rejected_trials" else HIP_TOL
+    assert len(rh) == len(ref["chi2"]) and np.all(np.abs(rh - ref["chi2"]) <= htol * ref["chi2"]), np.abs(rh / ref["chi2"] - 1).max()
+    hd = HipSolver(fp, rk); rd = hd.optimize(iters)["chi2"]             # default tolerance: the stated 1e-6
+    assert len(rd) == len(ref["chi2"]) and np.all(np.abs(rd - ref["chi2"]) <= 1e-6 * ref["chi2"])
+    # final estimates (the reference wrote them back into its vertex objects, finalize() :512-526)
+    # (Tukey gives outlier-only landmarks zero weight: their position is held by the damping term alone and moves by
+    # 1e-5 m for last-bit differences in the sums -- measured 2.9e-5 m between the reference and the oracle there)
+    rough = name == "tukey_rejected_trials"
+    for label, solver, lim in (("oracle", o, 1e-3 if rough else 1e-7), ("hip", h, 1e-3 if rough else 1e-6)):
+        for a, b in zip(in_graph_order(fp, g, solver.state()), (ref["q"], ref["t"], ref["Xw"])):
+            assert np.abs(a - b).max() <= lim, (label, np.abs(a - b).max())
+    # per-edge chi2 at the final estimate, caller's edge order; edges with both ends fixed report 0 on both sides
+    per_edge = np.zeros(g.nedges); per_edge[fp.edge_src] = h.chi_squares()
+    want = np.concatenate([ref["chi_mono"], ref["chi_stereo"]])
+    assert np.abs(per_edge - want).max() <= (1e-3 if rough else 1e-6) * max(1.0, np.abs(want).max())
+
+
+def test_warm_start_protocol_follows_the_reference():
+    """The samples' protocol (sample_comparison_with_g2o.cpp:303-307, 74-79): initialize + optimize(1), then initialize +
+    optimize(10) from the written-back estimates."""
+    from cuba_amd.capi import HipSolver
+    g = synth_ba(40, 600, 2400, seed=1)
+    ref = ref_lm.run(g, RK_HUBER, 1, nruns=1)
+    g1 = copy.deepcopy(g)
+    g1.pose_q, g1.pose_t, g1.lm_X = ref["q"], ref["t"], ref["Xw"]
+    ref2 = ref_lm.run(g1, RK_HUBER, 10)
+    fp = flatten(g); h = HipSolver(fp, RK_HUBER, pcg_tol=1e-11); h.optimize(1)
+    g2 = copy.deepcopy(g); write_back(g2, fp, *h.state())
+    fp2 = flatten(g2); h2 = HipSolver(fp2, RK_HUBER, pcg_tol=1e-11)
+    got = h2.optimize(10)["chi2"]
+    assert len(got) == len(ref2["chi2"]) and np.all(np.abs(got - ref2["chi2"]) <= HIP_TOL * ref2["chi2"])
