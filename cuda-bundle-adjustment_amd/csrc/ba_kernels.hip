@@ -1924,6 +1924,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			for (int m = 0; m < AC; m++) ainv[a][m] = *reinterpret_cast<const Scalar2*>(Arow + min(2 * lane + 128 * m, Nc - 2));   // Nc is even
 		}
 	}
+	TRACE_MARK();      // (trace build only: waits for every load issued above)
 	// ---- rare remainders (more partials / coarse unknowns / own rows than threads) and the arithmetic ------------
 	Scalar a_k = e_k, a_0 = e_0, a_q = e_q0 + e_q1;
 	if (doUpdate)

@@ -13,6 +13,7 @@
 #include "cuda_bundle_adjustment.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -422,7 +423,18 @@ private:
 
 }  // namespace
 
-CudaBundleAdjustment::Ptr CudaBundleAdjustment::create() { return std::make_unique<HipBundleAdjustment>(); }
+CudaBundleAdjustment::Ptr CudaBundleAdjustment::createChecked(const size_t* layout, int n)
+{
+	// the layouts THIS library was compiled with (see the inline create() in the header)
+	const size_t mine[8] = { sizeof(PoseVertex), alignof(PoseVertex), offsetof(PoseVertex, t), offsetof(PoseVertex, camera),
+		sizeof(LandmarkVertex), offsetof(LandmarkVertex, fixed), sizeof(MonoEdge), sizeof(StereoEdge) };
+	bool same = layout && n == 8;
+	for (int i = 0; same && i < 8; i++) same = layout[i] == mine[i];
+	if (!same)
+		throw std::runtime_error("cuba::CudaBundleAdjustment::create: the application and libcuda_bundle_adjustment.so were compiled with "
+			"different Eigen headers (vertex / edge layouts differ); rebuild one of them against the other's Eigen");
+	return std::make_unique<HipBundleAdjustment>();
+}
 
 CudaBundleAdjustment::~CudaBundleAdjustment() = default;
 

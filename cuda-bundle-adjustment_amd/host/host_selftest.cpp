@@ -66,6 +66,13 @@ int main()
 	threw = false;
 	try { ba->optimize(1); } catch (const std::runtime_error&) { threw = true; }   // initialize() is required again
 	REQUIRE(threw);
+	// an application compiled against another Eigen (different vertex layout) is refused instead of corrupting memory
+	{
+		size_t layout[8] = { sizeof(cuba::PoseVertex) + 16, 16, 32, 64, sizeof(cuba::LandmarkVertex), 24, sizeof(cuba::MonoEdge), sizeof(cuba::StereoEdge) };
+		threw = false;
+		try { auto bad = cuba::CudaBundleAdjustment::createChecked(layout, 8); } catch (const std::runtime_error&) { threw = true; }
+		REQUIRE(threw);
+	}
 	std::printf("host_selftest: all checks passed\n");
 	return 0;
 }

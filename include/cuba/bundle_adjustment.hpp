@@ -15,6 +15,8 @@
 // initialize()/optimize() instead of being printed and ignored (ref src/macro.h:22-27).
 #pragma once
 
+#include <cstddef>
+
 #include "ba_types.hpp"
 
 namespace cuba
@@ -25,7 +27,17 @@ class CudaBundleAdjustment
 public:
 	using Ptr = UniquePtr<CudaBundleAdjustment>;
 
-	static Ptr create();
+	// Inline on purpose: the application's own view of the vertex / edge layouts (they embed Eigen types, whose size and
+	// alignment depend on the Eigen the APPLICATION was compiled with) travels into the library, which refuses to start
+	// when it was built against a different layout -- e.g. the library against the in-repo Eigen stand-in and the
+	// application against real Eigen3, whose Quaterniond is 16-byte aligned.  Throws std::runtime_error on a mismatch.
+	static Ptr create()
+	{
+		const size_t layout[8] = { sizeof(PoseVertex), alignof(PoseVertex), offsetof(PoseVertex, t), offsetof(PoseVertex, camera),
+			sizeof(LandmarkVertex), offsetof(LandmarkVertex, fixed), sizeof(MonoEdge), sizeof(StereoEdge) };
+		return createChecked(layout, 8);
+	}
+	static Ptr createChecked(const size_t* layout, int n);
 
 	virtual void addPoseVertex(PoseVertex* v) = 0;
 	virtual void addLandmarkVertex(LandmarkVertex* v) = 0;

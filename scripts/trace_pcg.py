@@ -28,7 +28,7 @@ buf = np.zeros((3, 8192, 8), dtype=np.uint64)
 rc = lib.cuba_hip_debug_read_trace(buf.ctypes.data_as(C.c_void_p))
 assert rc == 0, rc
 for kid, name, stages in ((0, "pcg_spmv", ["entry", "indices+scalars", "operands", "fold+barrier", "end"]),
-                          (1, "pcg2_fused", ["entry", "sweep loads", "barrier 1", "barrier yc", "end"]),
+                          (1, "pcg2_fused", ["entry", "loads landed", "restricted sums", "barrier 1", "barrier yc", "end"]),
                           (2, "dense_gj_step (last step)", ["entry", "tile loads", "pivot block inverse", "end"])):
     t = buf[kid].astype(np.int64)
     on = t[:, 0] > 0
