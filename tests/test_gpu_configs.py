@@ -367,6 +367,29 @@ def test_block_rows_wider_than_the_fixed_width_rows(solvers):
     assert len(got) == len(r["chi2"]) and np.all(np.abs(got - r["chi2"]) <= CHI2_TOL * r["chi2"])
 
 
+def test_device_and_host_setup_agree(solvers, small_graph):
+    """The set-up built on the GPU (edge sort, block pattern, product lists, adjacency, coarse lists, wave list:
+    csrc/ba_structure.hip) against the host pipeline (option device_setup = 0, also what landmark-partitioned handles use):
+    same block pattern, bit-identical LM runs -- every list must come out in the same order for that."""
+    from conftest import with_fixed
+    HipSolver, _ = solvers
+    g_big = synth_named("kitti07")
+    cases = [flatten(small_graph), flatten(with_fixed(small_graph, fixed_pose_rows=[3, 4, 5, 20], fixed_lm_rows=list(range(0, 300, 7)))),
+             flatten(with_fixed(small_graph, fixed_lm_rows=range(small_graph.nlandmarks))),          # pose-only: no landmark is free
+             flatten(shuffled_pose_ids(g_big, seed=3)), flatten(g_big)]
+    for fp in cases:
+        a = HipSolver(fp, RK_HUBER); b = HipSolver(fp, RK_HUBER, device_setup=0)
+        ra, rb = a.optimize(6)["chi2"], b.optimize(6)["chi2"]
+        if fp.Pf and fp.Lf:
+            (rpa, cia), (rpb, cib) = a.hsc_structure(), b.hsc_structure()
+            assert np.array_equal(rpa, rpb) and np.array_equal(cia, cib)
+            ca, cb = a.counters(), b.counters()
+            assert ca["hsc_blocks"] == cb["hsc_blocks"] and ca["schur_products"] == cb["schur_products"] and ca["coarse_dim"] == cb["coarse_dim"]
+        assert np.array_equal(ra, rb)
+        assert all(np.array_equal(x, y) for x, y in zip(a.state(), b.state()))
+        assert np.array_equal(a.chi_squares(), b.chi_squares())               # caller order restored on the device / on the host
+
+
 # ---------------------------------------------------------------------------------------------------------
 # known-answer test on the reference's real data, when somebody supplies it
 # ---------------------------------------------------------------------------------------------------------
