@@ -116,6 +116,16 @@ struct cuba_hip_solver
 	DevBuf<uint64_t> d_k64a, d_k64b, d_v64a, d_v64b;
 	DevBuf<unsigned char> d_topoTemp;
 	DevBuf<long long> d_pairCount, d_freeCount, d_freeScan;
+	// Internal pose order.  The aggregates of the two-level preconditioner are runs of consecutive pose indices and must be
+	// pieces of the trajectory (strongly coupled poses): with arbitrary vertex ids (the caller's solver order follows the ids)
+	// they are not, and the PCG needs 20 x the iterations (KITTI-00 shape, shuffled ids: 1403 instead of 61 in the last LM
+	// iteration).  When most blocks of the caller-order pattern lie far off the diagonal, the poses are renumbered internally
+	// by a strongest-neighbour walk over the co-visibility counts (= Schur products per block), which recovers the
+	// trajectory; every entry point keeps speaking the caller's order.
+	bool poseReorder = true;
+	bool reorderActive = false, reorderTried = false;
+	std::vector<int> poseNewOfOld, poseOldOfNew;     // free poses only; identity unless reorderActive
+	DevBuf<int> d_rawEpCaller, d_poseMap;
 	bool mixedPrecision = false; // fp64 library: records + per-edge arithmetic of the pose / block passes in fp32 (sums, reduced system, PCG in fp64)
 	bool schurAtomic = false;    // true: first-generation landmark-major Schur kernel with fp64 atomics (A/B runs)
 	bool profile = false;
@@ -430,41 +440,38 @@ struct cuba_hip_solver
 		const DeviceGraph gOld = g;
 		bool sameTopology = false;
 		const bool useDev = deviceSetup && !schurAtomic && E > 0;
-		if (!useDev && !hostTopoValid) sameInput = false;      // the host-side sort of the previous call does not exist (device path)
+		if (!useDev && (!hostTopoValid || reorderActive)) sameInput = false;      // the host-side sort of the previous call does not exist (device path)
 		if (useDev)
 		{
 			// ---- device path: raw arrays go up as they are; sort, gather and the landmark pointers are kernels -------------
-			const bool reuseSort = sameInput && devTopology;
+			// (an internal pose order found for this very topology is kept; otherwise it starts over as the identity)
+			const bool keepOrder = reorderActive && sameInput && devTopology && sameCounts;
+			const bool reuseSort = sameInput && devTopology && (keepOrder || !reorderActive);
+			if (!keepOrder) resetPoseOrder();
 			if (!reuseSort)
 			{
 				if (!sameInput) { h_inEp.assign(ep, ep + E); h_inEl.assign(el, el + E); h_inDim.assign(edim, edim + E); }
-				d_rawEp.uploadRaw(ep, E, stream); d_rawEl.uploadRaw(el, E, stream); d_rawDim.uploadRaw(edim, E, stream);
+				d_rawEpCaller.uploadRaw(ep, E, stream); d_rawEl.uploadRaw(el, E, stream); d_rawDim.uploadRaw(edim, E, stream);
+				d_rawEp.resize(E);
+				HIP_TRY(hipMemcpyAsync(d_rawEp.data(), d_rawEpCaller.data(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, stream));
 			}
 			d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream);
 			lap("set_graph: raw uploads enqueued");
-			d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
-			if (!reuseSort)
-			{
-				d_k64a.resize(E); d_k64b.resize(E); d_v32a.resize(E); d_perm.resize(E); d_counters.resize(topo::CNT_COUNT);
-				d_epose.resize(E); d_elm.resize(E); d_lmptr.resize((size_t)Lt + 1);
-				d_counters.zero(stream);
-				topo::launch_edge_keys(d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), E, Pt, Pf, Lt, Lf, d_k64a.data(), d_v32a.data(), d_counters.data(), stream);
-				const size_t tb = topo::sort_temp_bytes(E);
-				d_topoTemp.resize(tb);
-				HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), tb, d_k64a.data(), d_k64b.data(), d_v32a.data(), d_perm.data(), E, 32 + bitsFor(Lt), stream));
-				topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
-					d_epose.data(), d_elm.data(), d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
-				topo::launch_segment_ptr(d_elm.data(), E, Lt, d_lmptr.data(), stream);
-			}
+			if (!reuseSort) runDeviceEdgeSort();
 			else
+			{
+				d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
 				topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
 					nullptr, nullptr, d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
+			}
 			sameTopology = sameCounts && reuseSort;
 			devTopology = true; hostTopoValid = false;
+			if (reorderActive) permuteStateRows(state, camv);          // the caller's rows -> the internal pose order kept from the last call
 			lap("set_graph: device sort + gather enqueued");
 		}
 		else
 		{
+		resetPoseOrder();
 		if (!sameInput)
 		{
 		h_inEp.assign(ep, ep + E); h_inEl.assign(el, el + E); h_inDim.assign(edim, edim + E);
@@ -574,6 +581,7 @@ struct cuba_hip_solver
 		if (haveStructure) return;
 		if (gjStream) { HIP_TRY(hipStreamSynchronize(gjStream)); pendingInv = -1; assemblePending = false; }   // an overlapped coarse inversion uses the old structure
 		if (devTopology && deviceSetup && partHi < 0 && !schurAtomic) { buildStructureDevice(); return; }
+		if (reorderActive) { std::vector<int> id(Pf); for (int i = 0; i < Pf; i++) id[i] = i; applyPoseOrder(id); }   // the host pipeline (partitions) runs in the caller's order
 		ensureHostTopology();
 		const auto t0 = Clock::now();
 		std::vector<int> nfree(Lf, 0);
@@ -932,6 +940,157 @@ struct cuba_hip_solver
 	}
 	bool hostPatternValid = false;     // h_rowptr / h_colind describe the current structure (the device-built one downloads them on demand)
 
+	// ---- internal pose order ------------------------------------------------------------------------------------------
+	int farOffset() const { return std::max(24, Pf / 8); }      // "far from the diagonal", in block columns
+	void resetPoseOrder()
+	{
+		reorderActive = false;
+		poseNewOfOld.resize(Pf); poseOldOfNew.resize(Pf);
+		for (int i = 0; i < Pf; i++) poseNewOfOld[i] = poseOldOfNew[i] = i;
+	}
+	// rows of a per-pose array (`width` numbers per pose, first Pf rows) between the caller's and the internal order
+	template <class T>
+	void permutePoseArray(T* a, int width, bool toInternal) const
+	{
+		if (!reorderActive) return;
+		std::vector<T> tmp(a, a + (size_t)width * Pf);
+		for (int old = 0; old < Pf; old++)
+		{
+			const int nw = poseNewOfOld[old];
+			const T* src = tmp.data() + (size_t)width * (toInternal ? old : nw);
+			T* dst = a + (size_t)width * (toInternal ? nw : old);
+			for (int k = 0; k < width; k++) dst[k] = src[k];
+		}
+	}
+	void permuteStateRows(std::vector<Scalar>& state, std::vector<Scalar>& camv) const
+	{
+		permutePoseArray(state.data(), 4, true);
+		permutePoseArray(state.data() + 4 * (size_t)Pt, 3, true);
+		permutePoseArray(camv.data(), 5, true);
+	}
+
+	// keys (landmark, pose) of the raw device edge arrays -> sort permutation, sorted edge arrays, landmark pointers
+	void runDeviceEdgeSort()
+	{
+		d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
+		d_k64a.resize(E); d_k64b.resize(E); d_v32a.resize(E); d_perm.resize(E); d_counters.resize(topo::CNT_COUNT);
+		d_epose.resize(E); d_elm.resize(E); d_lmptr.resize((size_t)Lt + 1);
+		d_counters.zero(stream);
+		topo::launch_edge_keys(d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), E, Pt, Pf, Lt, Lf, d_k64a.data(), d_v32a.data(), d_counters.data(), stream);
+		const size_t tb = topo::sort_temp_bytes(E);
+		d_topoTemp.resize(std::max(tb, d_topoTemp.size()));
+		HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), d_topoTemp.size(), d_k64a.data(), d_k64b.data(), d_v32a.data(), d_perm.data(), E, 32 + bitsFor(Lt), stream));
+		topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
+			d_epose.data(), d_elm.data(), d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
+		topo::launch_segment_ptr(d_elm.data(), E, Lt, d_lmptr.data(), stream);
+	}
+
+	// Strongest-neighbour walk over the pose graph weighted by the number of Schur products per block (= co-visible landmarks):
+	// start at the pose of smallest weighted degree, always step to the heaviest unvisited neighbour, when stuck continue from
+	// the unvisited pose most strongly tied to the visited ones.  On a keyframe trajectory this IS the trajectory order, loop
+	// closures included (consecutive frames share far more landmarks than revisits do); scripts/precond_experiment6.py.
+	// (A bandwidth-minimising order is the wrong tool: RCM interleaves the laps of a revisited stretch, the coarse space then
+	// cannot move one lap against the other and the PCG needs 1358 instead of 74 iterations.)
+	std::vector<int> chainOrder(const std::vector<int>& rowptr, const std::vector<int>& colind, const std::vector<int>& prodPtr) const
+	{
+		const int n = Pf;
+		std::vector<int> adjP(n + 1, 0);
+		for (int i = 0; i < n; i++)
+			for (int k = rowptr[i]; k < rowptr[i + 1]; k++) if (colind[k] != i) { adjP[i + 1]++; adjP[colind[k] + 1]++; }
+		for (int i = 0; i < n; i++) adjP[i + 1] += adjP[i];
+		std::vector<int> adjJ(adjP[n]), adjW(adjP[n]), cur(adjP.begin(), adjP.end() - 1);
+		std::vector<long long> deg(n, 0);
+		for (int i = 0; i < n; i++)
+			for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+			{
+				const int j = colind[k];
+				if (j == i) continue;
+				const int w = std::max(1, prodPtr[k + 1] - prodPtr[k]);
+				adjJ[cur[i]] = j; adjW[cur[i]++] = w; adjJ[cur[j]] = i; adjW[cur[j]++] = w;
+				deg[i] += w; deg[j] += w;
+			}
+		std::vector<char> visited(n, 0);
+		std::vector<int> order; order.reserve(n);
+		std::vector<std::pair<int, int>> heap;            // (weight, -pose) of unvisited poses next to visited ones
+		int at = -1;
+		for (int i = 0; i < n; i++) if (deg[i] > 0 && (at < 0 || deg[i] < deg[at])) at = i;
+		if (at < 0) at = 0;
+		int nextUnvisited = 0;
+		while ((int)order.size() < n)
+		{
+			visited[at] = 1; order.push_back(at);
+			int best = -1, bw = -1;
+			for (int x = adjP[at]; x < adjP[at + 1]; x++)
+			{
+				const int j = adjJ[x];
+				if (visited[j]) continue;
+				heap.emplace_back(adjW[x], -j); std::push_heap(heap.begin(), heap.end());
+				if (adjW[x] > bw || (adjW[x] == bw && j < best)) { best = j; bw = adjW[x]; }
+			}
+			if (best >= 0) { at = best; continue; }
+			at = -1;
+			while (!heap.empty())
+			{
+				std::pop_heap(heap.begin(), heap.end());
+				const int j = -heap.back().second; heap.pop_back();
+				if (!visited[j]) { at = j; break; }
+			}
+			if (at < 0)
+			{
+				while (nextUnvisited < n && visited[nextUnvisited]) nextUnvisited++;
+				if (nextUnvisited >= n) break;
+				at = nextUnvisited;
+			}
+		}
+		std::vector<int> newOfOld(n);
+		for (int k = 0; k < n; k++) newOfOld[order[k]] = k;
+		return newOfOld;
+	}
+
+	// renumber the free poses internally (device path only): state / camera rows, the pose index of every edge, then the edge
+	// sort again; the structure has to be rebuilt afterwards
+	void applyPoseOrder(const std::vector<int>& newOfOld)
+	{
+		std::vector<Scalar> state(d_state.size()), camv((size_t)5 * Pt);
+		HIP_TRY(hipMemcpyAsync(state.data(), d_state.data(), sizeof(Scalar) * state.size(), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(camv.data(), d_cam.data(), sizeof(Scalar) * camv.size(), hipMemcpyDeviceToHost, stream));
+		sync();
+		// back to the caller's order with the order in force, then into the new one
+		permutePoseArray(state.data(), 4, false); permutePoseArray(state.data() + 4 * (size_t)Pt, 3, false); permutePoseArray(camv.data(), 5, false);
+		poseNewOfOld = newOfOld;
+		reorderActive = false;
+		for (int i = 0; i < Pf; i++) { poseOldOfNew[newOfOld[i]] = i; if (newOfOld[i] != i) reorderActive = true; }
+		permuteStateRows(state, camv);
+		d_state.upload(state, stream); d_cam.upload(camv, stream);
+		d_poseMap.upload(poseNewOfOld, stream);
+		topo::launch_remap_poses(d_rawEpCaller.data(), d_poseMap.data(), E, Pf, d_rawEp.data(), stream);
+		runDeviceEdgeSort();
+		sync();          // the host vectors above go out of scope
+		haveStructure = false; hostTopoValid = false; hostPatternValid = false;
+	}
+
+	// after a caller-order structure build: is the pose order bad enough to look for a better one?  true = renumbered,
+	// build the structure again
+	bool tryReorder(int nblk, int farBlocks)
+	{
+		const int offDiag = nblk - Pf;
+		if (!poseReorder || Pf < 48 || offDiag <= 0 || 2 * (long long)farBlocks < offDiag) return false;
+		std::vector<int> rp((size_t)Pf + 1), ci(nblk), pp((size_t)nblk + 1);
+		HIP_TRY(hipMemcpyAsync(rp.data(), d_rowptr.data(), sizeof(int) * rp.size(), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(ci.data(), d_colind.data(), sizeof(int) * ci.size(), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(pp.data(), d_prodPtr.data(), sizeof(int) * pp.size(), hipMemcpyDeviceToHost, stream));
+		sync();
+		const std::vector<int> order = chainOrder(rp, ci, pp);
+		// worth it only if the new order really is more local
+		long long farNew = 0;
+		for (int i = 0; i < Pf; i++)
+			for (int k = rp[i]; k < rp[i + 1]; k++) farNew += std::abs(order[i] - order[ci[k]]) > farOffset();
+		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] pose order: %d of %d off-diagonal blocks far from the diagonal, %lld after the walk\n", farBlocks, offDiag, farNew);
+		if (2 * farNew >= farBlocks) return false;
+		applyPoseOrder(order);
+		return true;
+	}
+
 	// the host pipeline (landmark partitions, atomic Schur kernel) needs the sorted arrays the device path kept to itself
 	void ensureHostTopology()
 	{
@@ -1038,7 +1197,7 @@ struct cuba_hip_solver
 		d_k32a.resize(n32); d_k32b.resize(n32); d_v32a.resize(n32); d_v32b.resize(n32);
 		sortTemp(n32);
 		d_odBlocks.resize(nblk);
-		topo::launch_od_keys(d_prodPtr.data(), nblk, d_k32a.data(), d_v32a.data(), cnt, stream);
+		topo::launch_od_keys(d_prodPtr.data(), d_blkrow.data(), d_colind.data(), nblk, farOffset(), d_k32a.data(), d_v32a.data(), cnt, stream);
 		if (nblk) HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), nblk, 32, stream));
 		topo::launch_copy_u32_to_int(d_v32b.data(), d_odBlocks.data(), nblk, stream);
 		// 7. symmetric adjacency: the lower part of every row comes from the (column, row)-sorted list of the off-diagonal blocks
@@ -1076,12 +1235,37 @@ struct cuba_hip_solver
 		d_ell.resize((size_t)Pf * ellM * 20);
 		topo::launch_ell(d_adjPtr.data(), d_adjBlk.data(), d_adjCol.data(), Pf, ellM, d_ell.data(), stream);
 		d_pairBlk.resize(0);
+		if (!reorderActive && !reorderTried && tryReorder(nblk, hc[topo::CNT_FARBLOCKS]))
+		{
+			reorderTried = true;
+			buildStructureDevice();            // once more, now in the internal pose order
+			return;
+		}
+		reorderTried = false;
 		publishStructure(nblk, nWaves, nBig, hc[topo::CNT_NOD], cc.nc > 0 ? hc[topo::CNT_NCB] : 0, ellM, ellOver, cc);
 		hostPatternValid = false;
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] structure (device): nblk %d products %lld waves %d big %d od %d coarse blocks %d max row %d\n",
 			nblk, npairs, nWaves, nBig, hc[topo::CNT_NOD], hc[topo::CNT_NCB], maxRow);
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
 		prof[1] += 0.5 * dt; prof[5] += 0.5 * dt;
+	}
+
+	// the block pattern / values as the CALLER numbers the poses (introspection entry points; identity unless reorderActive)
+	struct CallerBlock { uint64_t key; int src; bool transposed; };
+	std::vector<CallerBlock> callerBlocks()
+	{
+		ensureHostPattern();
+		std::vector<CallerBlock> b; b.reserve(h_colind.size());
+		for (int i = 0; i < Pf; i++)
+			for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; k++)
+			{
+				int r = poseOldOfNew[i], c = poseOldOfNew[h_colind[k]];
+				const bool tr = r > c;
+				if (tr) std::swap(r, c);
+				b.push_back(CallerBlock{ ((uint64_t)(uint32_t)r << 32) | (uint32_t)c, k, tr });
+			}
+		std::sort(b.begin(), b.end(), [](const CallerBlock& x, const CallerBlock& y) { return x.key < y.key; });
+		return b;
 	}
 
 	void ensureHostPattern()
@@ -1607,6 +1791,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
+		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }
 		else if (k == "mixed_precision") s->mixedPrecision = value != 0 && sizeof(Scalar) == 8;
 		else if (k == "pcg_accept_unconverged") s->acceptUnconverged = value != 0;
@@ -1694,8 +1879,8 @@ int cuba_hip_get_solution(cuba_hip_solver* s, double* q, double* t, double* Xw)
 	return guarded(s, [&] {
 		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
 		const Scalar* base = s->d_state.data();
-		if (q) s->downloadAsDouble(base, q, (size_t)4 * s->Pt);
-		if (t) s->downloadAsDouble(base + 4 * (size_t)s->Pt, t, (size_t)3 * s->Pt);
+		if (q) { s->downloadAsDouble(base, q, (size_t)4 * s->Pt); s->permutePoseArray(q, 4, false); }
+		if (t) { s->downloadAsDouble(base + 4 * (size_t)s->Pt, t, (size_t)3 * s->Pt); s->permutePoseArray(t, 3, false); }
 		if (Xw) s->downloadAsDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
 	});
 }
@@ -1704,9 +1889,10 @@ int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, 
 {
 	return guarded(s, [&] {
 		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		s->buildStructure();          // the internal pose order (if any) is decided there
 		Scalar* base = s->d_state.data();
-		if (q) s->uploadFromDouble(base, q, (size_t)4 * s->Pt);
-		if (t) s->uploadFromDouble(base + 4 * (size_t)s->Pt, t, (size_t)3 * s->Pt);
+		if (q) { std::vector<double> v(q, q + (size_t)4 * s->Pt); s->permutePoseArray(v.data(), 4, true); s->uploadFromDouble(base, v.data(), v.size()); }
+		if (t) { std::vector<double> v(t, t + (size_t)3 * s->Pt); s->permutePoseArray(v.data(), 3, true); s->uploadFromDouble(base + 4 * (size_t)s->Pt, v.data(), v.size()); }
 		if (Xw) s->uploadFromDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
 	});
 }
@@ -1745,8 +1931,20 @@ int cuba_hip_get_hsc_structure(cuba_hip_solver* s, int32_t* row_ptr, int32_t* co
 		s->need();
 		s->ensureHostPattern();
 		if (nblk) *nblk = (int)s->h_colind.size();
-		if (row_ptr) std::memcpy(row_ptr, s->h_rowptr.data(), sizeof(int) * s->h_rowptr.size());
-		if (col_ind) std::memcpy(col_ind, s->h_colind.data(), sizeof(int) * s->h_colind.size());
+		if (!s->reorderActive)
+		{
+			if (row_ptr) std::memcpy(row_ptr, s->h_rowptr.data(), sizeof(int) * s->h_rowptr.size());
+			if (col_ind) std::memcpy(col_ind, s->h_colind.data(), sizeof(int) * s->h_colind.size());
+			return;
+		}
+		const auto blocks = s->callerBlocks();
+		if (row_ptr)
+		{
+			for (int i = 0; i <= s->Pf; i++) row_ptr[i] = 0;
+			for (const auto& b : blocks) row_ptr[(int)(b.key >> 32) + 1]++;
+			for (int i = 0; i < s->Pf; i++) row_ptr[i + 1] += row_ptr[i];
+		}
+		if (col_ind) for (size_t k = 0; k < blocks.size(); k++) col_ind[k] = (int)(uint32_t)blocks[k].key;
 	});
 }
 
@@ -1766,7 +1964,27 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
 		default: throw ArgError{ "unknown array id" };
 		}
 		if (count) *count = n;
-		if (out && n) s->downloadAsDouble(src, out, n);
+		if (out && n)
+		{
+			s->downloadAsDouble(src, out, n);
+			if (s->reorderActive)
+			{
+				// back to the caller's pose numbering
+				if (which == CUBA_HIP_ARRAY_BP || which == CUBA_HIP_ARRAY_BSC || which == CUBA_HIP_ARRAY_XP) s->permutePoseArray(out, 6, false);
+				else if (which == CUBA_HIP_ARRAY_HSC)
+				{
+					const std::vector<double> v(out, out + n);
+					const auto blocks = s->callerBlocks();
+					for (size_t k = 0; k < blocks.size(); k++)
+					{
+						const double* src36 = v.data() + 36 * (size_t)blocks[k].src;
+						double* dst = out + 36 * k;
+						for (int c = 0; c < 6; c++)
+							for (int r = 0; r < 6; r++) dst[c * 6 + r] = blocks[k].transposed ? src36[r * 6 + c] : src36[c * 6 + r];
+					}
+				}
+			}
+		}
 	});
 }
 

@@ -182,18 +182,28 @@ __global__ __launch_bounds__(T) void blocks_from_entries_kernel(const uint64_t* 
 	if (j == n - 1) prod_ptr[b + 1] = (int)(n - (size_t)Pf);
 }
 
-__global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_ptr, int nblk, uint32_t* keys, uint32_t* vals, int* counters)
+__global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters)
 {
 	const int k = blockIdx.x * T + threadIdx.x;
-	int cnt = 0;
+	int cnt = 0, far = 0;
 	if (k < nblk)
 	{
+		far = colind[k] - blkrow[k] > farOffset;
 		cnt = prod_ptr[k + 1] - prod_ptr[k];
 		keys[k] = cnt > 0 ? 0x7fffffffu - (uint32_t)cnt : 0xffffffffu;          // longest list first; blocks without products last
 		vals[k] = (uint32_t)k;
 	}
-	const int n = __popcll(__ballot(cnt > 0));
+	const int n = __popcll(__ballot(cnt > 0)), nf = __popcll(__ballot(far != 0));
 	if ((threadIdx.x & 63) == 0 && n) atomicAdd(&counters[CNT_NOD], n);
+	if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&counters[CNT_FARBLOCKS], nf);
+}
+
+__global__ __launch_bounds__(T) void remap_poses_kernel(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut)
+{
+	const int e = blockIdx.x * T + threadIdx.x;
+	if (e >= E) return;
+	const int p = epIn[e];
+	epOut[e] = p < Pf ? newOfOld[p] : p;
 }
 
 __global__ __launch_bounds__(T) void transpose_keys_kernel(const int* colind, const int* blkrow, int nblk, uint64_t* keys, uint32_t* vals)
@@ -425,9 +435,14 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 	if (n > 0) hipLaunchKernelGGL(blocks_from_entries_kernel, grid_for(n), dim3(T), 0, s, keys, vals, blkOfEntry, n, Pf, colind, blkrow, prod_ptr, prod_ea, prod_eb);
 }
 
-void launch_od_keys(const int* prod_ptr, int nblk, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)
+void launch_od_keys(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)
 {
-	if (nblk > 0) hipLaunchKernelGGL(od_keys_kernel, grid_for(nblk), dim3(T), 0, s, prod_ptr, nblk, keys, vals, counters);
+	if (nblk > 0) hipLaunchKernelGGL(od_keys_kernel, grid_for(nblk), dim3(T), 0, s, prod_ptr, blkrow, colind, nblk, farOffset, keys, vals, counters);
+}
+
+void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s)
+{
+	if (E > 0) hipLaunchKernelGGL(remap_poses_kernel, grid_for(E), dim3(T), 0, s, epIn, newOfOld, E, Pf, epOut);
 }
 
 void launch_transpose_keys(const int* colind, const int* blkrow, int nblk, uint64_t* keys, uint32_t* vals, hipStream_t s)

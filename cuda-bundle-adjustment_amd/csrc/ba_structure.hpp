@@ -30,7 +30,7 @@ hipError_t exclusive_scan_i64(void* temp, size_t tempBytes, const long long* in,
 hipError_t inclusive_scan_i32(void* temp, size_t tempBytes, const int* in, int* out, size_t n, hipStream_t s);
 
 // counters the kernels fill (one device int each), read back by the host at its synchronisation points
-enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_COUNT = 16 };
+enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_COUNT = 16 };
 
 // ---- A. edges ------------------------------------------------------------------------------------------------------
 // keys[e] = landmark << 32 | pose, vals[e] = e; counters[CNT_BAD] = 1 / 2 / 3 for an index out of range / a bad dimension /
@@ -59,7 +59,10 @@ void launch_entry_heads(const uint64_t* keys, size_t n, int* head, hipStream_t s
 void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, const int* blkOfEntry, size_t n, int Pf,
 	int* colind, int* blkrow, int* prod_ptr, int* prod_ea, int* prod_eb, hipStream_t s);
 // blocks with products, longest list first (stable): sort keys + values; counters[CNT_NOD] = their number
-void launch_od_keys(const int* prod_ptr, int nblk, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
+// counters[CNT_FARBLOCKS] = number of blocks more than farOffset block columns off the diagonal (pose order check)
+void launch_od_keys(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
+// pose indices of the caller-order edge array through a map of the free poses (fixed poses keep their index)
+void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s);
 // transposed view of the off-diagonal blocks: key = column << 32 | row (diagonal blocks get the largest key)
 void launch_transpose_keys(const int* colind, const int* blkrow, int nblk, uint64_t* keys, uint32_t* vals, hipStream_t s);
 void launch_keys_hi(const uint64_t* keys, int n, int limit, int* hi, hipStream_t s);       // hi[i] = min(keys[i] >> 32, limit)

@@ -96,7 +96,11 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "mixed_precision" (fp64 library
    only, default 0; 1 = the per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in
    fp32, every sum over edges, the reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29,
-   applied where it is second-order for the objective), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history), "device_setup" (default 1: the edge sort of cuba_hip_set_graph and
+   applied where it is second-order for the objective), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history), "pose_reorder" (default 1: when most blocks of the reduced matrix lie far off its diagonal in
+   the caller's pose numbering -- arbitrary vertex ids --, the free poses are renumbered internally along the trajectory found by a
+   strongest-neighbour walk over the co-visibility counts, which the aggregates of the two-level preconditioner need; every host-pointer
+   entry point keeps the caller's numbering, only cuba_hip_device_pointer / cuba_hip_reduction_buffer expose the internal one),
+   "device_setup" (default 1: the edge sort of cuba_hip_set_graph and
    the whole symbolic analysis of cuba_hip_build_structure run on the GPU; 0 = the host pipeline, which landmark-partitioned
    handles and "schur_atomic" use in any case), "profile" (0/1: per-stage
    synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */

@@ -226,9 +226,10 @@ def shuffled_pose_ids(g, seed=0):
 
 @pytest.mark.parametrize("name", ["kitti07", "kitti00"])
 def test_shuffled_pose_ids(solvers, name):
-    """The two-level preconditioner's aggregates are runs of consecutive solver indices.  With shuffled pose ids they
-    are no longer trajectory neighbours: parity must hold regardless, every solve must converge, and the iteration
-    counts are recorded next to the id-ordered ones."""
+    """The two-level preconditioner's aggregates are runs of consecutive pose indices.  With shuffled pose ids the caller's
+    solver order no longer follows the trajectory; the library then renumbers the free poses internally (strongest-neighbour
+    walk over the co-visibility counts, option pose_reorder).  Parity must hold, every solve must converge, the iteration
+    counts must stay those of the id-ordered graph, and without the renumbering they do not (recorded)."""
     HipSolver, OracleSolver = solvers
     g = synth_named(name)
     fp_ord = flatten(g)
@@ -241,10 +242,54 @@ def test_shuffled_pose_ids(solvers, name):
     it, bad = h.pcg_history()
     assert bad == 0
     ho = HipSolver(fp_ord, RK_HUBER); ho.optimize(10)
-    print(f"\n[{name}] PCG iterations per solve: id-ordered {ho.pcg_history()[0].tolist()}  shuffled {it.tolist()}")
+    it_ord = ho.pcg_history()[0]
+    hn = HipSolver(fp, RK_HUBER, pose_reorder=0); hn.optimize(10)
+    it_raw = hn.pcg_history()[0]
+    print(f"\n[{name}] PCG iterations per solve: id-ordered {it_ord.tolist()}  shuffled {it.tolist()}  shuffled, pose_reorder=0 {np.abs(it_raw).tolist()}")
+    assert it.sum() <= 1.15 * it_ord.sum()                           # the walk recovers the trajectory
+    assert np.abs(it_raw).sum() > 3 * it_ord.sum()                   # ... which is what the preconditioner needs
     # the same physical problem: chi2 agrees with the id-ordered run to solver tolerance
     ref_ord = named_case(name)[1]
     assert np.all(np.abs(got - ref_ord) <= CHI2_TOL * ref_ord)
+
+
+def test_shuffled_pose_ids_stage_outputs_keep_the_callers_numbering(solvers):
+    """With the internal renumbering active every host-pointer entry point still speaks the caller's pose order: bp, bsc, xp,
+    the block pattern and the block values of Hsc, the solution -- all against the oracle in the caller's order; set_state /
+    state round-trip; a landmark partition (which runs in the caller's order) after the renumbering."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(shuffled_pose_ids(synth_ba(200, 8000, 32000, seed=13), seed=2))
+    o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
+    md = o.max_diagonal(); lam = 1e-5 * md
+    h = HipSolver(fp, RK_HUBER, pcg_tol=1e-11)
+    assert h.max_diagonal() == pytest.approx(md, rel=1e-12)
+    o.set_lambda(lam); h.set_lambda(lam); o.schur(); h.schur()
+    rpo, cio, vo = o.hsc(); rp, ci, v = h.hsc()
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    diag = np.zeros(len(ci), bool); diag[rp[:-1]] = True
+    scale = np.abs(vo).max()
+    assert np.abs(v[~diag] - vo[~diag]).max() <= 1e-9 * scale
+    iu = np.triu_indices(6)
+    assert np.abs((v[diag][:, iu[0], iu[1]] + lam * (iu[0] == iu[1])) - vo[diag][:, iu[0], iu[1]]).max() <= 1e-9 * scale
+    for name in ("bp", "bsc"):
+        a, b = h.array(name), o.array(name)
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), name
+    assert o.solve() and h.solve_reduced()
+    xo = o.array("xp")
+    assert np.abs(h.array("xp") - xo).max() <= 1e-6 * np.abs(xo).max()
+    q0, t0, X0 = h.state()
+    assert np.array_equal(q0, fp.q) and np.array_equal(t0, fp.t)      # untouched estimates come back in the caller's order
+    h.set_state(q0 * 1.0, t0 + 0.0, X0)
+    assert all(np.array_equal(a, b) for a, b in zip(h.state(), (q0, t0, X0)))
+    # the renumbering really was active: at weak damping the caller's order needs several times the iterations
+    h.set_lambda(1e-9 * md); assert h.solve()
+    hn = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, pose_reorder=0); hn.set_lambda(1e-9 * md); assert hn.solve()
+    assert 1.2 * h.pcg_history()[0][-1] < hn.pcg_history()[0][-1], (h.pcg_history()[0], hn.pcg_history()[0])
+    # a landmark partition set on a renumbered handle: back to the caller's order, same results as a fresh handle
+    ref = OracleSolver(fp, RK_HUBER).optimize(3)["chi2"]
+    h2 = HipSolver(fp, RK_HUBER); h2.build_structure()
+    h2.set_partition(0, fp.Lt)
+    assert np.all(np.abs(h2.optimize(3)["chi2"] - ref) <= CHI2_TOL * ref)
 
 
 def dense_normal_equations(o, fp, lam):
@@ -378,7 +423,8 @@ def test_device_and_host_setup_agree(solvers, small_graph):
              flatten(with_fixed(small_graph, fixed_lm_rows=range(small_graph.nlandmarks))),          # pose-only: no landmark is free
              flatten(shuffled_pose_ids(g_big, seed=3)), flatten(g_big)]
     for fp in cases:
-        a = HipSolver(fp, RK_HUBER); b = HipSolver(fp, RK_HUBER, device_setup=0)
+        # (pose_reorder = 0: the internal renumbering of badly ordered poses exists in the device pipeline only)
+        a = HipSolver(fp, RK_HUBER, pose_reorder=0); b = HipSolver(fp, RK_HUBER, device_setup=0)
         ra, rb = a.optimize(6)["chi2"], b.optimize(6)["chi2"]
         if fp.Pf and fp.Lf:
             (rpa, cia), (rpb, cib) = a.hsc_structure(), b.hsc_structure()
