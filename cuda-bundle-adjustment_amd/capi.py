@@ -102,6 +102,7 @@ def load_library(precision="f64"):
         "cuba_hip_device_pointer": [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "cuba_hip_reduction_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "cuba_hip_get_stream": [H, C.POINTER(C.c_void_p)],
+        "cuba_hip_begin_run": [H],
         "cuba_hip_get_sizes": [H, C.POINTER(C.c_int)],
         "cuba_hip_evaluate_device": [H, C.c_double, C.c_int, C.POINTER(C.c_void_p)],
     }

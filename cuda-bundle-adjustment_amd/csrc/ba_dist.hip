@@ -166,6 +166,7 @@ int cuba_hip_dist_optimize(cuba_hip_dist* d, int niterations, double* chi2_per_i
 		bool haveF = false;
 		void* ev = nullptr;
 		double h[3];
+		SOLVER_TRY(cuba_hip_begin_run(d->s));
 		for (int it = 0; it < niterations; it++)
 		{
 			if (!haveF)

@@ -2047,6 +2047,11 @@ int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5])
 	});
 }
 
+int cuba_hip_begin_run(cuba_hip_solver* s)
+{
+	return guarded(s, [&] { s->need(); s->coarseValid = false; s->runIters.clear(); });
+}
+
 int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream)
 {
 	return guarded(s, [&] { if (!hip_stream) throw ArgError{ "null output" }; *hip_stream = (void*)s->stream; });

@@ -241,6 +241,11 @@ int cuba_hip_device_pointer(cuba_hip_solver* s, int which, void** device_ptr, si
 /* {Pt, Pf, Lt, Lf, E} of the uploaded graph. */
 int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5]);
 
+/* A driver that runs the Levenberg-Marquardt loop itself through the stage calls announces the start of a run (a new lambda_0):
+   the coarse inverse of the two-level preconditioner and the iteration-count predictions of the previous run are dropped, as
+   cuba_hip_optimize does at its start.  Optional (they would be refreshed after one slow solve anyway). */
+int cuba_hip_begin_run(cuba_hip_solver* s);
+
 /* The HIP stream the handle enqueues on (a collective library must order its operations with the solver's kernels). */
 int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream);
 
