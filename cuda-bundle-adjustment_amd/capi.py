@@ -110,6 +110,8 @@ def load_library(precision="f64"):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.cuba_hip_debug_dense_inverse.argtypes = [C.c_int, C.c_int, _dp, _dp]
+    lib.cuba_hip_debug_dense_inverse.restype = C.c_int
     lib.cuba_hip_last_error.argtypes = [H]
     lib.cuba_hip_last_error.restype = C.c_char_p
     lib.cuba_hip_version.restype = C.c_char_p
@@ -120,6 +122,16 @@ def load_library(precision="f64"):
 
 def _d(a):
     return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def dense_inverse(A, precision="f64", device=0):
+    """The library's blocked Gauss-Jordan inversion (coarse level of the preconditioner) applied to an SPD matrix: test hook."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    out = np.zeros_like(A, order="F")
+    rc = load_library(precision).cuba_hip_debug_dense_inverse(int(device), A.shape[0], _d(A), _d(out))
+    if rc != 0:
+        raise CubaHipError(f"cuba_hip_debug_dense_inverse failed with status {rc}")
+    return np.array(out)
 
 
 _live = weakref.WeakSet()

@@ -1672,6 +1672,21 @@ __global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st
 
 constexpr int GJ_B = 32;      // pivot block width of the Gauss-Jordan sweep = output tile edge
 
+// 16 x 16 x 4 matrix-core step in the library's Scalar: v_mfma_f64_16x16x4_f64 (fp64 build) / v_mfma_f32_16x16x4_f32 (fp32 build).
+// Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives 4 results of column l & 15, in rows (l >> 4) + 4 q (f64)
+// or 4 (l >> 4) + q (f32), q = 0..3.
+#ifdef CUBA_HIP_FLOAT32
+typedef float MfmaAcc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MfmaAcc mfma_16x16x4(float a, float b, MfmaAcc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mfma_row(int lane, int q) { return 4 * (lane >> 4) + q; }
+#else
+typedef double MfmaAcc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MfmaAcc mfma_16x16x4(double a, double b, MfmaAcc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mfma_row(int lane, int q) { return (lane >> 4) + 4 * q; }
+#endif
+__device__ __forceinline__ MfmaAcc mfma_zero() { return MfmaAcc{ 0, 0, 0, 0 }; }
+__device__ __forceinline__ Scalar mfma_get(const MfmaAcc& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
 // One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B: dst = GJ_step(src). After the
 // last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile; thread (r, cb) owns the elements (r, cb + 8u),
 // u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32 dependent launches), so:
@@ -1749,18 +1764,24 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 		Scalar (*tmp)[GJ_B + 1] = Dcur; Dcur = Dnext; Dnext = tmp;
 	}
 	TRACE_MARK();
+	// The two 32 x 32 x 32 tile products on the matrix cores: wave w owns the 16 x 16 output tile (w >> 1, w & 1), eight
+	// v_mfma_f64_16x16x4_f64 k-steps each (operands straight from LDS, one number per lane: A[i = lane & 15][k = lane >> 4],
+	// B[k = lane >> 4][j = lane & 15]).  This is the one GEMM-shaped piece of the whole path.
+	const int wv = tid >> 6, lane = tid & 63;
+	const int ti = wv >> 1, tj = wv & 1;
 	// R = Dinv * Apj (not needed by the tiles of the pivot columns)
-	Scalar acc[4] = { 0, 0, 0, 0 };
 	if (!colTile)
 	{
-		for (int m = 0; m < bk; m++)
+		MfmaAcc acc = mfma_zero();
+#pragma unroll
+		for (int s4 = 0; s4 < GJ_B; s4 += 4)
+			acc = mfma_16x16x4(Dcur[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+#pragma unroll
+		for (int q = 0; q < 4; q++)
 		{
-			const Scalar d = Dcur[r][m];
-#pragma unroll
-			for (int u = 0; u < 4; u++) acc[u] += d * Apj[m][cb + 8 * u];
+			const int rr = 16 * ti + mfma_row(lane, q);
+			R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
 		}
-#pragma unroll
-		for (int u = 0; u < 4; u++) R[r][cb + 8 * u] = r < bk ? acc[u] : Scalar(0);
 	}
 	__syncthreads();
 	Scalar out[4];
@@ -1772,20 +1793,22 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	else if (rowTile)
 	{
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = acc[u];
+		for (int u = 0; u < 4; u++) out[u] = R[r][cb + 8 * u];
 	}
 	else
 	{
-		Scalar s2[4] = { 0, 0, 0, 0 };
 		Scalar (*B)[GJ_B + 1] = colTile ? Dcur : R;            // pivot columns: -F Dinv; elsewhere: S - F R
-		for (int k = 0; k < bk; k++)
-		{
-			const Scalar f = F[r][k];
+		MfmaAcc acc = mfma_zero();
 #pragma unroll
-			for (int u = 0; u < 4; u++) s2[u] += f * B[k][cb + 8 * u];
-		}
+		for (int s4 = 0; s4 < GJ_B; s4 += 4)
+			acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+		// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
+		__syncthreads();
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = colTile ? -s2[u] : sv[u] - s2[u];
+		for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
 	}
 #pragma unroll
 	for (int u = 0; u < 4; u++)
@@ -1797,6 +1820,19 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
 }
 
+// blocked Gauss-Jordan sweep: work0 holds the matrix on entry; returns the buffer (work0 or work1) holding the inverse
+Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, hipStream_t s)
+{
+	Scalar* src = work0; Scalar* dst = work1;
+	const int tiles = (n + GJ_B - 1) / GJ_B;
+	for (int p0 = 0; p0 < n; p0 += GJ_B)
+	{
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0));
+		Scalar* tmp = src; src = dst; dst = tmp;
+	}
+	return src;
+}
+
 // Assemble P^T A P from the (already damped) reduced matrix and invert it; returns the buffer (work0 or work1) holding the inverse.
 Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled)
 {
@@ -1804,14 +1840,7 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
 	if (st.nCb) hipLaunchKernelGGL(coarse_assemble_kernel, dim3(st.nCb), dim3(256), 0, s, st, sys, work0, g.Pf);
 	if (assembled) (void)hipEventRecord(assembled, s);      // from here on the sweep no longer reads the reduced matrix
-	Scalar* src = work0; Scalar* dst = work1;
-	const int tiles = (Nc + GJ_B - 1) / GJ_B;
-	for (int p0 = 0; p0 < Nc; p0 += GJ_B)
-	{
-		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles), dim3(256), 0, s, src, dst, Nc, p0, min(GJ_B, Nc - p0));
-		Scalar* tmp = src; src = dst; dst = tmp;
-	}
-	return src;
+	return launch_dense_inverse(work0, work1, Nc, s);
 }
 
 // Fused B(k) of the two-level PCG: [x += alpha p; r -= alpha q;]  rc = P^T r;  z = Minv r + P (Ac^-1 rc);

@@ -148,6 +148,9 @@ void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const Devi
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 // two-level (block-Jacobi + aggregate coarse correction) variant: 3 kernels per iteration
 Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled = nullptr);
+// blocked Gauss-Jordan inversion of a dense SPD n x n matrix (column-major in work0; work1 = scratch of the same size);
+// returns whichever of the two buffers holds the inverse
+Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, hipStream_t s);
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);

@@ -2047,6 +2047,24 @@ int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5])
 	});
 }
 
+int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ainv)
+{
+	if (n <= 0 || !A || !Ainv) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	if (hipSetDevice(device) != hipSuccess) return CUBA_HIP_ERR_NO_DEVICE;
+	try
+	{
+		const size_t nn = (size_t)n * n;
+		std::vector<Scalar> h(A, A + nn);
+		DevBuf<Scalar> w0, w1;
+		w0.upload(h, nullptr); w1.resize(nn);
+		Scalar* res = launch_dense_inverse(w0.data(), w1.data(), n, nullptr);
+		HIP_TRY(hipMemcpy(h.data(), res, sizeof(Scalar) * nn, hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < nn; i++) Ainv[i] = (double)h[i];
+		return CUBA_HIP_OK;
+	}
+	catch (const HipError&) { return CUBA_HIP_ERR_RUNTIME; }
+}
+
 int cuba_hip_begin_run(cuba_hip_solver* s)
 {
 	return guarded(s, [&] { s->need(); s->coarseValid = false; s->runIters.clear(); });

@@ -241,6 +241,10 @@ int cuba_hip_device_pointer(cuba_hip_solver* s, int which, void** device_ptr, si
 /* {Pt, Pf, Lt, Lf, E} of the uploaded graph. */
 int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5]);
 
+/* Test hook for the one dense kernel of the path: the blocked Gauss-Jordan inversion (matrix-core tile products) that builds the
+   coarse inverse of the two-level preconditioner.  A, Ainv: n x n, column-major, SPD input.  No solver handle involved. */
+int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ainv);
+
 /* A driver that runs the Levenberg-Marquardt loop itself through the stage calls announces the start of a run (a new lambda_0):
    the coarse inverse of the two-level preconditioner and the iteration-count predictions of the previous run are dropped, as
    cuba_hip_optimize does at its start.  Optional (they would be refreshed after one slow solve anyway). */

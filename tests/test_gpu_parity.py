@@ -357,3 +357,22 @@ def test_kitti00_shape_properties(solvers):
     assert np.array_equal(res2, res)
     kt = h.time_kernels(5)
     assert all(v > 0 for k, v in kt.items() if k != "pcg_precond")   # merged into pcg_update in the two-level path
+
+
+@pytest.mark.parametrize("n", [20, 32, 50, 96, 672])
+def test_dense_inverse_kernel_matrix_core_tiles(n):
+    """The blocked Gauss-Jordan sweep behind the coarse level (32 x 32 tiles, tile products on v_mfma_f64_16x16x4_f64 /
+    v_mfma_f32_16x16x4_f32) against numpy, on SPD matrices with an ASYMMETRIC-looking spectrum and a short last block."""
+    from cuba_amd.capi import dense_inverse
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    A = (Q * np.logspace(0, 5, n)) @ Q.T
+    A = 0.5 * (A + A.T)
+    ref = np.linalg.inv(A)
+    got = dense_inverse(A)
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert np.abs(got @ A - np.eye(n)).max() <= 1e-7
+    A32 = (Q * np.logspace(0, 2, n)) @ Q.T
+    A32 = 0.5 * (A32 + A32.T)
+    got32 = dense_inverse(A32, precision="f32")
+    assert np.abs(got32 @ A32 - np.eye(n)).max() <= 2e-3
