@@ -302,11 +302,77 @@ def main():
         # (samples/sample_comparison_with_g2o.cpp:74-79, 303-307).  Reported next to `value`, never as `value`.
         if world == 1 and not args.no_end_to_end:
             out["contract_wall"] = contract_wall_leg(args.shape, E)
+    # ---- N > 1, independent-graphs mode: also measure BASELINE config 5's mode -- ONE graph of this shape, landmark-partitioned
+    # over the ranks by the native driver with RCCL all-reduces -- and report it inside the same line as `partitioned`.  It is the
+    # first place a multi-rank RCCL communicator of this library runs, so it is fenced: a watchdog on every rank prints the line
+    # without it and exits if the leg has not finished in time; any exception just drops the object.
+    if world > 1 and not partitioned and os.environ.get("CUBA_BENCH_PARTITION_LEG", "1") != "0":
+        import threading
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out["partitioned"] = {"error": "landmark-partitioned leg did not finish within its time limit"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("CUBA_BENCH_PARTITION_TIMEOUT", "150")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            res = partition_leg(args, dist, backend, rank, world, device_index, rk)
+            if rank == 0 and out is not None:
+                out["partitioned"] = res
+        except Exception as e:   # noqa: BLE001
+            if rank == 0 and out is not None:
+                out["partitioned"] = {"error": repr(e)[:300]}
+        watchdog.cancel()
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def partition_leg(args, dist, backend, rank, world, device_index, rk):
+    """BASELINE config 5's mode on the bench shape: every rank holds the whole graph (seed of the shape), the native driver
+    (libcuba_hip_dist.so) restricts it to its landmark range and all-reduces [Hsc | bsc | bp] once per LM trial."""
+    import torch
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.dist import NativeDist, TorchComm, rccl_unique_id
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import synth_named
+    fp = flatten(synth_named(args.shape))
+    h = HipSolver(fp, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
+    if backend == "nccl":
+        ids = [rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        d = NativeDist(h, fp, rank, world, unique_id=ids[0])
+    else:
+        d = NativeDist(h, fp, rank, world, comm=TorchComm())
+    d.optimize(1)                                   # the protocol's warm-up iteration
+    q0, t0, X0 = h.state()
+    d.optimize(LM_RUN)                              # untimed run (hipGraphs, RCCL channels)
+    runs = 3
+    dist.barrier(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(runs):
+        h.set_state(q0, t0, X0)
+        chi2 = d.optimize(LM_RUN)
+    dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    c = d.counters()
+    res = {"workload": f"ONE ba_{args.shape}-shaped graph, landmark-partitioned over {world} ranks (native driver, "
+                       f"{'RCCL' if backend == 'nccl' else backend} all-reduce of [Hsc|bsc|bp] per trial), {LM_RUN}-iteration LM runs",
+           "scaling": "strong", "wall_ms_10iter": dt * 1e3 / runs, "value": fp.E * LM_RUN * runs / dt, "unit": "edges/s",
+           "final_chi2": float(chi2[-1]), "iterations_done": int(len(chi2)),
+           "allreduce_elements_per_trial": c["large_elements"] // max(c["large_allreduces"], 1)}
+    d.close(); h.close()
+    return res
+
+
 
 
 if __name__ == "__main__":

@@ -209,6 +209,10 @@ def test_bench_independent_graphs_two_ranks_share_one_gpu_over_gloo():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["graphs"] == 2
     assert rec["lm_trials"] == 20 and rec["value"] > 0 and rec["steps"] == 20 and rec["warmup"] == 10
     assert "roofline" in rec and rec["roofline"]["path"]["trials"] == 20
+    # the same line also carries config 5's mode (one graph, landmark-partitioned, native driver) measured in the same invocation
+    part = rec["partitioned"]
+    assert "error" not in part, part
+    assert part["scaling"] == "strong" and part["iterations_done"] == 10 and part["value"] > 0
 
 
 @pytest.mark.gpu
