@@ -468,3 +468,37 @@ def test_readme_known_answer_kitti00(solvers):
         got = h.optimize(10)["chi2"]
         ok.append(len(got) == 10 and np.abs(got - README_CHI2_KITTI00).max() <= 0.051)
     assert any(ok), ok
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graphs_device_setup_host_setup_oracle(solvers, seed):
+    """Small random graphs with the irregularities the set-up code has to survive: random fixed poses / landmarks, landmarks
+    and free poses that lost all their edges (empty segments, diagonal-only block rows), mono-only landmarks, shuffled edge
+    order.  Device-built and host-built structures must give bit-identical runs, and both must follow the oracle."""
+    from conftest import with_fixed
+    HipSolver, OracleSolver = solvers
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.integers(10, 70)); L = int(rng.integers(40, 500)); E = int(L * rng.uniform(2.2, min(4.5, max(2.4, P / 3.0))))
+    g = synth_ba(P, L, E, seed=int(rng.integers(0, 1 << 30)), stereo_frac=float(rng.uniform(0.3, 1.0)))
+    g = with_fixed(g, fixed_pose_rows=rng.choice(P, size=int(rng.integers(0, max(1, P // 5))), replace=False),
+                   fixed_lm_rows=rng.choice(L, size=int(rng.integers(0, max(1, L // 6))), replace=False))
+    fp = flatten(g)
+    # some landmarks (and, for the smaller graphs, one free pose) lose all their edges AFTER the index assignment
+    drop_l = rng.choice(fp.Lt, size=max(1, fp.Lt // 20), replace=False)
+    dead = np.isin(fp.eL, drop_l)
+    if fp.Pf > 3 and seed % 2:
+        dead |= fp.eP == int(rng.integers(1, fp.Pf))
+    keep = np.nonzero(~dead)[0]
+    keep = keep[rng.permutation(len(keep))]                       # and the caller's edge order is arbitrary
+    for name in ("eP", "eL", "eDim", "omega", "meas", "edge_src"):
+        setattr(fp, name, np.ascontiguousarray(getattr(fp, name)[keep]))
+    o = OracleSolver(fp, RK_HUBER); r = o.optimize(5)
+    a = HipSolver(fp, RK_HUBER); b = HipSolver(fp, RK_HUBER, device_setup=0)
+    ra, rb = a.optimize(5)["chi2"], b.optimize(5)["chi2"]
+    assert np.array_equal(ra, rb)
+    assert all(np.array_equal(x, y) for x, y in zip(a.state(), b.state()))
+    assert np.array_equal(a.chi_squares(), b.chi_squares())
+    assert len(ra) == len(r["chi2"]) and np.all(np.abs(ra - r["chi2"]) <= CHI2_TOL * np.maximum(r["chi2"], 1e-30))
+    if fp.Pf and fp.Lf:
+        (rpa, cia), (rpo, cio, _) = a.hsc_structure(), o.hsc()
+        assert np.array_equal(rpa, rpo) and np.array_equal(cia, cio)
