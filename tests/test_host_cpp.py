@@ -149,3 +149,27 @@ def test_cpp_comparison_harness_prints_rmse_within_tolerance(tmp_path, shape):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "compare_with_oracle_cpp_kitti00.txt"), "w") as f:
             f.write(out.stdout)
+
+
+@pytest.mark.gpu
+def test_sample_binary_on_a_graph_with_shuffled_pose_ids(tmp_path):
+    """The C++ API on a graph whose vertex ids do not follow the trajectory (the library renumbers the poses internally, the
+    caller's vertices get their own estimates back): same chi2 as the id-ordered graph -- it is the same physical problem."""
+    import copy
+    from cuba_amd.synth import synth_ba
+    g = synth_ba(120, 6000, 24000, seed=9)
+    rng = np.random.default_rng(4)
+    perm = rng.permutation(g.nposes); perm[perm == 0], perm[0] = perm[0], 0
+    h = copy.deepcopy(g)
+    lut = np.zeros(int(g.pose_ids.max()) + 1, dtype=np.int64); lut[g.pose_ids] = perm
+    h.pose_ids = perm.astype(np.int64); h.mono_vp = lut[g.mono_vp]; h.stereo_vp = lut[g.stereo_vp]
+    exe = os.path.join(HOST, "samples", "sample_ba_from_file")
+    got = {}
+    for name, graph in (("ordered", g), ("shuffled", h)):
+        path = str(tmp_path / f"{name}.json")
+        graph.to_json(path)
+        out = subprocess.run([exe, path, "10", "1"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got[name] = np.array([float(m) for m in re.findall(r"iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
+    assert len(got["ordered"]) == len(got["shuffled"]) == 10
+    assert np.all(np.abs(got["ordered"] - got["shuffled"]) <= 1e-6 * got["ordered"])
