@@ -110,6 +110,10 @@ def load_library(precision="f64"):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.cuba_hip_host_alloc.argtypes = [C.c_size_t]
+    lib.cuba_hip_host_alloc.restype = C.c_void_p
+    lib.cuba_hip_host_free.argtypes = [C.c_void_p]
+    lib.cuba_hip_host_free.restype = None
     lib.cuba_hip_debug_dense_inverse.argtypes = [C.c_int, C.c_int, _dp, _dp]
     lib.cuba_hip_debug_dense_inverse.restype = C.c_int
     lib.cuba_hip_last_error.argtypes = [H]

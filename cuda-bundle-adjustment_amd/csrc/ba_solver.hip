@@ -1738,7 +1738,38 @@ int guarded(cuba_hip_solver* s, F&& f)
 }
 }  // namespace
 
+namespace
+{
+std::mutex g_pinMutex;
+std::vector<void*> g_pinned;      // blocks handed out by cuba_hip_host_alloc that really are page-locked
+}
+
 extern "C" {
+
+void* cuba_hip_host_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	int n = 0;
+	if (bytes && hipGetDeviceCount(&n) == hipSuccess && n > 0 && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p)
+	{
+		std::lock_guard<std::mutex> lk(g_pinMutex);
+		g_pinned.push_back(p);
+		return p;
+	}
+	(void)hipGetLastError();
+	return std::malloc(bytes ? bytes : 1);
+}
+
+void cuba_hip_host_free(void* p)
+{
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> lk(g_pinMutex);
+		auto it = std::find(g_pinned.begin(), g_pinned.end(), p);
+		if (it != g_pinned.end()) { g_pinned.erase(it); (void)hipHostFree(p); return; }
+	}
+	std::free(p);
+}
 
 const char* cuba_hip_version(void) { return sizeof(Scalar) == 8 ? "cuba-hip 0.1 (gfx950, fp64)" : "cuba-hip 0.1 (gfx950, fp32)"; }
 int cuba_hip_scalar_size(void) { return (int)sizeof(Scalar); }

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <map>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -32,6 +33,26 @@ namespace cuba
 {
 namespace
 {
+
+// Staging arrays that cross the C ABI live in page-locked memory (cuba_hip_host_alloc; plain malloc without a device): the
+// 18 MB of measurements a KITTI-00-sized initialize() hands over then move at full PCIe rate.
+template <class T>
+struct PinnedAllocator
+{
+	using value_type = T;
+	PinnedAllocator() = default;
+	template <class U> PinnedAllocator(const PinnedAllocator<U>&) {}
+	T* allocate(size_t n)
+	{
+		void* p = cuba_hip_host_alloc(n * sizeof(T));
+		if (!p) throw std::bad_alloc();
+		return static_cast<T*>(p);
+	}
+	void deallocate(T* p, size_t) { cuba_hip_host_free(p); }
+	template <class U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+	template <class U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+template <class T> using PinnedVector = std::vector<T, PinnedAllocator<T>>;
 
 const char* const kProfileKeys[CUBA_HIP_PROFILE_ITEMS] = {
 	"0: Initialize Optimizer", "1: Build Structure", "2: Compute Error", "3: Build System",
@@ -406,16 +427,16 @@ private:
 	std::vector<LandmarkVertex*> activeLandmarks_;
 	std::vector<BaseEdge*> activeEdges_;
 	int numFreePoses_ = 0, numFreeLandmarks_ = 0;
-	std::vector<double> q_, t_, cam_, Xw_, meas_, omega_;
-	std::vector<int32_t> edgePose_, edgeLandmark_;
-	std::vector<uint8_t> edgeDim_;
+	PinnedVector<double> q_, t_, cam_, Xw_, meas_, omega_;
+	PinnedVector<int32_t> edgePose_, edgeLandmark_;
+	PinnedVector<uint8_t> edgeDim_;
 	bool initialized_ = false, graphDirty_ = false;
 	double initSeconds_ = 0;
 
 	cuba_hip_solver* solver_ = nullptr;
 	BatchStatistics stats_;
 	TimeProfile timeProfile_;
-	std::vector<double> perEdgeChi_;
+	PinnedVector<double> perEdgeChi_;
 	mutable std::unordered_map<const BaseEdge*, double> chiSqs_;
 	mutable bool chiIndexBuilt_ = true;
 	mutable std::vector<BaseEdge*> chiEdges_;   // edge list the pending per-edge results refer to, once initialize() replaced activeEdges_

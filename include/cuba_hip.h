@@ -77,6 +77,12 @@ const char* cuba_hip_version(void);
    arguments of every entry point are double in both builds. */
 int cuba_hip_scalar_size(void);
 
+/* Page-locked host memory for the caller's staging arrays (what it passes to cuba_hip_set_graph / receives from
+   cuba_hip_get_solution / cuba_hip_chi_squares): transfers from it run at full PCIe rate and asynchronously.  Falls back to malloc
+   when no device is visible; cuba_hip_host_free releases either kind.  Optional -- any host pointer is accepted everywhere. */
+void* cuba_hip_host_alloc(size_t bytes);
+void cuba_hip_host_free(void* p);
+
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
