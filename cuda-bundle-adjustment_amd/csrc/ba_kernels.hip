@@ -1286,6 +1286,37 @@ __global__ __launch_bounds__(256) void update_landmarks_kernel(DeviceGraph g, De
 	if (i < g.Lf * 3) g.Xw[i] += sys.xl[i];
 }
 
+// both updates in one launch: the first workgroups take the poses, the rest the landmark coordinates
+__global__ __launch_bounds__(256) void update_state_kernel(DeviceGraph g, DeviceSystem sys, int poseBlocks)
+{
+	if ((int)blockIdx.x < poseBlocks)
+	{
+		const int i = blockIdx.x * 256 + threadIdx.x;
+		if (i >= g.Pf) return;
+		Scalar upd[6], q[4], t[3];
+#pragma unroll
+		for (int k = 0; k < 6; k++) upd[k] = sys.xp[6 * (size_t)i + k];
+#pragma unroll
+		for (int k = 0; k < 4; k++) q[k] = g.q[4 * (size_t)i + k];
+#pragma unroll
+		for (int k = 0; k < 3; k++) t[k] = g.t[3 * (size_t)i + k];
+		pose_exp_update(upd, q, t);
+#pragma unroll
+		for (int k = 0; k < 4; k++) g.q[4 * (size_t)i + k] = q[k];
+#pragma unroll
+		for (int k = 0; k < 3; k++) g.t[3 * (size_t)i + k] = t[k];
+		return;
+	}
+	const int i = (blockIdx.x - poseBlocks) * 256 + threadIdx.x;
+	if (i < g.Lf * 3) g.Xw[i] += sys.xl[i];
+}
+
+void launch_update_state(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s)
+{
+	const int pb = (g.Pf + 255) / 256, lb = (g.Lf * 3 + 255) / 256;
+	if (pb + lb > 0) hipLaunchKernelGGL(update_state_kernel, dim3(pb + lb), dim3(256), 0, s, g, sys, pb);
+}
+
 void launch_update_poses(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s)
 {
 	if (g.Pf > 0) hipLaunchKernelGGL(update_poses_kernel, dim3((g.Pf + 255) / 256), dim3(256), 0, s, g, sys);

@@ -140,6 +140,7 @@ void launch_pose_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lam
 void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
 
 void launch_update_poses(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
+void launch_update_state(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);   // poses + landmarks in one launch
 void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
 
 // block-Jacobi PCG on the upper-BSR reduced system

@@ -898,6 +898,7 @@ struct cuba_hip_solver
 		d_minv.resize((size_t)36 * Pf);
 		d_r.resize((size_t)6 * Pf); d_z.resize((size_t)6 * Pf); d_p0.resize((size_t)6 * Pf); d_p1.resize((size_t)6 * Pf); d_ap.resize((size_t)6 * Pf);
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
+		reducedZeroed = true;
 		for (auto& b : d_coarse) b.resize((size_t)36 * c.cl * c.cl * c.nc * c.nc);
 		d_rc.resize((size_t)12 * c.cl * c.nc); d_r2.resize((size_t)6 * Pf);
 		maxIterAlloc = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
@@ -1296,7 +1297,11 @@ struct cuba_hip_solver
 		return readSlots(0);
 	}
 
-	void zeroReduced() { waitAssembled(); d_red.zero(stream); }
+	// [hsc | bsc | bp] needs zeroing only where a block may have no writer: the atomic Schur kernel accumulates, and a landmark
+	// partition leaves blocks without local products; on the default path the pose pass writes every diagonal block, bp and bsc
+	// and the block pass every off-diagonal block
+	void zeroReduced() { waitAssembled(); if (schurAtomic || partHi >= 0 || !reducedZeroed) { d_red.zero(stream); reducedZeroed = true; } }
+	bool reducedZeroed = false;
 
 	void linearize(int mode, double lam)
 	{
@@ -1515,8 +1520,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 7);
-		launch_update_poses(g, sys, stream);
-		launch_update_landmarks(g, sys, stream);
+		launch_update_state(g, sys, stream);
 	}
 
 	// Stage-API version of sum x (lambda x + b): recomputed from xp/bp and xl/bl, valid for any lambda.
