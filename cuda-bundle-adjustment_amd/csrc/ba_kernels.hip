@@ -1726,7 +1726,7 @@ __device__ __forceinline__ Scalar mfma_get(const MfmaAcc& v, int q) { return q =
 //     (v_rcp_f64 + two Newton steps: the pivots of an SPD matrix are positive and well scaled) per step -- ping-ponging
 //     between two LDS copies so that one barrier per step is enough; a thread keeps its own elements in registers;
 //   * the two 32x32x32 products reuse one LDS operand across the thread's four outputs.
-__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk)
+__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk, int colsPerGroup)
 {
 	__shared__ Scalar D[GJ_B][GJ_B + 1];
 	__shared__ Scalar D2[GJ_B][GJ_B + 1];
@@ -1736,9 +1736,12 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	const int tid = threadIdx.x;
 	TRACE_DECL
 	TRACE_MARK();
-	const int i0 = blockIdx.y * GJ_B, j0 = blockIdx.x * GJ_B;
+	const int tiles = (n + GJ_B - 1) / GJ_B;
+	const int jt0 = blockIdx.x * colsPerGroup, jt1 = min(tiles, jt0 + colsPerGroup);
+	const int i0 = blockIdx.y * GJ_B;
+	int j0 = jt0 * GJ_B;
 	const int r = tid & 31, cb = tid >> 5;
-	const bool rowTile = i0 == p0, colTile = j0 == p0;      // this tile lies in the pivot rows / columns
+	const bool rowTile = i0 == p0;                          // this workgroup's tiles lie in the pivot rows
 	Scalar dv[4], av[4], fv[4], sv[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++)
@@ -1800,52 +1803,82 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	// B[k = lane >> 4][j = lane & 15]).  This is the one GEMM-shaped piece of the whole path.
 	const int wv = tid >> 6, lane = tid & 63;
 	const int ti = wv >> 1, tj = wv & 1;
-	// R = Dinv * Apj (not needed by the tiles of the pivot columns)
-	if (!colTile)
+	// A workgroup walks over colsPerGroup column tiles (1 up to n = 768: the sweep is latency there and the grid small;
+	// more beyond, where a tile per workgroup would run the pivot inversion above in several rounds of workgroups).
+	for (int jt = jt0; jt < jt1; jt++)
 	{
-		MfmaAcc acc = mfma_zero();
-#pragma unroll
-		for (int s4 = 0; s4 < GJ_B; s4 += 4)
-			acc = mfma_16x16x4(Dcur[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
-#pragma unroll
-		for (int q = 0; q < 4; q++)
+		j0 = jt * GJ_B;
+		const bool colTile = j0 == p0;                      // this tile lies in the pivot columns
+		// next column tile of this workgroup: loads in flight under the products of the current one
+		Scalar avN[4], svN[4];
+		if (jt + 1 < jt1)
 		{
-			const int rr = 16 * ti + mfma_row(lane, q);
-			R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const size_t pr = (size_t)min(p0 + r, n - 1), gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + GJ_B + cb + 8 * u, n - 1);
+				avN[u] = src[gj * n + pr];
+				svN[u] = src[gj * n + gi];
+			}
 		}
-	}
-	__syncthreads();
-	Scalar out[4];
-	if (rowTile && colTile)
-	{
+		// R = Dinv * Apj (not needed by the tiles of the pivot columns)
+		if (!colTile)
+		{
+			MfmaAcc acc = mfma_zero();
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = dv[u];
-	}
-	else if (rowTile)
-	{
+			for (int s4 = 0; s4 < GJ_B; s4 += 4)
+				acc = mfma_16x16x4(Dcur[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = R[r][cb + 8 * u];
-	}
-	else
-	{
-		Scalar (*B)[GJ_B + 1] = colTile ? Dcur : R;            // pivot columns: -F Dinv; elsewhere: S - F R
-		MfmaAcc acc = mfma_zero();
-#pragma unroll
-		for (int s4 = 0; s4 < GJ_B; s4 += 4)
-			acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
-		// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
+			for (int q = 0; q < 4; q++)
+			{
+				const int rr = 16 * ti + mfma_row(lane, q);
+				R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
+			}
+		}
 		__syncthreads();
+		Scalar out[4];
+		if (rowTile && colTile)
+		{
 #pragma unroll
-		for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
-		__syncthreads();
+			for (int u = 0; u < 4; u++) out[u] = dv[u];
+		}
+		else if (rowTile)
+		{
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
-	}
+			for (int u = 0; u < 4; u++) out[u] = R[r][cb + 8 * u];
+		}
+		else
+		{
+			Scalar (*B)[GJ_B + 1] = colTile ? Dcur : R;            // pivot columns: -F Dinv; elsewhere: S - F R
+			MfmaAcc acc = mfma_zero();
 #pragma unroll
-	for (int u = 0; u < 4; u++)
-	{
-		const int gi = i0 + r, gj = j0 + cb + 8 * u;
-		if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
+			for (int s4 = 0; s4 < GJ_B; s4 += 4)
+				acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+			// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
+			__syncthreads();
+#pragma unroll
+			for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int gi = i0 + r, gj = j0 + cb + 8 * u;
+			if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
+		}
+		if (jt + 1 < jt1)
+		{
+			__syncthreads();                                   // every reader of Apj / R of this tile is through
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				sv[u] = svN[u];
+				Apj[r][cb + 8 * u] = (r < bk && j0 + GJ_B + cb + 8 * u < n) ? avN[u] : Scalar(0);
+			}
+			__syncthreads();
+		}
 	}
 	TRACE_MARK();
 	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
@@ -1856,9 +1889,14 @@ Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, hipStream_t s)
 {
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (n + GJ_B - 1) / GJ_B;
+	// column tiles per workgroup: enough workgroups to fill 256 CUs once (3 fit a CU by their LDS), no second round
+	int cols = 1;
+	if (const char* e = std::getenv("CUBA_HIP_GJ_COLS")) cols = std::max(1, std::atoi(e));
+	else while (tiles * ((tiles + cols - 1) / cols) > 768) cols++;
+	const int groups = (tiles + cols - 1) / cols;
 	for (int p0 = 0; p0 < n; p0 += GJ_B)
 	{
-		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0));
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols);
 		Scalar* tmp = src; src = dst; dst = tmp;
 	}
 	return src;
