@@ -1456,7 +1456,7 @@ void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const De
 }
 
 // N entries of one lane at once: all 9 N (16-byte) loads are issued before the first use. Padding entries (column -1)
-// read column 0 and are discarded by a select, which keeps the loads of a wave free of branches.
+// read z / p of column 0 against a zero matrix entry.
 template <int N>
 __device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar* pold, const int2 (&e)[3], const Scalar* Arow, int rr, Scalar& accz, Scalar& accp)
 {
@@ -1468,17 +1468,19 @@ __device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar
 		const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + (size_t)n * (20 * 36) + 6 * rr);
 		const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
 		const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
+		// the matrix entry of a padding slot is never fetched (the lanes are masked off for these loads: ~25 % of the
+		// fixed-width slots are padding, and at S2M / G4M size their bytes show); z / p of column 0 are cache hits
+		const bool on = e[n].y >= 0;
 #pragma unroll
-		for (int c = 0; c < 3; c++) { av[n][c] = A2[c]; zv[n][c] = z2[c]; pv[n][c] = p2[c]; }
+		for (int c = 0; c < 3; c++) { av[n][c] = on ? A2[c] : Scalar2{ 0, 0 }; zv[n][c] = z2[c]; pv[n][c] = p2[c]; }
 	}
 #pragma unroll
 	for (int n = 0; n < N; n++)
 	{
-		const bool on = e[n].y >= 0;
 #pragma unroll
 		for (int c = 0; c < 3; c++)
 		{
-			const Scalar a0 = on ? av[n][c].x : Scalar(0), a1 = on ? av[n][c].y : Scalar(0);
+			const Scalar a0 = av[n][c].x, a1 = av[n][c].y;
 			accz += a0 * zv[n][c].x; accp += a0 * pv[n][c].x;
 			accz += a1 * zv[n][c].y; accp += a1 * pv[n][c].y;
 		}
@@ -1599,6 +1601,150 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 	}
 	TRACE_MARK();
 	TRACE_FLUSH(0, blockIdx.x * 2 * ROWS + wv);
+}
+
+// One wave per block row (large graphs).  With two waves per row S2M / G4M need 10 000 / 20 000 waves of ~5 KB each, i.e.
+// 2.5 / 5 rounds of resident waves whose life is two dependent round trips + a barrier: the launch is bound by
+// wave slots x latency, not by bytes.  Here lane (slot, r2) = (lane / 3, lane % 3) takes block rows 2 r2 and 2 r2 + 1 of one of
+// the 20 entry slots: half the waves, twice the bytes per wave, no cross-wave exchange.  Two levels of the fixed-width row are
+// in flight at once (96 VGPRs of operands: occupancy 3); the third level, which few rows have, follows.
+template <int N>
+__device__ __forceinline__ void spmv_batch2(const DeviceSystem& sys, const Scalar* pold, const int2* e, const Scalar* Arow, int r2,
+	Scalar& az0, Scalar& ap0, Scalar& az1, Scalar& ap1)
+{
+	Scalar2 a0v[N][3], a1v[N][3], zv[N][3], pv[N][3];
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+		const size_t j = e[n].y >= 0 ? e[n].y : 0;
+		const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + (size_t)n * (20 * 36) + 12 * r2);
+		const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
+		const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
+		const bool on = e[n].y >= 0;       // padding slots: matrix entry not fetched
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			a0v[n][c] = on ? A2[c] : Scalar2{ 0, 0 }; a1v[n][c] = on ? A2[3 + c] : Scalar2{ 0, 0 };
+			zv[n][c] = z2[c]; pv[n][c] = p2[c];
+		}
+	}
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			az0 += a0v[n][c].x * zv[n][c].x; ap0 += a0v[n][c].x * pv[n][c].x;
+			az0 += a0v[n][c].y * zv[n][c].y; ap0 += a0v[n][c].y * pv[n][c].y;
+			az1 += a1v[n][c].x * zv[n][c].x; ap1 += a1v[n][c].x * pv[n][c].x;
+			az1 += a1v[n][c].y * zv[n][c].y; ap1 += a1v[n][c].y * pv[n][c].y;
+		}
+	}
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	const int lane = threadIdx.x & 63, lr = threadIdx.x >> 6;
+	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
+	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
+	const int row = blockIdx.x * ROWS + lr;
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
+	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
+	const Scalar s_m = load_parts(rz_slot(sys, k - 1), sys.nrz, lane);
+	const bool rowOn = row < g.Pf;
+	const int slot = lane / 3, r2 = lane - 3 * slot;
+	int2 e[3];
+	int a0 = 0, a1 = 0;
+#pragma unroll
+	for (int m = 0; m < 3; m++)
+		e[m] = (rowOn && lane < 60 && m < st.ell_m) ? st.ell[((size_t)row * st.ell_m + m) * 20 + slot] : int2{ 0, -1 };
+	if (rowOn && st.ell_over && lane < 60) { a0 = st.adj_ptr[row] + 20 * st.ell_m + slot; a1 = st.adj_ptr[row + 1]; }
+	Scalar zi = 0, pi_old = 0;
+	if (rowOn && lane < 6)
+	{
+		zi = sys.z[6 * (size_t)row + lane];
+		pi_old = pold[6 * (size_t)row + lane];
+	}
+	k += __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+		return;
+	}
+	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
+	Scalar az0 = 0, ap0 = 0, az1 = 0, ap1 = 0;
+	if (rowOn)
+	{
+		int cnt = 0;                       // wave-uniform: entries of the fullest slot
+#pragma unroll
+		for (int m = 0; m < 3; m++) cnt += __any(e[m].y >= 0) ? 1 : 0;
+		const Scalar* Arow = sys.hrow + 36 * ((size_t)row * st.ell_m * 20 + slot);     // entry (row, m, slot) at + m * 20 * 36
+		if (cnt >= 2) spmv_batch2<2>(sys, pold, e, Arow, r2, az0, ap0, az1, ap1);
+		else if (cnt == 1) spmv_batch2<1>(sys, pold, e, Arow, r2, az0, ap0, az1, ap1);
+		if (cnt == 3) spmv_batch2<1>(sys, pold, e + 2, Arow + 2 * (20 * 36), r2, az0, ap0, az1, ap1);
+		for (int a = a0; a < a1; a += 20)          // rows wider than the fixed part: from the upper-triangular storage
+		{
+			const int bi = st.adj_blk[a];
+			const size_t j = st.adj_col[a];
+			const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
+			const int sr = bi < 0 ? 6 : 1, sc = bi < 0 ? 1 : 6;   // transposed read of the stored upper block for the lower half
+#pragma unroll
+			for (int c = 0; c < 6; c++)
+			{
+				const Scalar zc = sys.z[6 * j + c], pc = pold[6 * j + c];
+				const Scalar b0 = B[(2 * r2) * sr + c * sc], b1 = B[(2 * r2 + 1) * sr + c * sc];
+				az0 += b0 * zc; ap0 += b0 * pc; az1 += b1 * zc; ap1 += b1 * pc;
+			}
+		}
+	}
+	// fold the 20 slots (lanes 3 apart) onto lanes 0..2, then spread the six block rows over lanes 0..5
+	az0 += __shfl_down(az0, 30); ap0 += __shfl_down(ap0, 30); az1 += __shfl_down(az1, 30); ap1 += __shfl_down(ap1, 30);
+	az0 += __shfl_down(az0, 15); ap0 += __shfl_down(ap0, 15); az1 += __shfl_down(az1, 15); ap1 += __shfl_down(ap1, 15);
+	Scalar t0 = az0, u0 = ap0, t1 = az1, u1 = ap1;
+#pragma unroll
+	for (int d = 3; d <= 12; d += 3) { t0 += __shfl_down(az0, d); u0 += __shfl_down(ap0, d); t1 += __shfl_down(az1, d); u1 += __shfl_down(ap1, d); }
+	const Scalar tzA = __shfl(t0, lane >> 1), tzB = __shfl(t1, lane >> 1), tpA = __shfl(u0, lane >> 1), tpB = __shfl(u1, lane >> 1);
+	const Scalar tz = (lane & 1) ? tzB : tzA, tp = (lane & 1) ? tpB : tpA;
+	__shared__ Scalar qrow[ROWS][6];
+	__shared__ Scalar part[ROWS];
+	Scalar q = 0, dot = 0;
+	if (rowOn && lane < 6)
+	{
+		const Scalar pi = zi + beta * pi_old;
+		q = tz + beta * tp;
+		pnew[6 * (size_t)row + lane] = pi;
+		sys.ap[6 * (size_t)row + lane] = q;
+		dot = pi * q;
+	}
+	if (lane < 6) qrow[lr][lane] = q;
+	dot = wave_sum(dot);
+	if (lane == 0) part[lr] = dot;
+	__syncthreads();
+	if (threadIdx.x < 6 * sys.cl)   // (weighted) row sums of q over this workgroup's rows: the two-level kernel builds P^T q from these
+	{
+		const int a = threadIdx.x / 6, c = threadIdx.x - 6 * a;
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < ROWS; w++)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		if (sys.qpart && sys.agg > 0)
+		{
+			const int per = sys.agg / ROWS, J = blockIdx.x / per, m = blockIdx.x - J * per;
+			sys.qpart[(size_t)m * (6 * sys.cl * sys.nc) + 6 * sys.cl * J + threadIdx.x] = s2;
+		}
+	}
+	if (threadIdx.x == 64)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < ROWS; w++) s2 += part[w];
+		pq_slot(sys, k)[blockIdx.x] = s2;
+	}
 }
 
 // B(k): alpha = rz[k]/pq[k]; x += alpha p; r -= alpha q; z = Minv r; rz[k+1] += r.z
@@ -1967,8 +2113,6 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const int own0 = 6 * I * sys.agg;
 	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
 	const int per = sys.agg / sys.spmv_rows;             // SpMV workgroups per aggregate
-	const int J = t / CD;                               // aggregate of the first (usually only) coarse unknown of this thread
-	const int g0 = J * per, g1 = min(sys.npq, g0 + per);
 	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
 	Scalar pre_r = 0, pre_q = 0, pre_p = 0, pre_x = 0, pre_m[6] = { 0, 0, 0, 0, 0, 0 };   // own rows
 	Scalar sr = 0, qv[QV];                               // restricted sums
@@ -2007,7 +2151,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			// compiler merge registers after each one and wait for it
 #pragma unroll
 			for (int m = 0; m < QV; m++)
-				if (m < per) qv[m] = sys.qpart[(size_t)max(0, min(m, g1 - g0 - 1)) * Nc + t];      // (m < per is uniform over the grid)
+				if (m < per) qv[m] = sys.qpart[(size_t)m * Nc + t];      // (m < per is uniform over the grid; sets of workgroups that do not exist stay zero)
 		}
 	}
 #pragma unroll
@@ -2044,21 +2188,21 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		Scalar s1 = 0, s2 = 0;
 		if (doUpdate)
 		{
-			const int h0 = Jj * per, h1 = min(sys.npq, h0 + per);
 			if (jc == t)
 			{
 				s1 = sr;
 #pragma unroll
-				for (int m = 0; m < QV; m++) s2 += h0 + m < h1 ? qv[m] : Scalar(0);
+				for (int m = 0; m < QV; m++) s2 += qv[m];
 			}
 			else s1 = rcin[jc];
-			for (int gq = h0 + (jc == t ? QV : 0); gq < h1; gq += QV)      // further unknowns of this thread (large graphs): QV loads per trip
+			for (int m0 = jc == t ? QV : 0; m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
 			{
 				Scalar qx[QV];
+				const Scalar* src = sys.qpart + (size_t)m0 * Nc + jc;
 #pragma unroll
-				for (int m = 0; m < QV; m++) qx[m] = sys.qpart[(size_t)min(gq + m - h0, h1 - h0 - 1) * Nc + jc];
+				for (int m = 0; m < QV; m++) qx[m] = m0 + m < per ? src[(size_t)m * Nc] : Scalar(0);      // uniform condition
 #pragma unroll
-				for (int m = 0; m < QV; m++) s2 += gq + m < h1 ? qx[m] : Scalar(0);
+				for (int m = 0; m < QV; m++) s2 += qx[m];
 			}
 		}
 		else
@@ -2204,17 +2348,23 @@ int spmv_rows_for(int Pf)
 	if (const char* e = std::getenv("CUBA_HIP_SPMV_ROWS")) { const int r = std::atoi(e); return r == 8 ? 8 : r == 4 ? 4 : 2; }     // A/B knob
 	return 2 * (long long)Pf > 3 * 1024 ? 4 : 2;
 }                            // (the 4-row workgroup needs the 128-VGPR instantiation)
+static bool spmv_row_per_wave(const DeviceSystem& sys)
+{
+	static const bool off = std::getenv("CUBA_HIP_SPMV_TWO_WAVES") != nullptr;     // A/B knob
+	return sys.spmv_rows >= 4 && !off;
+}
 static void* spmv_kernel_for(const DeviceGraph& g, const DeviceSystem& sys)
 {
-	if (sys.spmv_rows == 8) return (void*)pcg_spmv_kernel<8, 1>;
-	if (sys.spmv_rows == 4) return (void*)pcg_spmv_kernel<4, 4>;
+	if (sys.spmv_rows == 8) return spmv_row_per_wave(sys) ? (void*)pcg_spmv_row_kernel<8> : (void*)pcg_spmv_kernel<8, 1>;
+	if (sys.spmv_rows == 4) return spmv_row_per_wave(sys) ? (void*)pcg_spmv_row_kernel<4> : (void*)pcg_spmv_kernel<4, 4>;
 	return spmv_wants_occupancy(g) ? (void*)pcg_spmv_kernel<2, 4> : (void*)pcg_spmv_kernel<2, 1>;
 }
+static dim3 spmv_block_for(const DeviceSystem& sys) { return dim3((spmv_row_per_wave(sys) ? 64 : 128) * sys.spmv_rows); }
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	const dim3 grid((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), block(128 * sys.spmv_rows);
-	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar))spmv_kernel_for(g, sys), grid, block, 0, s, g, st, sys, k, maxIter, tol2);
+	const dim3 grid((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows);
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar))spmv_kernel_for(g, sys), grid, spmv_block_for(sys), 0, s, g, st, sys, k, maxIter, tol2);
 }
 
 void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -2285,7 +2435,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 	hipError_t e = hipSuccess;
 	for (int k = 0; k < chunk && e == hipSuccess; k++)
 	{
-		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), dim3(128 * sys.spmv_rows), 0, g, st, sys, k, maxIter, tol2);
+		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{

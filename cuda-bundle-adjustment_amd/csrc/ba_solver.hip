@@ -934,6 +934,7 @@ struct cuba_hip_solver
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
 		d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
+		d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
 		sys.spmv_rows = spmvRows;
 		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
