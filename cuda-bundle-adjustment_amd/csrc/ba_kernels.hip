@@ -2087,7 +2087,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
 	constexpr int QV = 16;             // SpMV-workgroup partials prefetched per coarse unknown
-	extern __shared__ unsigned char pcg2_lds[];
+	extern __shared__ __align__(16) unsigned char pcg2_lds[];
 	const int Nc = CD * sys.nc;
 	Scalar* sR = reinterpret_cast<Scalar*>(pcg2_lds);
 	Scalar* sQ = sR + Nc;
@@ -2115,7 +2115,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const int per = sys.agg / sys.spmv_rows;             // SpMV workgroups per aggregate
 	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
 	Scalar pre_r = 0, pre_q = 0, pre_p = 0, pre_x = 0, pre_m[6] = { 0, 0, 0, 0, 0, 0 };   // own rows
-	Scalar sr = 0, qv[QV];                               // restricted sums
+	Scalar2 sr = { 0, 0 }, qv[QV];                       // restricted sums: thread t takes the coarse unknowns 2 t, 2 t + 1 (Nc is even)
 	// coarse inverse: rows CD I .. CD I + CD - 1 (= columns: symmetric, contiguous).  Wave w applies rows w, w + 8 (< CD) to
 	// the whole coarse vector -- lane l takes the columns l, l + 64, ... -- so that a row costs ONE wave reduction in one
 	// wave (a thread-per-column layout needs CD reductions in every wave plus a cross-wave stage).
@@ -2125,7 +2125,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	// instruction on the workgroup's one CU, which is what bounds this kernel
 	Scalar2 ainv[AR][AC];
 #pragma unroll
-	for (int m = 0; m < QV; m++) qv[m] = 0;
+	for (int m = 0; m < QV; m++) qv[m] = Scalar2{ 0, 0 };
 	if (doUpdate)
 	{
 		if (t < sys.nrz) e_k = rz_slot(sys, k)[t];
@@ -2142,17 +2142,12 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 		for (int c = 0; c < 6; c++) pre_m[c] = sys.minv[36 * pose + c * 6 + comp];
 	}
-	if (t < Nc)
+	if (doUpdate && 2 * t < Nc)
 	{
-		if (doUpdate)
-		{
-			sr = rcin[t];
-			// unconditional loads from clamped addresses (selected below): a predicated load per element makes the
-			// compiler merge registers after each one and wait for it
+		sr = *reinterpret_cast<const Scalar2*>(rcin + 2 * t);
 #pragma unroll
-			for (int m = 0; m < QV; m++)
-				if (m < per) qv[m] = sys.qpart[(size_t)m * Nc + t];      // (m < per is uniform over the grid; sets of workgroups that do not exist stay zero)
-		}
+		for (int m = 0; m < QV; m++)      // (m < per is uniform over the grid; sets of workgroups that do not exist stay zero)
+			if (m < per) qv[m] = *reinterpret_cast<const Scalar2*>(sys.qpart + (size_t)m * Nc + 2 * t);
 	}
 #pragma unroll
 	for (int a = 0; a < AR; a++)
@@ -2182,33 +2177,39 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		qown[w] = doUpdate ? sys.ap[own0 + w] : Scalar(0);
 	}
 	// restricted sums P^T r_k and P^T q_k (fixed summation order => reproducible)
-	for (int jc = t; jc < Nc; jc += PCG2_T)
+	if (doUpdate)
 	{
-		const int Jj = jc / CD, rem = jc - CD * Jj;
-		Scalar s1 = 0, s2 = 0;
-		if (doUpdate)
+		for (int pj = t; 2 * pj < Nc; pj += PCG2_T)
 		{
-			if (jc == t)
+			Scalar2 s1, s2 = { 0, 0 };
+			if (pj == t)
 			{
 				s1 = sr;
 #pragma unroll
 				for (int m = 0; m < QV; m++) s2 += qv[m];
 			}
-			else s1 = rcin[jc];
-			for (int m0 = jc == t ? QV : 0; m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
+			else s1 = *reinterpret_cast<const Scalar2*>(rcin + 2 * pj);
+			for (int m0 = pj == t ? QV : 0; m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
 			{
-				Scalar qx[QV];
-				const Scalar* src = sys.qpart + (size_t)m0 * Nc + jc;
+				Scalar2 qx[QV];
+				const Scalar* src = sys.qpart + (size_t)m0 * Nc + 2 * pj;
 #pragma unroll
-				for (int m = 0; m < QV; m++) qx[m] = m0 + m < per ? src[(size_t)m * Nc] : Scalar(0);      // uniform condition
+				for (int m = 0; m < QV; m++) qx[m] = m0 + m < per ? *reinterpret_cast<const Scalar2*>(src + (size_t)m * Nc) : Scalar2{ 0, 0 };      // uniform condition
 #pragma unroll
 				for (int m = 0; m < QV; m++) s2 += qx[m];
 			}
+			*reinterpret_cast<Scalar2*>(sR + 2 * pj) = s1;
+			*reinterpret_cast<Scalar2*>(sQ + 2 * pj) = s2;
 		}
-		else
+	}
+	else
+	{
+		for (int jc = t; jc < Nc; jc += PCG2_T)       // once per solve: P^T r_0 from the residual itself
 		{
+			const int Jj = jc / CD, rem = jc - CD * Jj;
 			const int a = rem / 6, c = rem - 6 * a;
 			const int i0 = Jj * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+			Scalar s1 = 0;
 			for (int i = i0; i < i1; i += 8)
 			{
 				Scalar rv[8];
@@ -2217,8 +2218,8 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 				for (int m = 0; m < 8; m++) s1 += (a == 0 ? Scalar(1) : agg_weight_local(Jj, i + m - i0, sys, g.Pf)) * rv[m];
 			}
+			sR[jc] = s1; sQ[jc] = 0;
 		}
-		sR[jc] = s1; sQ[jc] = s2;
 	}
 	TRACE_MARK();
 	a_k = wave_sum(a_k); a_0 = wave_sum(a_0); a_q = wave_sum(a_q);
