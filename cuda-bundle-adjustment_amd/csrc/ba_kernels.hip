@@ -1864,15 +1864,96 @@ __device__ __forceinline__ int mfma_row(int lane, int q) { return (lane >> 4) + 
 __device__ __forceinline__ MfmaAcc mfma_zero() { return MfmaAcc{ 0, 0, 0, 0 }; }
 __device__ __forceinline__ Scalar mfma_get(const MfmaAcc& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
+// Inverse of the 32 x 32 block a 256-thread workgroup holds as Dcur[r][c] in LDS (Dnext: identity outside [0, bk)^2): 2x2 block
+// pivots -- 16 dependent steps instead of 32, one reciprocal (v_rcp_f64 + two Newton steps: the pivots of an SPD matrix are
+// positive and well scaled) per step -- ping-ponging between the two LDS copies so that one barrier per step is enough.
+// Returns the array holding the result (callers synchronise before reading it: the last step ends with a barrier).
+// The chain is instruction issue + latency of one wave per SIMD (every element changes in every step), so the thread -> element
+// map is chosen for the fewest instructions: thread (c, rb) = (tid & 31, tid >> 5) owns rows rb + 8u of column c, hence one
+// (W D[P][c]) pair per thread instead of one per element, and whether a row is a pivot row is uniform over a wave (rows rb + 8u,
+// rb in {2w, 2w + 1}: the pivot rows p, p + 1 are the element u = p / 8 of wave w = (p mod 8) / 2) -- a scalar branch, no selects.
+__device__ __forceinline__ Scalar (*gj_pivot_inverse(Scalar (*Dcur)[GJ_B + 1], Scalar (*Dnext)[GJ_B + 1], int tid, int bk))[GJ_B + 1]
+{
+	const int c = tid & 31, rb = tid >> 5;
+	const int wv2 = 2 * __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int bkPad = (bk + 1) & ~1;
+	Scalar d[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) d[u] = Dcur[rb + 8 * u][c];
+	for (int p = 0; p < bkPad; p += 2)
+	{
+		const Scalar a00 = Dcur[p][p], a01 = Dcur[p][p + 1], a10 = Dcur[p + 1][p], a11 = Dcur[p + 1][p + 1];
+		const Scalar m0 = Dcur[p][c], m1 = Dcur[p + 1][c];
+		Scalar mi0[4], mi1[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { mi0[u] = Dcur[rb + 8 * u][p]; mi1[u] = Dcur[rb + 8 * u][p + 1]; }
+		const Scalar rdet = fast_rcp(a00 * a11 - a01 * a10);
+		const Scalar w00 = a11 * rdet, w01 = -a01 * rdet, w10 = -a10 * rdet, w11 = a00 * rdet;     // W = inverse of the 2x2 pivot block
+		const Scalar t0 = w00 * m0 + w01 * m1, t1 = w10 * m0 + w11 * m1;                           // (W D[P][c])
+		const bool jp = c == p || c == p + 1;
+		const Scalar wA = c == p ? w00 : w01, wB = c == p ? w10 : w11;                              // column c - p of W
+		const bool pivotWave = (p & 7) == wv2;                                                        // (scalar)
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int r = rb + 8 * u;
+			Scalar v;
+			if (pivotWave && u == (p >> 3))          // rows p (rb even) and p + 1 (rb odd)
+			{
+				const Scalar vRow = r == p ? t0 : t1;
+				const Scalar vBoth = r == p ? wA : wB;
+				v = jp ? vBoth : vRow;
+			}
+			else
+			{
+				const Scalar vGen = d[u] - (mi0[u] * t0 + mi1[u] * t1);
+				const Scalar vCol = -(mi0[u] * wA + mi1[u] * wB);
+				v = jp ? vCol : vGen;
+			}
+			if (r < bkPad && c < bkPad) { d[u] = v; Dnext[r][c] = v; }
+		}
+		__syncthreads();
+		Scalar (*tmp)[GJ_B + 1] = Dcur; Dcur = Dnext; Dnext = tmp;
+	}
+	return Dcur;
+}
+
+// Inverse of the first pivot block (rows / columns [0, bk)) of the sweep -> pivOut[c * 32 + r]; every later pivot block is
+// inverted by the step before it (below).
+__global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar* __restrict__ src, int n, int bk, Scalar* __restrict__ pivOut)
+{
+	__shared__ Scalar D[GJ_B][GJ_B + 1];
+	__shared__ Scalar D2[GJ_B][GJ_B + 1];
+	const int tid = threadIdx.x, r = tid & 31, cb = tid >> 5;
+	Scalar dv[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) dv[u] = src[(size_t)min(cb + 8 * u, n - 1) * n + min(r, n - 1)];
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u;
+		dv[u] = (r < bk && c < bk) ? dv[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short block
+		D[r][c] = dv[u];
+		D2[r][c] = r == c ? Scalar(1) : Scalar(0);
+	}
+	__syncthreads();
+	Scalar (*res)[GJ_B + 1] = gj_pivot_inverse(D, D2, tid, bk);
+#pragma unroll
+	for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
+}
+
 // One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B: dst = GJ_step(src). After the
-// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile; thread (r, cb) owns the elements (r, cb + 8u),
-// u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32 dependent launches), so:
+// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile (or per colsPerGroup tiles of one tile row); thread
+// (r, cb) owns the elements (r, cb + 8u), u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32
+// dependent launches), so:
 //   * every global load of the kernel is issued before the first use (clamped addresses, selected afterwards);
-//   * the pivot block is inverted with 2x2 block pivots -- 16 dependent steps instead of 32, one reciprocal
-//     (v_rcp_f64 + two Newton steps: the pivots of an SPD matrix are positive and well scaled) per step -- ping-ponging
-//     between two LDS copies so that one barrier per step is enough; a thread keeps its own elements in registers;
-//   * the two 32x32x32 products reuse one LDS operand across the thread's four outputs.
-__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk, int colsPerGroup)
+//   * the inverse of the pivot block comes in ready-made (pivIn): the workgroup that produced the NEXT pivot block in the
+//     previous step -- tile (p0/32 + 1, p0/32 + 1) is final for this purpose once step p0 has updated it -- inverted it right
+//     away (look-ahead).  One workgroup runs the 16-step chain per launch instead of all of them (twice as slow when two
+//     workgroups share a CU), and it has its CU nearly to itself by then: 15.9 -> ~10 us per step;
+//   * the two 32x32x32 products run on the matrix cores.
+__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk, int colsPerGroup,
+	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
 {
 	__shared__ Scalar D[GJ_B][GJ_B + 1];
 	__shared__ Scalar D2[GJ_B][GJ_B + 1];
@@ -1888,14 +1969,16 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	int j0 = jt0 * GJ_B;
 	const int r = tid & 31, cb = tid >> 5;
 	const bool rowTile = i0 == p0;                          // this workgroup's tiles lie in the pivot rows
-	Scalar dv[4], av[4], fv[4], sv[4];
+	const int pNext = p0 + GJ_B;                            // look-ahead: the tile (pNext, pNext) is the next pivot block
+	const bool aheadRow = i0 == pNext && pNext < n;
+	Scalar dv[4], av[4], fv[4], sv[4], keep[4] = { 0, 0, 0, 0 };
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 	{
 		const int c = cb + 8 * u;
 		const size_t pr = (size_t)min(p0 + r, n - 1), pc = (size_t)min(p0 + c, n - 1);
 		const size_t gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + c, n - 1);
-		dv[u] = src[pc * n + pr];      // D[r][c]   = A[p0+r, p0+c]
+		dv[u] = pivIn[c * GJ_B + r];   // D[r][c]   = inverse of the pivot block A[p0.., p0..]
 		av[u] = src[gj * n + pr];      // Apj[r][c] = A[p0+r, j0+c]
 		fv[u] = src[pc * n + gi];      // F[r][c]   = A[i0+r, p0+c]
 		sv[u] = src[gj * n + gi];      // own tile
@@ -1904,53 +1987,20 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	for (int u = 0; u < 4; u++)
 	{
 		const int c = cb + 8 * u;
-		dv[u] = (r < bk && c < bk) ? dv[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short last block
 		D[r][c] = dv[u];
-		D2[r][c] = r == c ? Scalar(1) : Scalar(0);
 		Apj[r][c] = (r < bk && j0 + c < n) ? av[u] : Scalar(0);
 		F[r][c] = (c < bk && i0 + r < n) ? fv[u] : Scalar(0);
 	}
 	__syncthreads();
 	TRACE_MARK();
-	Scalar (*Dcur)[GJ_B + 1] = D, (*Dnext)[GJ_B + 1] = D2;
-	const int bkPad = (bk + 1) & ~1;
-	for (int p = 0; p < bkPad; p += 2)
-	{
-		const Scalar a00 = Dcur[p][p], a01 = Dcur[p][p + 1], a10 = Dcur[p + 1][p], a11 = Dcur[p + 1][p + 1];
-		const Scalar mi0 = Dcur[r][p], mi1 = Dcur[r][p + 1];
-		Scalar m0[4], m1[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) { m0[u] = Dcur[p][cb + 8 * u]; m1[u] = Dcur[p + 1][cb + 8 * u]; }
-		const Scalar rdet = fast_rcp(a00 * a11 - a01 * a10);
-		const Scalar w00 = a11 * rdet, w01 = -a01 * rdet, w10 = -a10 * rdet, w11 = a00 * rdet;     // W = inverse of the 2x2 pivot block
-		const bool ip = r == p || r == p + 1;
-#pragma unroll
-		for (int u = 0; u < 4; u++)
-		{
-			const int c = cb + 8 * u;
-			const bool jp = c == p || c == p + 1;
-			const Scalar t0 = w00 * m0[u] + w01 * m1[u], t1 = w10 * m0[u] + w11 * m1[u];   // (W D[P][j])
-			// all four cases are computed and selected (lanes of a wave fall into different ones: branches would
-			// run them one after the other)
-			const Scalar wA = c == p ? w00 : w01, wB = c == p ? w10 : w11;                  // column c - p of W
-			const Scalar vGen = dv[u] - (mi0 * t0 + mi1 * t1);
-			const Scalar vRow = r == p ? t0 : t1;
-			const Scalar vCol = -(mi0 * wA + mi1 * wB);
-			const Scalar vBoth = r == p ? wA : wB;
-			const Scalar v = ip ? (jp ? vBoth : vRow) : (jp ? vCol : vGen);
-			if (r < bkPad && c < bkPad) { dv[u] = v; Dnext[r][c] = v; }
-		}
-		__syncthreads();
-		Scalar (*tmp)[GJ_B + 1] = Dcur; Dcur = Dnext; Dnext = tmp;
-	}
-	TRACE_MARK();
+	Scalar (*Dcur)[GJ_B + 1] = D;
 	// The two 32 x 32 x 32 tile products on the matrix cores: wave w owns the 16 x 16 output tile (w >> 1, w & 1), eight
 	// v_mfma_f64_16x16x4_f64 k-steps each (operands straight from LDS, one number per lane: A[i = lane & 15][k = lane >> 4],
 	// B[k = lane >> 4][j = lane & 15]).  This is the one GEMM-shaped piece of the whole path.
 	const int wv = tid >> 6, lane = tid & 63;
 	const int ti = wv >> 1, tj = wv & 1;
 	// A workgroup walks over colsPerGroup column tiles (1 up to n = 768: the sweep is latency there and the grid small;
-	// more beyond, where a tile per workgroup would run the pivot inversion above in several rounds of workgroups).
+	// more beyond).
 	for (int jt = jt0; jt < jt1; jt++)
 	{
 		j0 = jt * GJ_B;
@@ -2014,6 +2064,11 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 			const int gi = i0 + r, gj = j0 + cb + 8 * u;
 			if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
 		}
+		if (aheadRow && j0 == pNext)                        // (uniform over the workgroup)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++) keep[u] = out[u];
+		}
 		if (jt + 1 < jt1)
 		{
 			__syncthreads();                                   // every reader of Apj / R of this tile is through
@@ -2027,11 +2082,34 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 		}
 	}
 	TRACE_MARK();
+	// look-ahead: this workgroup produced the next pivot block -> invert it for the next launch
+	if (aheadRow && jt0 * GJ_B <= pNext && pNext < jt1 * GJ_B)
+	{
+		const int bkN = min(GJ_B, n - pNext);
+		__syncthreads();                                       // D (the current inverse) is no longer an operand
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int c = cb + 8 * u;
+			keep[u] = (r < bkN && c < bkN) ? keep[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short last block
+			D[r][c] = keep[u];
+			D2[r][c] = r == c ? Scalar(1) : Scalar(0);
+		}
+		__syncthreads();
+		Scalar (*res)[GJ_B + 1] = gj_pivot_inverse(D, D2, tid, bkN);
+#pragma unroll
+		for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
+		TRACE_MARK();
+		TRACE_FLUSH(2, 8000 + (threadIdx.x >> 6));          // (kept apart: the last launch of a sweep has no look-ahead workgroup)
+		return;
+	}
+	TRACE_MARK();
 	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
 }
 
-// blocked Gauss-Jordan sweep: work0 holds the matrix on entry; returns the buffer (work0 or work1) holding the inverse
-Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, hipStream_t s)
+// blocked Gauss-Jordan sweep: work0 holds the matrix on entry; returns the buffer (work0 or work1) holding the inverse.
+// pivots: 2 x 32 x 32 numbers of scratch (the inverse of the current / of the next pivot block)
+Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s)
 {
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (n + GJ_B - 1) / GJ_B;
@@ -2040,10 +2118,13 @@ Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, hipStream_t s)
 	if (const char* e = std::getenv("CUBA_HIP_GJ_COLS")) cols = std::max(1, std::atoi(e));
 	else while (tiles * ((tiles + cols - 1) / cols) > 768) cols++;
 	const int groups = (tiles + cols - 1) / cols;
+	Scalar* pivIn = pivots; Scalar* pivOut = pivots + GJ_B * GJ_B;
+	hipLaunchKernelGGL(dense_gj_first_pivot_kernel, dim3(1), dim3(256), 0, s, src, n, min(GJ_B, n), pivIn);
 	for (int p0 = 0; p0 < n; p0 += GJ_B)
 	{
-		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols);
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols, pivIn, pivOut);
 		Scalar* tmp = src; src = dst; dst = tmp;
+		tmp = pivIn; pivIn = pivOut; pivOut = tmp;
 	}
 	return src;
 }
@@ -2055,7 +2136,7 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
 	if (st.nCb) hipLaunchKernelGGL(coarse_assemble_kernel, dim3(st.nCb), dim3(256), 0, s, st, sys, work0, g.Pf);
 	if (assembled) (void)hipEventRecord(assembled, s);      // from here on the sweep no longer reads the reduced matrix
-	return launch_dense_inverse(work0, work1, Nc, s);
+	return launch_dense_inverse(work0, work1, Nc, sys.gj_pivots, s);
 }
 
 // Fused B(k) of the two-level PCG: [x += alpha p; r -= alpha q;]  rc = P^T r;  z = Minv r + P (Ac^-1 rc);

@@ -106,6 +106,7 @@ struct DeviceSystem
 	int cl = 1;                // coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose
 	                           // index (coarse dimension = 6*cl*nc)
 	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
+	Scalar* gj_pivots = nullptr;   // [2][32 x 32] scratch of the Gauss-Jordan sweep (inverse of the current / next pivot block)
 	Scalar* rc = nullptr;      // [2*6nc] restricted residual P^T r_k, ping-pong by the parity of k like r / r2 (each
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
 	Scalar* hrow = nullptr;    // [36 * 20 * ell_m * Pf] row-ordered copy of Hsc for the SpMV (launch_hsc_expand), entry (row, m, slot)
@@ -151,7 +152,7 @@ void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const De
 Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled = nullptr);
 // blocked Gauss-Jordan inversion of a dense SPD n x n matrix (column-major in work0; work1 = scratch of the same size);
 // returns whichever of the two buffers holds the inverse
-Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, hipStream_t s);
+Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);

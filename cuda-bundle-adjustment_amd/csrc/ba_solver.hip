@@ -151,7 +151,7 @@ struct cuba_hip_solver
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
-	DevBuf<Scalar> d_coarse[3], d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
+	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -933,7 +933,8 @@ struct cuba_hip_solver
 		sys.rzStride = rzStrideCfg; sys.pqStride = pqStrideCfg; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
-		d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
+		d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); d_gjPivots.resize(2 * 32 * 32); sys.gj_pivots = d_gjPivots.data();
+		sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 		d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
 		sys.spmv_rows = spmvRows;
@@ -2093,7 +2094,8 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 		std::vector<Scalar> h(A, A + nn);
 		DevBuf<Scalar> w0, w1;
 		w0.upload(h, nullptr); w1.resize(nn);
-		Scalar* res = launch_dense_inverse(w0.data(), w1.data(), n, nullptr);
+		DevBuf<Scalar> piv; piv.resize(2 * 32 * 32);
+		Scalar* res = launch_dense_inverse(w0.data(), w1.data(), n, piv.data(), nullptr);
 		HIP_TRY(hipMemcpy(h.data(), res, sizeof(Scalar) * nn, hipMemcpyDeviceToHost));
 		for (size_t i = 0; i < nn; i++) Ainv[i] = (double)h[i];
 		return CUBA_HIP_OK;

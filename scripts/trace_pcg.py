@@ -29,8 +29,13 @@ rc = lib.cuba_hip_debug_read_trace(buf.ctypes.data_as(C.c_void_p))
 assert rc == 0, rc
 for kid, name, stages in ((0, "pcg_spmv", ["entry", "indices+scalars", "operands", "fold+barrier", "end"]),
                           (1, "pcg2_fused", ["entry", "loads landed", "restricted sums", "barrier 1", "barrier yc", "end"]),
-                          (2, "dense_gj_step (last step)", ["entry", "tile loads", "pivot block inverse", "end"])):
+                          (2, "dense_gj_step (last launch that has a look-ahead workgroup... the last step has none)", ["entry", "tile loads", "tiles done", "end (look-ahead chain in one workgroup)"])):
     t = buf[kid].astype(np.int64)
+    if kid == 2:
+        la = t[8000:8004]
+        print("dense_gj_step, look-ahead workgroup (4 waves): ns since entry at [loads, tiles done, chain done]:",
+              [[int((w[s] - w[0]) * 10) for s in (1, 2, 3)] for w in la if w[0] > 0])
+        t = t[:8000]
     on = t[:, 0] > 0
     t = t[on]
     n = len(stages)
