@@ -232,8 +232,11 @@ struct cuba_hip_solver
 	bool coarseValid = false, coarseFresh = false;
 	// overlapped refresh: while the PCG of trial k runs (with the inverse built from trial k-1's matrix), a second stream
 	// assembles and inverts trial k's coarse matrix for trial k+1
-	bool coarseOverlap = false;   // measured: the concurrent sweep slows the latency-bound PCG kernels by ~15 %, which costs more than
-	                              // the hidden inversions save (scripts/overlap_ab.py: 12.2 vs 11.9 ms KITTI-00, 43.9 vs 42.8 ms S2M) -> off
+	// Pays since the sweep became light (look-ahead pivot inversion: one workgroup runs the 16-step chain, the others ~2 us of
+	// tile products): 9.43 -> 9.09 ms at KITTI-00; at S2M the ten 0.85 ms sweeps per run cost the latency-bound PCG kernels more
+	// than the four hidden refreshes save (28.7 vs 28.3 ms) -> automatic: on up to a coarse dimension of 768.
+	int coarseOverlap = -1;       // -1 automatic, 0 off, 1 on
+	bool overlapActive() const { return coarseOverlap < 0 ? 6 * sys.cl * sys.nc <= 768 : coarseOverlap != 0; }
 	hipStream_t gjStream = nullptr;
 	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr;
 	int liveInv = 0, pendingInv = -1;   // buffer with the inverse in use / buffer the running inversion will leave its result in
@@ -1395,30 +1398,35 @@ struct cuba_hip_solver
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
-			if (coarseOverlap)
+			// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
+			const int gjSteps = (6 * sys.cl * sys.nc + 31) / 32, first = gjSteps & 1;
+			if (overlapActive())
 			{
+				// The inverse in use lives in d_coarse[2] (the iteration graphs have the pointer baked in); d_coarse[0 / 1] are
+				// the work buffers of the sweep, which leaves its result in d_coarse[0].
 				ensureOverlapObjects();
+				const size_t invBytes = sizeof(Scalar) * (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
 				if (!coarseValid)
 				{
 					// first solve of a run: nothing to overlap with, invert here
 					drainInversion();
-					Scalar* res = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
-					liveInv = res == d_coarse[0].data() ? 0 : 1;
+					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
+					HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
 					coarseValid = true; cntCoarseRefresh++;
 				}
 				else if (pendingInv >= 0)
 				{
 					HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done: it ran under the previous PCG
-					liveInv = pendingInv; pendingInv = -1;
+					HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
+					pendingInv = -1;
 				}
-				sys.acinv = d_coarse[liveInv].data();
-				// this trial's matrix -> the inverse the next trial will use, on the other stream, into the two idle buffers
-				const int a = (liveInv + 1) % 3, b = (liveInv + 2) % 3;
+				sys.acinv = d_coarse[2].data();
+				// this trial's matrix -> the inverse the next trial will use, on the other stream (after the copy above)
 				HIP_TRY(hipEventRecord(evSetup, stream));
 				HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
-				Scalar* res = launch_coarse_setup(g, st, sys, d_coarse[a].data(), d_coarse[b].data(), gjStream, evAssembled);
+				(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
 				HIP_TRY(hipEventRecord(evInverse, gjStream));
-				pendingInv = res == d_coarse[a].data() ? a : b;
+				pendingInv = 0;
 				assemblePending = true; cntCoarseRefresh++;
 				coarseFresh = false;
 			}
@@ -1427,9 +1435,7 @@ struct cuba_hip_solver
 				const bool refresh = !coarseValid || coarseAge >= coarseMaxAge || lastSolveIters > coarseGrowth * itersAtRefresh + 8;
 				if (refresh)
 				{
-					// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0] (the
-					// iteration graphs have the pointer baked in)
-					const int steps = (6 * sys.cl * sys.nc + 31) / 32, first = steps & 1;
+					drainInversion();
 					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
 				}
@@ -1833,7 +1839,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
-		else if (k == "coarse_overlap") { s->coarseOverlap = value != 0; s->coarseValid = false; }
+		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }
 		else if (k == "mixed_precision") s->mixedPrecision = value != 0 && sizeof(Scalar) == 8;
