@@ -178,9 +178,8 @@ __device__ __forceinline__ Scalar* pq_slot(const DeviceSystem& sys, int k) { ret
 // Deterministic second stage of every global sum (chi2, gain-ratio denominator): one workgroup adds the
 // per-workgroup partials in a fixed order and writes the total to out[0] (out[1..NSLOT) = 0, so hosts that add up a
 // slot group keep working).  No atomics anywhere => results are reproducible bit for bit.
-__global__ __launch_bounds__(1024) void reduce_parts_kernel(const Scalar* __restrict__ parts, int n, Scalar* out)
+__device__ __forceinline__ void reduce_parts_body(const Scalar* __restrict__ parts, int n, Scalar* out, Scalar* sh)
 {
-	__shared__ Scalar sh[1024];
 	Scalar v0 = 0, v1 = 0, v2 = 0, v3 = 0;
 	int i = threadIdx.x;
 	for (; i + 3072 < n; i += 4096)
@@ -197,6 +196,13 @@ __global__ __launch_bounds__(1024) void reduce_parts_kernel(const Scalar* __rest
 		__syncthreads();
 	}
 	if (threadIdx.x < NSLOT) out[threadIdx.x] = threadIdx.x == 0 ? sh[0] : Scalar(0);
+	__syncthreads();       // sh may be reused
+}
+
+__global__ __launch_bounds__(1024) void reduce_parts_kernel(const Scalar* __restrict__ parts, int n, Scalar* out)
+{
+	__shared__ Scalar sh[1024];
+	reduce_parts_body(parts, n, out, sh);
 }
 
 static void launch_reduce_parts(const Scalar* parts, int n, Scalar* out, hipStream_t s)
@@ -249,10 +255,10 @@ __device__ __forceinline__ void linearize_edge(const DeviceGraph& g, int e, Lane
 // Replaces computeActiveErrorsKernel / computeChiSquaresKernel (cuda_block_solver.cu:733-786, 841-875):
 // no errors/Xcs are stored -- later kernels recompute them from 40 B/edge instead of re-reading 48 B/edge.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scalar* parts, Scalar* per_edge)
+__device__ __forceinline__ void residual_chi2_body(const DeviceGraph& g, Scalar* parts, Scalar* per_edge, int bid, int nb)
 {
 	Scalar acc = 0;
-	for (int e = g.e_begin + blockIdx.x * 256 + threadIdx.x; e < g.e_end; e += gridDim.x * 256)
+	for (int e = g.e_begin + bid * 256 + threadIdx.x; e < g.e_end; e += nb * 256)
 	{
 		const int pe = g.e_pose[e];
 		const bool stereo = (pe & STEREO_BIT) != 0;
@@ -273,7 +279,12 @@ __global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scala
 	__shared__ Scalar part[4];
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	if (threadIdx.x == 0) parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+	if (threadIdx.x == 0) parts[bid] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void residual_chi2_kernel(DeviceGraph g, Scalar* parts, Scalar* per_edge)
+{
+	residual_chi2_body(g, parts, per_edge, blockIdx.x, gridDim.x);
 }
 
 void launch_residual_chi2(const DeviceGraph& g, Scalar* parts, Scalar* slots, Scalar* per_edge, hipStream_t st)
@@ -1207,9 +1218,8 @@ __global__ __launch_bounds__(256) void big_back_substitute_kernel(DeviceGraph g,
 	}
 }
 
-void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
+static void launch_back_substitute_kernels(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
 {
-	if (g.Lf <= 0) return;
 	if (st.nWaves > 0)
 	{
 		const int grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
@@ -1217,20 +1227,59 @@ void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, con
 	}
 	if (st.nBig > 0)
 		hipLaunchKernelGGL(big_back_substitute_kernel, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+}
+
+void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
+{
+	if (g.Lf <= 0) return;
+	launch_back_substitute_kernels(g, st, sys, lambda, s);
 	launch_reduce_parts(sys.parts, st.nWaves + st.nBig, sys.slots + NSLOT, s);
 }
 
 // sum x (lambda x + b), pose part and (stage API only) landmark part.  Ref: computeScaleKernel :1070-1091.
-__global__ __launch_bounds__(256) void pose_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* parts)
+__device__ __forceinline__ void pose_scale_body(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* parts, int bid, int nb)
 {
 	Scalar acc = 0;
-	for (int i = blockIdx.x * 256 + threadIdx.x; i < g.Pf * 6; i += gridDim.x * 256)
+	for (int i = bid * 256 + threadIdx.x; i < g.Pf * 6; i += nb * 256)
 	{
 		const Scalar x = sys.xp[i];
 		acc += x * (lambda * x + sys.bp[i]);
 	}
 	acc = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0) parts[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+	if ((threadIdx.x & 63) == 0) parts[bid * 4 + (threadIdx.x >> 6)] = acc;
+}
+
+__global__ __launch_bounds__(256) void pose_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* parts)
+{
+	pose_scale_body(g, sys, lambda, parts, blockIdx.x, gridDim.x);
+}
+
+// Evaluation of an LM trial in one launch: the first nRes workgroups sum the robust chi2 at the updated estimate, the others the
+// pose part of the gain-ratio denominator (same partials, in the same places of their arrays, as the two separate kernels).
+__global__ __launch_bounds__(256) void eval_trial_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* resParts, int nRes, Scalar* scaleParts, int nScale)
+{
+	if ((int)blockIdx.x < nRes) residual_chi2_body(g, resParts, nullptr, blockIdx.x, nRes);
+	else pose_scale_body(g, sys, lambda, scaleParts, blockIdx.x - nRes, nScale);
+}
+
+// Second stage of the three sums of a trial (landmark part of the denominator from the back-substitution, chi2, pose part) and
+// the report to the host in one launch: each sum is added exactly as reduce_parts_kernel adds it; the results go into the
+// mapped host block, the ticket follows them.
+__global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, const Scalar* pA, int nA, Scalar* oA, const Scalar* pB, int nB, Scalar* oB,
+	const Scalar* pC, int nC, Scalar* oC)
+{
+	__shared__ Scalar sh[1024];
+	reduce_parts_body(pA, nA, oA, sh);
+	reduce_parts_body(pB, nB, oB, sh);
+	reduce_parts_body(pC, nC, oC, sh);
+	__threadfence_system();          // every writer's results before the ticket
+	__syncthreads();
+	if (threadIdx.x == 0 && sys.host_flags)
+	{
+		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
+		__threadfence_system();
+		sys.host_flags[3] = ++(*sys.ticket);
+	}
 }
 
 __global__ __launch_bounds__(256) void landmark_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* parts)
@@ -1315,6 +1364,24 @@ void launch_update_state(const DeviceGraph& g, const DeviceSystem& sys, hipStrea
 {
 	const int pb = (g.Pf + 255) / 256, lb = (g.Lf * 3 + 255) / 256;
 	if (pb + lb > 0) hipLaunchKernelGGL(update_state_kernel, dim3(pb + lb), dim3(256), 0, s, g, sys, pb);
+}
+
+// Everything between a converged reduced solve and the LM decision in four launches: back-substitution, update, evaluation of
+// the trial (chi2 + pose part of the gain-ratio denominator), then the second stage of the three sums with the report to the
+// host.  The stage API runs the same kernels one call at a time (eight launches); per LM trial that is ~26 us more.
+// The partial sums share sys.parts: [0, nWaves + nBig) back-substitution, then 2048 for chi2, then 1024 for the pose part.
+void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
+{
+	const int nA = g.Lf > 0 ? st.nWaves + st.nBig : 0;
+	Scalar* resParts = sys.parts + (nA + 63) / 64 * 64;
+	Scalar* scaleParts = resParts + 2048;
+	if (g.Lf > 0) launch_back_substitute_kernels(g, st, sys, lambda, s);
+	launch_update_state(g, sys, s);
+	const int n = g.e_end - g.e_begin;
+	const int nRes = n > 0 ? min((n + 255) / 256, 2048) : 0;
+	const int nScale = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
+	if (nRes + nScale > 0) hipLaunchKernelGGL(eval_trial_kernel, dim3(nRes + nScale), dim3(256), 0, s, g, sys, lambda, resParts, nRes, scaleParts, nScale);
+	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, sys.parts, nA, sys.slots + NSLOT, resParts, nRes, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT);
 }
 
 void launch_update_poses(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s)

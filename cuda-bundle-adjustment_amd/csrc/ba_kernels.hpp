@@ -137,6 +137,8 @@ void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, con
 
 // pose-side part of the gain-ratio denominator: sum xp (lambda xp + bp) -> slots[0..NSLOT)
 void launch_pose_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
+// back-substitution + update + evaluation of the trial + second stage of their three sums + report to the host: four launches
+void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);
 // landmark-side part recomputed from xl and the stored bl (stage API; the fused path gets it from back_substitute)
 void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
 

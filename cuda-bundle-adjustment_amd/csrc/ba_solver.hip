@@ -1577,10 +1577,19 @@ struct cuba_hip_solver
 				const std::function<void()> undo = [&] { pop(); };
 				bool tailValid = false;
 				const bool ok = speculateTail ? solveReduced(&tail, &undo, &tailValid) : solveReduced();
-				if (ok && !tailValid) { backSubstitute(); update(); }
 				double Fhat = 0, scale = 0;
 				if (ok && tailValid) readEvaluate(true, &Fhat, &scale);     // already there: it came with the solver's flags
-				else evaluateTrial(lam, ok, &Fhat, &scale);                 // chi2 at the trial estimate + gain-ratio denominator, one host look
+				else if (ok && !profile && partHi < 0 && (size_t)st.nWaves + st.nBig + 64 + 3072 <= d_parts.size())
+				{
+					// back-substitution, update, evaluation, sums and report in four launches, one host look
+					launch_trial_tail(g, st, sys, (Scalar)lam, stream); noteReport();
+					readEvaluate(true, &Fhat, &scale);
+				}
+				else
+				{
+					if (ok) { backSubstitute(); update(); }
+					evaluateTrial(lam, ok, &Fhat, &scale);                  // chi2 at the trial estimate + gain-ratio denominator, one host look
+				}
 				scale += 1e-3;
 				rho = ok ? (F - Fhat) / scale : -1;
 				if (rho > 0)
