@@ -233,10 +233,13 @@ struct cuba_hip_solver
 	// overlapped refresh: while the PCG of trial k runs (with the inverse built from trial k-1's matrix), a second stream
 	// assembles and inverts trial k's coarse matrix for trial k+1
 	// Pays since the sweep became light (look-ahead pivot inversion: one workgroup runs the 16-step chain, the others ~2 us of
-	// tile products): 9.43 -> 9.09 ms at KITTI-00; at S2M the ten 0.85 ms sweeps per run cost the latency-bound PCG kernels more
-	// than the four hidden refreshes save (28.7 vs 28.3 ms) -> automatic: on up to a coarse dimension of 768.
+	// tile products): 9.43 -> 9.09 ms at KITTI-00 with a refresh under every trial; at S2M ten 0.85 ms sweeps per run cost the
+	// latency-bound PCG kernels more than they save (28.7 vs 28.4 ms), one under every third trial does pay (27.1 ms; G4M 67.6 -> 65.3).
 	int coarseOverlap = -1;       // -1 automatic, 0 off, 1 on
-	bool overlapActive() const { return coarseOverlap < 0 ? 6 * sys.cl * sys.nc <= 768 : coarseOverlap != 0; }
+	int coarseOverlapPeriod = -1; // trials between two overlapped refreshes: -1 automatic (1 up to a coarse dimension of 768, 3 beyond)
+	int sideAge = 0;
+	bool overlapActive() const { return coarseOverlap != 0; }
+	int overlapPeriod() const { return coarseOverlapPeriod > 0 ? coarseOverlapPeriod : (6 * sys.cl * sys.nc <= 768 ? 1 : 3); }
 	hipStream_t gjStream = nullptr;
 	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr;
 	int liveInv = 0, pendingInv = -1;   // buffer with the inverse in use / buffer the running inversion will leave its result in
@@ -1412,7 +1415,7 @@ struct cuba_hip_solver
 					drainInversion();
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
-					coarseValid = true; cntCoarseRefresh++;
+					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
 				}
 				else if (pendingInv >= 0)
 				{
@@ -1421,13 +1424,18 @@ struct cuba_hip_solver
 					pendingInv = -1;
 				}
 				sys.acinv = d_coarse[2].data();
-				// this trial's matrix -> the inverse the next trial will use, on the other stream (after the copy above)
-				HIP_TRY(hipEventRecord(evSetup, stream));
-				HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
-				(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
-				HIP_TRY(hipEventRecord(evInverse, gjStream));
-				pendingInv = 0;
-				assemblePending = true; cntCoarseRefresh++;
+				// this trial's matrix -> the inverse the next trial will use, on the other stream (after the copy above): every
+				// trial for small coarse dimensions, every overlapPeriod()-th one beyond (the sweep's share of the CUs slows
+				// the latency-bound PCG kernels it runs under)
+				if (++sideAge >= overlapPeriod())
+				{
+					HIP_TRY(hipEventRecord(evSetup, stream));
+					HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
+					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
+					HIP_TRY(hipEventRecord(evInverse, gjStream));
+					pendingInv = 0; sideAge = 0;
+					assemblePending = true; cntCoarseRefresh++;
+				}
 				coarseFresh = false;
 			}
 			else
@@ -1848,6 +1856,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
+		else if (k == "coarse_overlap_period") s->coarseOverlapPeriod = (int)value;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }

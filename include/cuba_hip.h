@@ -91,14 +91,16 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
    preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses and max(24, Pf/115) above with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
    only), "coarse_linear" (default 1: constant + linear-in-pose-index coarse functions per aggregate, 12 unknowns each;
-   0 = constant only, 6 unknowns), "coarse_max_age" (default 3: the coarse
+   0 = constant only, 6 unknowns), "coarse_overlap" (default 1: the coarse matrix of a trial is assembled and inverted on a second,
+   low-priority stream under that trial's PCG and serves from the next trial on -- only the first solve of a run inverts in line;
+   0 = invert in line, on the policy of the next two options), "coarse_overlap_period" (trials between two overlapped inversions;
+   -1 = automatic: every trial up to a coarse dimension of 768, every third beyond), "coarse_max_age" (in-line mode; default 3: the coarse
    inverse of the two-level preconditioner is reused for up to three further solves of a run; 0 = rebuild it for every
-   solve), "coarse_refresh_growth" (default 1.6: rebuild early once a solve needs that many times the iterations of
+   solve), "coarse_refresh_growth" (in-line mode; default 1.6: rebuild early once a solve needs that many times the iterations of
    the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
    the device writes into mapped host memory, not from hipStreamSynchronize), "speculate_tail" (default 0; 1 = optimize()
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
-   was too short -- measured slightly slower), "coarse_overlap" (default 0; 1 = invert every trial's coarse matrix on a second
-   stream under the PCG of that trial, for use by the next one -- measured slower, kept for A/B runs), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "schur_atomic"
+   was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "schur_atomic"
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "mixed_precision" (fp64 library
    only, default 0; 1 = the per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in
    fp32, every sum over edges, the reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29,
