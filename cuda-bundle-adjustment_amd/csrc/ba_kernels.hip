@@ -2230,7 +2230,10 @@ __device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
 
 // CL = coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose index.  Coarse
 // unknown (aggregate J, function a, component c) has index (6 CL) J + 6 a + c.
-template <int CL, int AC>
+// AC2: further column pairs per lane and row, fetched in a second batch once the restricted sums have freed their registers
+// (coarse dimensions beyond 128 AC = 1536: large graphs with small aggregates; a column-by-column tail would pay one memory
+// round trip per 64 columns)
+template <int CL, int AC, int AC2>
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
@@ -2369,6 +2372,17 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			sR[jc] = s1; sQ[jc] = 0;
 		}
 	}
+	Scalar2 ainv2[AR][AC2 > 0 ? AC2 : 1];
+	if (AC2 > 0 && Nc > 128 * AC)                       // (uniform over the grid)
+	{
+#pragma unroll
+		for (int a = 0; a < AR; a++)
+		{
+			const Scalar* Arow = sys.acinv + (size_t)(CD * I + min(wv + 8 * a, CD - 1)) * Nc;
+#pragma unroll
+			for (int m = 0; m < AC2; m++) ainv2[a][m] = *reinterpret_cast<const Scalar2*>(Arow + min(2 * lane + 128 * (AC + m), Nc - 2));
+		}
+	}
 	TRACE_MARK();
 	a_k = wave_sum(a_k); a_0 = wave_sum(a_0); a_q = wave_sum(a_q);
 	if (lane == 0) { wsum[wv] = a_k; wsum[8 + wv] = a_0; wsum[16 + wv] = a_q; }
@@ -2418,8 +2432,17 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			const int j = 2 * lane + 128 * m;
 			if (j < Nc) acc += ainv[a][m].x * (sR[j] - alpha * sQ[j]) + ainv[a][m].y * (sR[j + 1] - alpha * sQ[j + 1]);
 		}
+		if (AC2 > 0 && Nc > 128 * AC)
+		{
+#pragma unroll
+			for (int m = 0; m < AC2; m++)
+			{
+				const int j = 2 * lane + 128 * (AC + m);
+				if (j < Nc) acc += ainv2[a][m].x * (sR[j] - alpha * sQ[j]) + ainv2[a][m].y * (sR[j + 1] - alpha * sQ[j + 1]);
+			}
+		}
 		if (row < CD)
-			for (int j = lane + 128 * AC; j < Nc; j += 64) acc += sys.acinv[(size_t)(CD * I + row) * Nc + j] * (sR[j] - alpha * sQ[j]);
+			for (int j = lane + 128 * (AC + AC2); j < Nc; j += 64) acc += sys.acinv[(size_t)(CD * I + row) * Nc + j] * (sR[j] - alpha * sQ[j]);
 		acc = wave_sum(acc);
 		if (lane == 0 && row < CD) yc[row] = acc;
 	}
@@ -2475,8 +2498,8 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 static void* pcg2_kernel_for(const DeviceSystem& sys)
 {
 	const bool small = 6 * sys.cl * sys.nc <= 768;
-	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6> : (void*)pcg2_fused_kernel<2, 12>;
-	return small ? (void*)pcg2_fused_kernel<1, 6> : (void*)pcg2_fused_kernel<1, 12>;
+	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0> : (void*)pcg2_fused_kernel<2, 12, 6>;
+	return small ? (void*)pcg2_fused_kernel<1, 6, 0> : (void*)pcg2_fused_kernel<1, 12, 6>;
 }
 
 static size_t pcg2_lds_bytes(const DeviceSystem& sys)

@@ -885,7 +885,10 @@ struct cuba_hip_solver
 		const int cl = coarseLinear ? 2 : 1;
 		// automatic size: coarse dimension <= ~700-960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
 		// (small graphs want smaller aggregates: KITTI-07, 247 free poses: 24 / 16 / 12 / 8 / 6 / 4 poses -> 8.6 / 7.0 / 6.4 / 6.3 / 6.5 / 7.9 ms)
-		if (agg < 0) agg = cl == 2 ? (Pf >= 1320 ? std::max(24, (Pf + 114) / 115) : std::max(8, (Pf + 27) / 55)) : std::max(12, (Pf + 159) / 160);
+		// (large graphs, inversion hidden under the PCG of earlier trials: S2M 44 / 40 / 36 / 32 poses -> 27.1 / 26.35 / 26.7 / 26.4 ms,
+		// G4M 88 / 72 / 64 / 56 / 48 -> 65.1 / 59.6 / 54.8 / 54.0 / 58.3 ms: the aggregate count may grow from 115 to 180 with the graph)
+		const int ncMax = std::min(180, std::max(115, (Pf + 39) / 40));
+		if (agg < 0) agg = cl == 2 ? (Pf >= 1320 ? std::max(24, (Pf + ncMax - 1) / ncMax) : std::max(8, (Pf + 27) / 55)) : std::max(12, (Pf + 159) / 160);
 		const int spmvRows = spmv_rows_for(Pf);
 		if (agg > 0) agg = (agg + spmvRows - 1) / spmvRows * spmvRows;   // aggregates = whole SpMV workgroups (sys.qpart)
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;

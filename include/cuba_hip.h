@@ -89,7 +89,7 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 /* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
    (default 4*6*Pf capped at 32768), "pcg_check_every" (PCG iterations between host looks at the device stop flag; default 0 =
    batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
-   preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses and max(24, Pf/115) above with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
+   preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses and max(24, Pf/min(180, max(115, Pf/40))) above with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
    only), "coarse_linear" (default 1: constant + linear-in-pose-index coarse functions per aggregate, 12 unknowns each;
    0 = constant only, 6 unknowns), "coarse_overlap" (default 1: the coarse matrix of a trial is assembled and inverted on a second,
    low-priority stream under that trial's PCG and serves from the next trial on -- only the first solve of a run inverts in line;
