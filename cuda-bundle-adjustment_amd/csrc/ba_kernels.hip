@@ -880,10 +880,10 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 // wave = free pose: diagonal block (upper triangle), bp, bsc.  ET = record / per-edge arithmetic type; sums over edges are
 // always accumulated in Scalar.
 template <int MODE, typename ET>
-__global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+__device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
 {
 	const int lane = threadIdx.x & 63;
-	const int ip = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int ip = bid * 4 + (threadIdx.x >> 6);
 	if (ip >= g.Pf) return;
 	ET q[4], cam[5];
 	load_pose_as<ET>(g, ip, q, cam);
@@ -959,11 +959,17 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 // the 16 lanes and the stored block are Scalar.
 constexpr int BP_GROUP = 16;
 
+template <int MODE, typename ET>
+__global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+{
+	pose_pass_body<MODE, ET>(g, st, sys, blockIdx.x);
+}
+
 template <typename ET>
-__global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+__device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
 {
 	const int gl = threadIdx.x & (BP_GROUP - 1);
-	const int grp = (blockIdx.x * 256 + threadIdx.x) / BP_GROUP;
+	const int grp = (bid * 256 + threadIdx.x) / BP_GROUP;
 	const bool on = grp < st.nOd;
 	const int blk = on ? st.od_blocks[grp] : 0;
 	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
@@ -1043,6 +1049,22 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 }
 
 template <typename ET>
+__global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+{
+	block_pass_body<ET>(g, st, sys, blockIdx.x);
+}
+
+// Pose pass and block pass in one launch: they write disjoint parts of the reduced system (diagonal blocks / bp / bsc vs the
+// off-diagonal blocks) from the same records.  The pose workgroups come first (a wave walks a pose's ~420 edges in 7 trips:
+// 33 us of latency when launched alone) and run under the ALU-bound block workgroups.
+template <typename ET>
+__global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
+{
+	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
+	else block_pass_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
+}
+
+template <typename ET>
 static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
 {
 	if (st.nWaves > 0)
@@ -1055,6 +1077,13 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 	{
 		if (mode == 0) hipLaunchKernelGGL((big_lm_pass_kernel<0, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
+	}
+	static const bool separate = std::getenv("CUBA_HIP_SEPARATE_SCHUR_PASSES") != nullptr;     // A/B knob
+	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0 && !separate)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)
+	{
+		const int np = (g.Pf + 3) / 4;
+		hipLaunchKernelGGL((schur_pass_kernel<ET>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		return;
 	}
 	if (g.Pf > 0)
 	{

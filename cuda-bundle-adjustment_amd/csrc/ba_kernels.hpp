@@ -58,6 +58,7 @@ struct DeviceStructure
 	// destination-major (atomic-free) Schur assembly
 	int* hsc_blkrow = nullptr;         // [nblk] block row of every block
 	int nOd = 0;                       // blocks that receive at least one off-diagonal (or duplicate-pose) product
+	int nDiagProd = 0;                 // of these, diagonal blocks (a landmark observed twice by one pose): the block pass then updates what the pose pass stored
 	int* od_blocks = nullptr;          // [nOd] their ids, largest product count first
 	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
 	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)

@@ -871,6 +871,7 @@ struct cuba_hip_solver
 		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream); d_cbWi.upload(cbWi, stream); d_cbWj.upload(cbWj, stream);
 		sync();
 		lap("structure: coarse lists + sync");
+		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += blkRow[k] == h_colind[k];
 		publishStructure(nblk, (int)waveLm.size() / 2, (int)bigLm.size(), (int)odBlocks.size(), (int)cbI.size(), ellM, ellOver, cc);
 		hostPatternValid = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -919,6 +920,7 @@ struct cuba_hip_solver
 	}
 
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
+	int diagProdBlocks = 0;      // diagonal blocks with products (duplicate observations), set by the structure builders
 	void publishStructure(int nblk, int nWaves, int nBig, int nOd, int nCb, int ellM, int ellOver, const CoarseCfg& c)
 	{
 		const int agg = c.agg, cl = c.cl, nc = c.nc, spmvRows = c.spmvRows;
@@ -930,7 +932,7 @@ struct cuba_hip_solver
 		st.pair_blk = d_pairBlk.data(); st.lm_pair_base = d_lmPairBase.data(); st.lm_nfree = d_lmNfree.data();
 		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
 		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
-		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.od_blocks = d_odBlocks.data();
+		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data();
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
@@ -1256,6 +1258,7 @@ struct cuba_hip_solver
 			return;
 		}
 		reorderTried = false;
+		diagProdBlocks = hc[topo::CNT_DIAGPROD];
 		publishStructure(nblk, nWaves, nBig, hc[topo::CNT_NOD], cc.nc > 0 ? hc[topo::CNT_NCB] : 0, ellM, ellOver, cc);
 		hostPatternValid = false;
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] structure (device): nblk %d products %lld waves %d big %d od %d coarse blocks %d max row %d\n",

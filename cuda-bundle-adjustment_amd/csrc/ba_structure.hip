@@ -185,17 +185,20 @@ __global__ __launch_bounds__(T) void blocks_from_entries_kernel(const uint64_t* 
 __global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters)
 {
 	const int k = blockIdx.x * T + threadIdx.x;
-	int cnt = 0, far = 0;
+	int cnt = 0, far = 0, dup = 0;
 	if (k < nblk)
 	{
 		far = colind[k] - blkrow[k] > farOffset;
 		cnt = prod_ptr[k + 1] - prod_ptr[k];
+		dup = cnt > 0 && colind[k] == blkrow[k];
 		keys[k] = cnt > 0 ? 0x7fffffffu - (uint32_t)cnt : 0xffffffffu;          // longest list first; blocks without products last
 		vals[k] = (uint32_t)k;
 	}
 	const int n = __popcll(__ballot(cnt > 0)), nf = __popcll(__ballot(far != 0));
 	if ((threadIdx.x & 63) == 0 && n) atomicAdd(&counters[CNT_NOD], n);
 	if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&counters[CNT_FARBLOCKS], nf);
+	const int nd = __popcll(__ballot(dup != 0));
+	if ((threadIdx.x & 63) == 0 && nd) atomicAdd(&counters[CNT_DIAGPROD], nd);
 }
 
 __global__ __launch_bounds__(T) void remap_poses_kernel(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut)

@@ -30,7 +30,7 @@ hipError_t exclusive_scan_i64(void* temp, size_t tempBytes, const long long* in,
 hipError_t inclusive_scan_i32(void* temp, size_t tempBytes, const int* in, int* out, size_t n, hipStream_t s);
 
 // counters the kernels fill (one device int each), read back by the host at its synchronisation points
-enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_COUNT = 16 };
+enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_COUNT = 16 };
 
 // ---- A. edges ------------------------------------------------------------------------------------------------------
 // keys[e] = landmark << 32 | pose, vals[e] = e; counters[CNT_BAD] = 1 / 2 / 3 for an index out of range / a bad dimension /
@@ -60,6 +60,7 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 	int* colind, int* blkrow, int* prod_ptr, int* prod_ea, int* prod_eb, hipStream_t s);
 // blocks with products, longest list first (stable): sort keys + values; counters[CNT_NOD] = their number
 // counters[CNT_FARBLOCKS] = number of blocks more than farOffset block columns off the diagonal (pose order check)
+// counters[CNT_DIAGPROD] = number of DIAGONAL blocks with products (a landmark observed twice by one pose)
 void launch_od_keys(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
 // pose indices of the caller-order edge array through a map of the free poses (fixed poses keep their index)
 void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s);
