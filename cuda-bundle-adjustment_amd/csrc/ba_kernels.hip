@@ -1430,9 +1430,12 @@ void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipS
 //   every workgroup re-derives alpha / beta / the stop test from them, so a finished solve turns the
 //   remaining queued launches into no-ops without a host round trip.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
+// ROWCOPY: also store the damped diagonal block into the row-ordered copy of the matrix (the fused launch: its expand workgroups
+// leave the diagonal entries alone, because this body rewrites the diagonal blocks they would read)
+template <bool ROWCOPY>
+__device__ __forceinline__ void pcg_setup_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, int bid, int nb)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int i = bid * 256 + threadIdx.x;
 	Scalar rz = 0;
 	if (i < g.Pf)
 	{
@@ -1450,6 +1453,17 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 			}
 #pragma unroll
 		for (int k = 0; k < 36; k++) blk[k] = A[k];   // full symmetric diagonal block, damping included
+		if (ROWCOPY)
+		{
+			// adjacency of a row = its lower neighbours, then its own blocks, the diagonal one first
+			const int pos = (st.adj_ptr[i + 1] - st.adj_ptr[i]) - (st.hsc_rowptr[i + 1] - st.hsc_rowptr[i]);
+			if (pos < 20 * st.ell_m)
+			{
+				Scalar* dst = sys.hrow + 36 * ((size_t)i * st.ell_m * 20 + pos);
+#pragma unroll
+				for (int k = 0; k < 36; k++) dst[k] = A[k];      // (symmetric: row-major = column-major)
+			}
+		}
 		if (!spd6_inverse(A, Ai)) *sys.fail = 1;
 #pragma unroll
 		for (int k = 0; k < 36; k++) sys.minv[36 * (size_t)i + k] = Ai[k];
@@ -1479,12 +1493,17 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 		if (threadIdx.x == 0)
 		{
 			const Scalar s2 = part[0] + part[1] + part[2] + part[3];
-			sys.rz[blockIdx.x] = s2;
-			sys.rz[sys.rzStride + blockIdx.x] = s2;
+			sys.rz[bid] = s2;
+			sys.rz[sys.rzStride + bid] = s2;
 		}
-		for (int t = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; t < sys.nrz; t += gridDim.x * blockDim.x) sys.rz[sys.rzStride + t] = 0;
+		for (int t = nb + bid * 256 + threadIdx.x; t < sys.nrz; t += nb * 256) sys.rz[sys.rzStride + t] = 0;
 	}
 	if (i == 0) { *sys.iters = 0; *sys.done = 0; *sys.kbase = 0; }
+}
+
+__global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
+{
+	pcg_setup_body<false>(g, st, sys, lambda, blockIdx.x, gridDim.x);
 }
 
 void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
@@ -1533,22 +1552,47 @@ typedef Scalar Scalar2 __attribute__((ext_vector_type(2)));
 // 6x6 block as seen from that row (transposed for the lower half), row-major, so that lane (slot, rr) reads the six
 // numbers it needs as three aligned 16-byte loads (half as many load instructions as element-wise strided reads of
 // the upper storage; the per-CU load path, not bandwidth, limits this kernel at KITTI-00 size).
-__global__ __launch_bounds__(256) void hsc_expand_kernel(DeviceStructure st, DeviceSystem sys, size_t total)
+// FUSED: runs beside pcg_setup_body in one launch, which damps and symmetrises the diagonal blocks meanwhile -- they are left to it.
+template <bool FUSED>
+__device__ __forceinline__ void hsc_expand_body(const DeviceStructure& st, const DeviceSystem& sys, size_t total, size_t bid)
 {
-	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t t = bid * 256 + threadIdx.x;
 	if (t >= total) return;
 	const size_t slot = t / 36;
 	const int e = (int)(t - 36 * slot);
 	const int2 en = st.ell[slot];
 	if (en.y < 0) return;
 	const int rr = e / 6, c = e - 6 * rr;
-	sys.hrow[t] = sys.hsc[36 * (size_t)(en.x & 0x7fffffff) + (en.x < 0 ? rr * 6 + c : c * 6 + rr)];
+	const Scalar* B = sys.hsc + 36 * (size_t)(en.x & 0x7fffffff);
+	if (FUSED && en.y == (int)(slot / ((size_t)st.ell_m * 20))) return;       // the row's own diagonal block: written by the set-up body
+	sys.hrow[t] = B[en.x < 0 ? rr * 6 + c : c * 6 + rr];
+}
+
+__global__ __launch_bounds__(256) void hsc_expand_kernel(DeviceStructure st, DeviceSystem sys, size_t total)
+{
+	hsc_expand_body<false>(st, sys, total, blockIdx.x);
+}
+
+// pcg_setup (a handful of workgroups, one 6x6 inverse per thread: 11 us of latency) and the row-ordered copy (9 us of streaming)
+// in one launch
+__global__ __launch_bounds__(256) void pcg_setup_expand_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda, int nSetup, size_t total)
+{
+	if ((int)blockIdx.x < nSetup) pcg_setup_body<true>(g, st, sys, lambda, blockIdx.x, nSetup);
+	else hsc_expand_body<true>(st, sys, total, blockIdx.x - nSetup);
 }
 
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s)
 {
 	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
 	if (total) hipLaunchKernelGGL(hsc_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st, sys, total);
+}
+
+void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
+{
+	if (g.Pf <= 0) return;
+	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
+	const int nSetup = (g.Pf + 255) / 256;
+	hipLaunchKernelGGL(pcg_setup_expand_kernel, dim3(nSetup + (unsigned)((total + 255) / 256)), dim3(256), 0, s, g, st, sys, lambda, nSetup, total);
 }
 
 // N entries of one lane at once: all 9 N (16-byte) loads are issued before the first use. Padding entries (column -1)

@@ -167,6 +167,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 
 // hsc (damped, after pcg_setup) -> sys.hrow
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
+void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);   // both in one launch
 
 // out3 = {chi2 total, landmark scale part, pose scale part} gathered from the result slots of the kernels enqueued before
 void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s);

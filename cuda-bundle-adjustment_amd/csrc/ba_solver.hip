@@ -1402,8 +1402,8 @@ struct cuba_hip_solver
 		const int maxIter = maxIterAlloc;
 		const Scalar tol2 = pcgTol * pcgTol;
 		d_fail.zero(stream);
-		launch_pcg_setup(g, st, sys, lambda, stream);   // also clears the device-side `done` flag and the iteration offset
-		launch_hsc_expand(g, st, sys, stream);          // row-ordered copy of the damped matrix for the SpMV
+		// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
+		launch_pcg_setup_expand(g, st, sys, lambda, stream);
 		const bool twoLevel = sys.agg > 0;
 		if (twoLevel)
 		{
