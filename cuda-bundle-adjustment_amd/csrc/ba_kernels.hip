@@ -728,10 +728,18 @@ __device__ __forceinline__ void load_pose_as(const DeviceGraph& g, int ip, ET q[
 	for (int i = 0; i < 5; i++) cam[i] = (ET)g.cam[5 * (size_t)ip + i];
 }
 
+// Workgroups beyond nLmGroups (optimize() only) copy the state into its backup: the push() of the LM loop rides in this launch.
 template <int MODE, typename ET>
-__global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
+__global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
+	unsigned nLmGroups, const Scalar* __restrict__ backupSrc, Scalar* __restrict__ backupDst, size_t backupCount)
 {
 	__shared__ Scalar lds_all[(LIN_BLOCK / WAVE) * WAVE * 9];
+	if (blockIdx.x >= nLmGroups)
+	{
+		const size_t stride = (size_t)(gridDim.x - nLmGroups) * LIN_BLOCK;
+		for (size_t i = (size_t)(blockIdx.x - nLmGroups) * LIN_BLOCK + threadIdx.x; i < backupCount; i += stride) backupDst[i] = backupSrc[i];
+		return;
+	}
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int wave = blockIdx.x * (LIN_BLOCK / WAVE) + wv;
@@ -1065,14 +1073,18 @@ __global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceSt
 }
 
 template <typename ET>
-static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
+static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
+	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
 {
 	if (st.nWaves > 0)
 	{
-		const int grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
-		if (mode == 0) hipLaunchKernelGGL((lm_pass_kernel<0, ET>), dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
-		else hipLaunchKernelGGL((lm_pass_kernel<1, ET>), dim3(grid), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda);
+		const unsigned grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
+		const unsigned nCopy = backupSrc ? (unsigned)std::min<size_t>(512, (backupCount + LIN_BLOCK - 1) / LIN_BLOCK) : 0;
+		if (mode == 0) hipLaunchKernelGGL((lm_pass_kernel<0, ET>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
+		else hipLaunchKernelGGL((lm_pass_kernel<1, ET>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
 	}
+	else if (backupSrc && backupCount)
+		(void)hipMemcpyAsync(backupDst, backupSrc, backupCount * sizeof(Scalar), hipMemcpyDeviceToDevice, s);
 	if (st.nBig > 0)
 	{
 		if (mode == 0) hipLaunchKernelGGL((big_lm_pass_kernel<0, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
@@ -1094,10 +1106,11 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		hipLaunchKernelGGL((block_pass_kernel<ET>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
 }
 
-void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s)
+void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
+	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
 {
-	if (st.mixed && sizeof(Scalar) == 8) launch_linearize_dm_t<float>(g, st, sys, mode, lambda, s);
-	else launch_linearize_dm_t<Scalar>(g, st, sys, mode, lambda, s);
+	if (st.mixed && sizeof(Scalar) == 8) launch_linearize_dm_t<float>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount);
+	else launch_linearize_dm_t<Scalar>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1575,10 +1588,17 @@ __global__ __launch_bounds__(256) void hsc_expand_kernel(DeviceStructure st, Dev
 
 // pcg_setup (a handful of workgroups, one 6x6 inverse per thread: 11 us of latency) and the row-ordered copy (9 us of streaming)
 // in one launch
-__global__ __launch_bounds__(256) void pcg_setup_expand_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda, int nSetup, size_t total)
+// (+ optionally, in the last nCopy workgroups, the copy of a freshly inverted coarse matrix into the buffer the iteration graphs read)
+__global__ __launch_bounds__(256) void pcg_setup_expand_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda, int nSetup, size_t total,
+	unsigned nExpand, const Scalar2* __restrict__ copySrc, Scalar2* __restrict__ copyDst, size_t copyPairs)
 {
 	if ((int)blockIdx.x < nSetup) pcg_setup_body<true>(g, st, sys, lambda, blockIdx.x, nSetup);
-	else hsc_expand_body<true>(st, sys, total, blockIdx.x - nSetup);
+	else if (blockIdx.x < nSetup + nExpand) hsc_expand_body<true>(st, sys, total, blockIdx.x - nSetup);
+	else
+	{
+		const size_t stride = (size_t)(gridDim.x - nSetup - nExpand) * 256;
+		for (size_t i = (size_t)(blockIdx.x - nSetup - nExpand) * 256 + threadIdx.x; i < copyPairs; i += stride) copyDst[i] = copySrc[i];
+	}
 }
 
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s)
@@ -1587,12 +1607,17 @@ void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const De
 	if (total) hipLaunchKernelGGL(hsc_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st, sys, total);
 }
 
-void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
+void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s,
+	const Scalar* copySrc, Scalar* copyDst, size_t copyCount)
 {
 	if (g.Pf <= 0) return;
 	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
 	const int nSetup = (g.Pf + 255) / 256;
-	hipLaunchKernelGGL(pcg_setup_expand_kernel, dim3(nSetup + (unsigned)((total + 255) / 256)), dim3(256), 0, s, g, st, sys, lambda, nSetup, total);
+	const unsigned nExpand = (unsigned)((total + 255) / 256);
+	const size_t pairs = copySrc ? copyCount / 2 : 0;            // (coarse dimensions are even)
+	const unsigned nCopy = pairs ? (unsigned)std::min<size_t>(1024, (pairs + 255) / 256) : 0;
+	hipLaunchKernelGGL(pcg_setup_expand_kernel, dim3(nSetup + nExpand + nCopy), dim3(256), 0, s, g, st, sys, lambda, nSetup, total, nExpand,
+		reinterpret_cast<const Scalar2*>(copySrc), reinterpret_cast<Scalar2*>(copyDst), pairs);
 }
 
 // N entries of one lane at once: all 9 N (16-byte) loads are issued before the first use. Padding entries (column -1)

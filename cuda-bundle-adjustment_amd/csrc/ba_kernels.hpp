@@ -127,7 +127,9 @@ void launch_residual_chi2(const DeviceGraph& g, Scalar* parts, Scalar* slots, Sc
 // launch_linearize: landmark-major kernel with fp64 atomics on the pose side (first design, kept for A/B runs)
 // launch_linearize_dm: destination-major, atomic-free and bitwise reproducible (default):
 //   landmark pass (Hll/bl, inverse, per-edge record) -> pose pass (diagonal blocks, bp, bsc) -> block pass (off-diagonal blocks)
-void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s);
+// backupSrc != nullptr: the landmark pass's launch also copies backupCount numbers backupSrc -> backupDst (the LM loop's push())
+void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
+	const Scalar* backupSrc = nullptr, Scalar* backupDst = nullptr, size_t backupCount = 0);
 void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s);
 
 // max over the diagonal of the diagonal blocks of hsc (Hpp after an assemble pass) folded into sys.maxdiag
@@ -167,7 +169,10 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 
 // hsc (damped, after pcg_setup) -> sys.hrow
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
-void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);   // both in one launch
+// both in one launch; copySrc != nullptr: the same launch also copies copyCount (even) numbers copySrc -> copyDst (a freshly inverted
+// coarse matrix into the buffer the iteration graphs read)
+void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s,
+	const Scalar* copySrc = nullptr, Scalar* copyDst = nullptr, size_t copyCount = 0);
 
 // out3 = {chi2 total, landmark scale part, pose scale part} gathered from the result slots of the kernels enqueued before
 void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s);

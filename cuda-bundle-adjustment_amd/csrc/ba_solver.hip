@@ -1319,11 +1319,14 @@ struct cuba_hip_solver
 	void zeroReduced() { waitAssembled(); if (schurAtomic || partHi >= 0 || !reducedZeroed) { d_red.zero(stream); reducedZeroed = true; } }
 	bool reducedZeroed = false;
 
-	void linearize(int mode, double lam)
+	// withBackup: the state is also copied into its backup (push() of the LM loop) -- inside the landmark pass's launch where possible
+	void linearize(int mode, double lam, bool withBackup = false)
 	{
 		waitAssembled();            // an overlapped coarse assembly may still be reading the previous reduced matrix
+		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
+		if (schurAtomic || separateCopies) { if (withBackup) push(); withBackup = false; }
 		if (schurAtomic) launch_linearize(g, st, sys, mode, lam, stream);
-		else launch_linearize_dm(g, st, sys, mode, lam, stream);
+		else launch_linearize_dm(g, st, sys, mode, lam, stream, withBackup ? d_state.data() : nullptr, d_backup.data(), d_state.size());
 	}
 
 	// assemble only: Hpp -> diagonal blocks, bp, raw Hll/bl, landmark part of the max diagonal
@@ -1381,12 +1384,12 @@ struct cuba_hip_solver
 		return v;
 	}
 
-	void schur()
+	void schur(bool withBackup = false)
 	{
 		need();
 		StageTimer tm(this, 4);
 		zeroReduced();
-		linearize(1, lambda);
+		linearize(1, lambda, withBackup);
 	}
 
 	// `tail` (optional): work that only makes sense once the solve has converged (back-substitution, update, evaluation of
@@ -1402,9 +1405,24 @@ struct cuba_hip_solver
 		const int maxIter = maxIterAlloc;
 		const Scalar tol2 = pcgTol * pcgTol;
 		d_fail.zero(stream);
-		// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
-		launch_pcg_setup_expand(g, st, sys, lambda, stream);
 		const bool twoLevel = sys.agg > 0;
+		// an inversion that ran on the second stream under the previous trial's PCG: its result moves into the buffer the iteration
+		// graphs read within the next launch
+		const size_t invCount = (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
+		bool takeInverse = false;
+		if (twoLevel && overlapActive() && coarseValid && pendingInv >= 0)
+		{
+			HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done
+			takeInverse = true; pendingInv = -1;
+		}
+		// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
+		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
+		if (takeInverse && separateCopies)
+		{
+			HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invCount * sizeof(Scalar), hipMemcpyDeviceToDevice, stream));
+			takeInverse = false;
+		}
+		launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
 		if (twoLevel)
 		{
 			// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
@@ -1422,12 +1440,6 @@ struct cuba_hip_solver
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
 					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
-				}
-				else if (pendingInv >= 0)
-				{
-					HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done: it ran under the previous PCG
-					HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
-					pendingInv = -1;
 				}
 				sys.acinv = d_coarse[2].data();
 				// this trial's matrix -> the inverse the next trial will use, on the other stream (after the copy above): every
@@ -1583,9 +1595,8 @@ struct cuba_hip_solver
 			for (; qn < maxq && rho < 0; qn++)
 			{
 				cntTrials++;
-				push();
 				lambda = lam;
-				schur();
+				schur(true);          // (with the push() of the reference's loop: the backup of the state rides in the landmark pass's launch)
 				// back-substitution, update and evaluation of the trial ride behind the first batch of PCG iterations
 				const std::function<void()> tail = [&] { backSubstitute(); update(); enqueueEvaluate(lam, true); };
 				const std::function<void()> undo = [&] { pop(); };
