@@ -294,6 +294,7 @@ struct cuba_hip_solver
 
 	// Completion of the work enqueued so far, learnt from the ticket the last reporting kernel writes into the mapped host
 	// block: a spin on host memory sees it ~1 us after the kernel, hipStreamSynchronize only after ~20 us.
+	bool failDirty = true;       // the device-side failure flag of the PCG may be non-zero
 	int expectedTicket = 0;
 	bool spinWait = true;
 	bool speculateTail = false;  // optimize(): enqueue back-substitution/update/evaluation behind the first PCG batch. Measured with
@@ -1404,7 +1405,7 @@ struct cuba_hip_solver
 		if (Pf == 0) return true;
 		const int maxIter = maxIterAlloc;
 		const Scalar tol2 = pcgTol * pcgTol;
-		d_fail.zero(stream);
+		if (failDirty) { d_fail.zero(stream); failDirty = false; }      // (the device flag only changes when a solve fails, and every solve reports it)
 		const bool twoLevel = sys.agg > 0;
 		// an inversion that ran on the second stream under the previous trial's PCG: its result moves into the buffer the iteration
 		// graphs read within the next launch
@@ -1507,7 +1508,7 @@ struct cuba_hip_solver
 			if (speculate) (*tail)();                                             // ends with its own report
 			else if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (the graphs end with this report)
 			waitReport();
-			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; lastSolveIters = 0; return false; }
+			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; lastSolveIters = 0; failDirty = true; return false; }
 			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 			if (speculate)
 			{
@@ -1736,7 +1737,7 @@ struct cuba_hip_solver
 			msOut[5] = 0; msOut[6] = 0;
 		}
 		msOut[4] = timeit([&] { launch_back_substitute(g, st, sys, lam, stream); });
-		d_fail.zero(stream);
+		d_fail.zero(stream); failDirty = true;
 		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	}
 
