@@ -178,7 +178,8 @@ __device__ __forceinline__ Scalar* pq_slot(const DeviceSystem& sys, int k) { ret
 // Deterministic second stage of every global sum (chi2, gain-ratio denominator): one workgroup adds the
 // per-workgroup partials in a fixed order and writes the total to out[0] (out[1..NSLOT) = 0, so hosts that add up a
 // slot group keep working).  No atomics anywhere => results are reproducible bit for bit.
-__device__ __forceinline__ void reduce_parts_body(const Scalar* __restrict__ parts, int n, Scalar* out, Scalar* sh)
+// per-thread share of a partial-sum array (1024 threads, fixed strides => fixed summation order)
+__device__ __forceinline__ Scalar parts_thread_sum(const Scalar* __restrict__ parts, int n)
 {
 	Scalar v0 = 0, v1 = 0, v2 = 0, v3 = 0;
 	int i = threadIdx.x;
@@ -188,21 +189,30 @@ __device__ __forceinline__ void reduce_parts_body(const Scalar* __restrict__ par
 		v0 += a; v1 += b; v2 += c; v3 += d;
 	}
 	for (; i < n; i += 1024) v0 += parts[i];
-	sh[threadIdx.x] = (v0 + v1) + (v2 + v3);
+	return (v0 + v1) + (v2 + v3);
+}
+
+// 1024 thread values -> their sum, in every lane of wave 0: a wave reduction (DPP, fixed order), 16 numbers through LDS, one more
+// wave reduction -- one barrier instead of the ten of a shared-memory tree
+__device__ __forceinline__ Scalar block_sum_1024(Scalar v, Scalar* sh16)
+{
+	v = wave_sum(v);
+	if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = v;
 	__syncthreads();
-	for (int stride = 512; stride > 0; stride >>= 1)
-	{
-		if (threadIdx.x < stride) sh[threadIdx.x] += sh[threadIdx.x + stride];
-		__syncthreads();
-	}
-	if (threadIdx.x < NSLOT) out[threadIdx.x] = threadIdx.x == 0 ? sh[0] : Scalar(0);
-	__syncthreads();       // sh may be reused
+	Scalar t = threadIdx.x < 16 ? sh16[threadIdx.x] : Scalar(0);
+	if (threadIdx.x < 64) t = wave_sum(t);
+	return t;
+}
+
+__device__ __forceinline__ void store_slot_group(Scalar* out, Scalar total)
+{
+	if (threadIdx.x < NSLOT) out[threadIdx.x] = threadIdx.x == 0 ? total : Scalar(0);
 }
 
 __global__ __launch_bounds__(1024) void reduce_parts_kernel(const Scalar* __restrict__ parts, int n, Scalar* out)
 {
-	__shared__ Scalar sh[1024];
-	reduce_parts_body(parts, n, out, sh);
+	__shared__ Scalar sh[16];
+	store_slot_group(out, block_sum_1024(parts_thread_sum(parts, n), sh));
 }
 
 static void launch_reduce_parts(const Scalar* parts, int n, Scalar* out, hipStream_t s)
@@ -1310,10 +1320,18 @@ __global__ __launch_bounds__(256) void eval_trial_kernel(DeviceGraph g, DeviceSy
 __global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, const Scalar* pA, int nA, Scalar* oA, const Scalar* pB, int nB, Scalar* oB,
 	const Scalar* pC, int nC, Scalar* oC)
 {
-	__shared__ Scalar sh[1024];
-	reduce_parts_body(pA, nA, oA, sh);
-	reduce_parts_body(pB, nB, oB, sh);
-	reduce_parts_body(pC, nC, oC, sh);
+	__shared__ Scalar sh[3][16];
+	// the three sums side by side: thread shares first, then one barrier for all of them (each is added exactly as
+	// reduce_parts_kernel adds it)
+	const Scalar vA = wave_sum(parts_thread_sum(pA, nA)), vB = wave_sum(parts_thread_sum(pB, nB)), vC = wave_sum(parts_thread_sum(pC, nC));
+	if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = vA; sh[1][threadIdx.x >> 6] = vB; sh[2][threadIdx.x >> 6] = vC; }
+	__syncthreads();
+	if (threadIdx.x < 64)
+	{
+		const bool in = threadIdx.x < 16;
+		const Scalar tA = wave_sum(in ? sh[0][threadIdx.x] : Scalar(0)), tB = wave_sum(in ? sh[1][threadIdx.x] : Scalar(0)), tC = wave_sum(in ? sh[2][threadIdx.x] : Scalar(0));
+		store_slot_group(oA, tA); store_slot_group(oB, tB); store_slot_group(oC, tC);
+	}
 	__threadfence_system();          // every writer's results before the ticket
 	__syncthreads();
 	if (threadIdx.x == 0 && sys.host_flags)
