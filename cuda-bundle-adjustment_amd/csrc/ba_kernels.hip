@@ -1466,7 +1466,9 @@ void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipS
 template <bool ROWCOPY>
 __device__ __forceinline__ void pcg_setup_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, int bid, int nb)
 {
-	const int i = bid * 256 + threadIdx.x;
+	// one pose per thread, 64 poses per workgroup (only its first wave works): every load / store of a thread is 288 bytes from its
+	// neighbour's, so the set-up is the address path of the CUs it runs on -- spread over four times as many of them
+	const int i = threadIdx.x < PCG_SETUP_POSES ? bid * PCG_SETUP_POSES + (int)threadIdx.x : g.Pf;
 	Scalar rz = 0;
 	if (i < g.Pf)
 	{
@@ -1516,20 +1518,17 @@ __device__ __forceinline__ void pcg_setup_body(const DeviceGraph& g, const Devic
 		}
 	}
 	rz = wave_sum(rz);
-	__shared__ Scalar part[4];
-	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rz;
-	__syncthreads();
 	if (sys.agg == 0)   // block-Jacobi only: this kernel produces r0.z0 -> slot 0 and, as "r_k.z_k for k = 0", ring slot 1
 	{
 		if (threadIdx.x == 0)
 		{
-			const Scalar s2 = part[0] + part[1] + part[2] + part[3];
+			const Scalar s2 = rz;
 			sys.rz[bid] = s2;
 			sys.rz[sys.rzStride + bid] = s2;
 		}
 		for (int t = nb + bid * 256 + threadIdx.x; t < sys.nrz; t += nb * 256) sys.rz[sys.rzStride + t] = 0;
 	}
-	if (i == 0) { *sys.iters = 0; *sys.done = 0; *sys.kbase = 0; }
+	if (bid == 0 && threadIdx.x == 0) { *sys.iters = 0; *sys.done = 0; *sys.kbase = 0; }
 }
 
 __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
@@ -1539,7 +1538,7 @@ __global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStr
 
 void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
 {
-	if (g.Pf > 0) hipLaunchKernelGGL(pcg_setup_kernel, dim3((g.Pf + 255) / 256), dim3(256), 0, s, g, st, sys, lambda);
+	if (g.Pf > 0) hipLaunchKernelGGL(pcg_setup_kernel, dim3((g.Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES), dim3(256), 0, s, g, st, sys, lambda);
 }
 
 __device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int lane, Scalar& rzk)
@@ -1630,7 +1629,7 @@ void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, co
 {
 	if (g.Pf <= 0) return;
 	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
-	const int nSetup = (g.Pf + 255) / 256;
+	const int nSetup = (g.Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES;
 	const unsigned nExpand = (unsigned)((total + 255) / 256);
 	const size_t pairs = copySrc ? copyCount / 2 : 0;            // (coarse dimensions are even)
 	const unsigned nCopy = pairs ? (unsigned)std::min<size_t>(1024, (pairs + 255) / 256) : 0;

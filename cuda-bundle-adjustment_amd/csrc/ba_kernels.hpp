@@ -20,6 +20,7 @@
 namespace cubahip
 {
 
+constexpr int PCG_SETUP_POSES = 64;   // poses per workgroup of the PCG set-up (= its partial sums of r0.z0 in block-Jacobi-only mode)
 constexpr int NSLOT = 16;            // partial-sum slots for global reductions (spreads same-address atomics)
 constexpr int WAVE = 64;
 constexpr int LIN_BLOCK = 256;       // 4 wavefronts per workgroup in the landmark-major kernels

@@ -915,7 +915,7 @@ struct cuba_hip_solver
 		for (auto& b : d_coarse) b.resize((size_t)36 * c.cl * c.cl * c.nc * c.nc);
 		d_rc.resize((size_t)12 * c.cl * c.nc); d_r2.resize((size_t)6 * Pf);
 		maxIterAlloc = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
-		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + c.spmvRows - 1) / c.spmvRows;
+		const int gridSetup = (Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + c.spmvRows - 1) / c.spmvRows;
 		rzStrideCfg = std::max(1, std::max(std::max(gridSetup, gridUpd), c.nc)); pqStrideCfg = std::max(1, gridSpmv);
 		d_rz.resize((size_t)5 * rzStrideCfg); d_pq.resize((size_t)4 * pqStrideCfg);
 	}
@@ -925,7 +925,7 @@ struct cuba_hip_solver
 	void publishStructure(int nblk, int nWaves, int nBig, int nOd, int nCb, int ellM, int ellOver, const CoarseCfg& c)
 	{
 		const int agg = c.agg, cl = c.cl, nc = c.nc, spmvRows = c.spmvRows;
-		const int gridSetup = (Pf + 255) / 256, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + spmvRows - 1) / spmvRows;
+		const int gridSetup = (Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + spmvRows - 1) / spmvRows;
 		st = DeviceStructure();
 		st.nWaves = nWaves; st.wave_lm = d_waveLm.data();
 		st.nBig = nBig; st.big_lm = d_bigLm.data(); st.big_scratch_ofs = d_bigOfs.data(); st.big_hpl = d_bigHpl.data();
