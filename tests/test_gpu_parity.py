@@ -232,18 +232,35 @@ def test_preconditioner_modes_agree(solvers, small_fp):
     assert its[16] < its[0] and its[5] < its[0] and its[2] < its[5], its       # the coarse level must pay off on a keyframe chain
 
 
-def test_overlapped_coarse_inversion_option(solvers):
-    """coarse_overlap=1 (inverse of trial k built on a second stream for trial k+1) solves the same problems."""
+def test_coarse_refresh_modes(solvers):
+    """The coarse inverse of trial k is built on a second stream for a later trial (default: under every trial for a coarse dimension
+    up to 768, under every third beyond); coarse_overlap=0 inverts in line and reuses the inverse for up to coarse_max_age solves.
+    Every mode solves the same problems, deterministically."""
     HipSolver, OracleSolver = solvers
     fp = flatten(synth_ba(200, 8000, 32000, seed=13))
     ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
-    h = HipSolver(fp, RK_HUBER, coarse_overlap=1, speculate_tail=1, spin_wait=0)      # the other off-by-default paths ride along
+    h = HipSolver(fp, RK_HUBER, speculate_tail=1, spin_wait=0)      # the off-by-default paths ride along
     a = h.optimize(6)["chi2"]
-    q0, t0, X0 = h.state()
     assert rel(a, ref) < CHI2_TOL
-    h2 = HipSolver(fp, RK_HUBER, coarse_overlap=1, speculate_tail=1)
+    assert h.counters()["coarse_refreshes"] >= 6          # one in line + one under every trial
+    h2 = HipSolver(fp, RK_HUBER, speculate_tail=1)
     assert np.array_equal(h2.optimize(6)["chi2"], a)          # still deterministic
-    assert h.counters()["coarse_refreshes"] >= 6
+    runs = {}
+    for name, opts in (("period 3", dict(coarse_overlap_period=3)), ("in line", dict(coarse_overlap=0)),
+                       ("in line, every solve", dict(coarse_overlap=0, coarse_max_age=0))):
+        g1 = HipSolver(fp, RK_HUBER, **opts); c1 = g1.optimize(6)["chi2"]
+        g2 = HipSolver(fp, RK_HUBER, **opts); c2 = g2.optimize(6)["chi2"]
+        assert rel(c1, ref) < CHI2_TOL, name
+        assert np.array_equal(c1, c2), name
+        runs[name] = g1.counters()["coarse_refreshes"]
+    assert runs["period 3"] < h.counters()["coarse_refreshes"] and runs["in line"] < runs["in line, every solve"], runs
+    # switching modes on a live handle (a pending inversion of the other mode must not leak into the next run)
+    h.set_option("coarse_overlap", 0)
+    b = h.optimize(3)["chi2"]                                  # continues from the result of the first run
+    assert np.isfinite(b).all() and b[0] <= a[-1] * (1 + 1e-12) and np.all(np.diff(b) <= 0)
+    h.set_option("coarse_overlap", 1)
+    c = h.optimize(2)["chi2"]
+    assert np.isfinite(c).all() and c[0] <= b[-1] * (1 + 1e-12)
 
 
 def test_golden_trajectories_on_gpu(solvers):
