@@ -236,10 +236,15 @@ struct cuba_hip_solver
 	// tile products): 9.43 -> 9.09 ms at KITTI-00 with a refresh under every trial; at S2M ten 0.85 ms sweeps per run cost the
 	// latency-bound PCG kernels more than they save (28.7 vs 28.4 ms), one under every third trial does pay (27.1 ms; G4M 67.6 -> 65.3).
 	int coarseOverlap = -1;       // -1 automatic, 0 off, 1 on
-	int coarseOverlapPeriod = -1; // trials between two overlapped refreshes: -1 automatic (1 up to a coarse dimension of 768, 3 beyond)
+	int coarseOverlapPeriod = -1; // trials between two overlapped refreshes: -1 automatic (1 up to a coarse dimension of 512, 2 up to 1024, 3 beyond)
 	int sideAge = 0;
 	bool overlapActive() const { return coarseOverlap != 0; }
-	int overlapPeriod() const { return coarseOverlapPeriod > 0 ? coarseOverlapPeriod : (6 * sys.cl * sys.nc <= 768 ? 1 : 3); }
+	int overlapPeriod() const
+	{
+		// KITTI-07 (Nc 372): 4.20 / 4.79 ms with period 1 / 2; KITTI-00 (672): 8.55 / 8.33 / 8.41 ms with 1 / 2 / 3; S2M (1500): 28.7 / 27.7 / 27.1 / 27.1 with 1 / 2 / 3 / 4
+		const int Nc = 6 * sys.cl * sys.nc;
+		return coarseOverlapPeriod > 0 ? coarseOverlapPeriod : Nc <= 512 ? 1 : Nc <= 1024 ? 2 : 3;
+	}
 	hipStream_t gjStream = nullptr;
 	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr;
 	int liveInv = 0, pendingInv = -1;   // buffer with the inverse in use / buffer the running inversion will leave its result in

@@ -94,7 +94,7 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    0 = constant only, 6 unknowns), "coarse_overlap" (default 1: the coarse matrix of a trial is assembled and inverted on a second,
    low-priority stream under that trial's PCG and serves from the next trial on -- only the first solve of a run inverts in line;
    0 = invert in line, on the policy of the next two options), "coarse_overlap_period" (trials between two overlapped inversions;
-   -1 = automatic: every trial up to a coarse dimension of 768, every third beyond), "coarse_max_age" (in-line mode; default 3: the coarse
+   -1 = automatic: every trial up to a coarse dimension of 512, every second up to 1024, every third beyond), "coarse_max_age" (in-line mode; default 3: the coarse
    inverse of the two-level preconditioner is reused for up to three further solves of a run; 0 = rebuild it for every
    solve), "coarse_refresh_growth" (in-line mode; default 1.6: rebuild early once a solve needs that many times the iterations of
    the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket

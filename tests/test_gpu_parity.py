@@ -234,7 +234,7 @@ def test_preconditioner_modes_agree(solvers, small_fp):
 
 def test_coarse_refresh_modes(solvers):
     """The coarse inverse of trial k is built on a second stream for a later trial (default: under every trial for a coarse dimension
-    up to 768, under every third beyond); coarse_overlap=0 inverts in line and reuses the inverse for up to coarse_max_age solves.
+    up to 512, under every second up to 1024, every third beyond); coarse_overlap=0 inverts in line and reuses the inverse for up to coarse_max_age solves.
     Every mode solves the same problems, deterministically."""
     HipSolver, OracleSolver = solvers
     fp = flatten(synth_ba(200, 8000, 32000, seed=13))
