@@ -16,6 +16,13 @@ Next to `value` the line carries
                  B_alg(trial) x trials / t_hot against 8.0 and 6.3 TB/s (SURVEY section 8d);
   cpu_baseline   the CPU oracle (our g2o-faithful restatement -- "port", not g2o itself) on the host cores:
                  all cores (OpenMP build) and single thread, nproc printed.
+  repeats        the timed block (exactly --steps steps, as `value`) five more times: median / min / max, so that a short
+                 timed region is not one sample;
+  shapes         every other single-GPU BASELINE.json configuration, driver-timed in the same invocation: kitti07
+                 (configs[0], with the CPU path timed beside it), s2m (configs[2]), g4m (configs[4]'s graph on one GPU):
+                 wall of 10 LM iterations (median / min / max of three runs under the same protocol), edge-iterations/s,
+                 PCG iterations, chi2 max-rel-diff against the oracle (live for kitti07, the committed
+                 tests/golden/baseline_shapes_chi2.json for all).
 
 N = 1 : BASELINE.json configs[1] -- ba_kitti_00 shape (1332 poses / 133383 landmarks / 561116 edges,
         synthetic stand-in, seed 0), fp64, Huber kernels as in samples/sample_comparison_with_g2o.cpp:195-200.
@@ -87,6 +94,81 @@ def contract_wall_leg(shape, E, runs=5):
     return res
 
 
+def source_sha16():
+    """Identity of the kernel sources the running library was built from (a PMC traffic file records the same at profiling time)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ba_kernels.hip", "ba_math.hpp", "ba_kernels.hpp"):
+        with open(os.path.join(ROOT, "cuda-bundle-adjustment_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def shapes_leg(rk, device_index, stream, names=("kitti07", "s2m", "g4m"), runs=3, cpu=True):
+    """Driver-timed numbers for the single-GPU BASELINE configurations the headline shape is not: for each shape one parity run
+    (10 LM iterations from the generator's initial guess, per-iteration chi2 against the oracle) and `runs` timed runs under the
+    bench protocol (1-iteration warm-up, then optimize(10) from that state, graph resident)."""
+    import torch
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import synth_named
+    gpath = os.path.join(ROOT, "tests", "golden", "baseline_shapes_chi2.json")
+    golden = json.load(open(gpath))["shapes"] if os.path.exists(gpath) else {}
+    res = {}
+    for name in names:
+        try:
+            fp = flatten(synth_named(name))
+            h = HipSolver(fp, rk, device=device_index, stream=stream)
+            got = h.optimize(LM_RUN)["chi2"]
+            rec = {"poses": fp.Pt, "landmarks": fp.Lt, "edges": fp.E, "chi2_first": float(got[0]), "chi2_last": float(got[-1])}
+            if name in golden and len(golden[name]["chi2"]) == len(got):
+                ref = np.array(golden[name]["chi2"])
+                rec["chi2_max_rel_diff_vs_golden"] = float(np.max(np.abs(got - ref) / ref))
+            h.set_state(fp.q, fp.t, fp.Xw)
+            h.optimize(1)                                    # the protocol's warm-up iteration
+            q1, t1, X1 = h.state()
+            walls, iters = [], []
+            for _ in range(runs):
+                h.set_state(q1, t1, X1)
+                c0 = h.counters()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                r = h.optimize(LM_RUN)["chi2"]
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t)
+                iters.append(h.counters()["pcg_iterations"] - c0["pcg_iterations"])
+                if len(r) != LM_RUN:
+                    raise RuntimeError(f"LM stopped after {len(r)} iterations")
+            med = float(np.median(walls))
+            rec.update({"wall_ms_10iter": med * 1e3, "wall_ms_10iter_min": min(walls) * 1e3, "wall_ms_10iter_max": max(walls) * 1e3,
+                        "runs": runs, "edge_iterations_per_s": fp.E * LM_RUN / med, "pcg_iterations_per_run": int(np.median(iters)),
+                        "hsc_blocks": h.counters()["hsc_blocks"], "coarse_dim": h.counters()["coarse_dim"],
+                        "unconverged_solves": h.pcg_history()[1]})
+            if name == "kitti07" and cpu:
+                # BASELINE configs[0] is the CPU-path configuration: the oracle on the host cores, same graph, same protocol
+                from oracle.oracle import OracleSolver
+                ref = OracleSolver(fp, rk).optimize(LM_RUN)["chi2"]
+                rec["chi2_max_rel_diff_vs_oracle"] = float(np.max(np.abs(got - ref) / ref))
+                base = {}
+                ncpu = os.cpu_count() or 1
+                for threads in sorted({1, min(ncpu, 8), min(ncpu, 16), min(ncpu, 32)}):
+                    orc = OracleSolver(fp, rk, threads=threads)
+                    orc.build_structure()
+                    orc.set_state(q1, t1, X1)
+                    tc = time.perf_counter(); r = orc.optimize(LM_RUN); tc = time.perf_counter() - tc
+                    base["threads_%d" % orc.threads] = {"value": fp.E * len(r["chi2"]) / tc, "unit": "edges/s", "cores": orc.threads, "seconds": tc}
+                best = max(base.values(), key=lambda b: b["value"])
+                rec["cpu_baseline"] = {"value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port", "nproc": ncpu,
+                                       "sample": "10 LM iterations of oracle/ba_oracle.cpp from the same warm state (structure analysis excluded)",
+                                       "thread_sweep_edges_per_s": {k: v["value"] for k, v in base.items()},
+                                       "single_thread_seconds": base["threads_1"]["seconds"]}
+            h.close()
+            res[name] = rec
+        except Exception as e:   # noqa: BLE001  -- one shape failing must not take the line down
+            res[name] = {"error": repr(e)[:300]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +177,8 @@ def main():
     ap.add_argument("--shape", default="kitti00")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the C++-API leg (the reference's sample protocol)")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the kitti07 / s2m / g4m legs (N = 1 only)")
+    ap.add_argument("--repeats", type=int, default=5, help="further timed blocks of --steps steps for the median / min / max")
     ap.add_argument("--partition", action="store_true",
                     help="N>1: ONE graph, landmark-partitioned over the ranks with an RCCL all-reduce of [Hsc|bsc|bp] "
                          "per trial (BASELINE config 5, strong scaling) instead of one independent graph per GPU")
@@ -191,6 +275,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the same block again, `--repeats` times: spread of the measurement (the line's `value` stays the block above)
+    block_ms = []
+    for _ in range(max(0, args.repeats)):
+        fence()
+        tb = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        tb = time.perf_counter() - tb
+        if dist is not None:
+            tt = torch.tensor([tb], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tb = float(tt.item())
+        block_ms.append(tb * 1e3)
+
     pcg_iters = c1["pcg_iterations"] - c0["pcg_iterations"]
     trials = c1["lm_trials"] - c0["lm_trials"]
     E = fp.E
@@ -222,20 +320,25 @@ def main():
         # measured HBM-side traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, see
         # the newest profiles/*_kitti00_pmc_traffic.json, written by scripts/profile_round.sh; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950)
+        # The file is a profile of an EARLIER run of this command, so it is checked against the running build: it records the hash of
+        # the kernel sources it was taken with (scripts/pmc_traffic.py) and must name the dominant kernel's launches; a file from
+        # other sources is still quoted but flagged `traffic_stale` (round-2 verdict: it used to go stale silently).
         import glob
-        traffic = None
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kitti00_pmc_traffic.json")))
+        traffic, traffic_stale = None, None
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kitti00_pmc_traffic.json")), key=os.path.getmtime)
         pmc_path = pmc_files[-1] if pmc_files else ""
         pmc_names = {"pcg_spmv": ["pcg_spmv_kernel"], "pcg_update": ["pcg2_fused_kernel"], "residual_chi2": ["residual_chi2_kernel"],
-                     "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1>", "pose_pass_kernel<1>", "block_pass_kernel"]}   # (exact names match first)
+                     "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1", "schur_pass_kernel"]}   # (exact names match first)
         if args.shape == "kitti00" and os.path.exists(pmc_path) and dom in pmc_names:
-            pk = json.load(open(pmc_path))["kernels"]
+            pj = json.load(open(pmc_path))
+            pk = pj["kernels"]
             def find(name):          # template instantiations carry their arguments in the name: match the exact name or "name<...>"
-                hits = [v for k, v in pk.items() if k == name or k.startswith(name + "<")]
+                hits = [v for k, v in pk.items() if k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name))]
                 return max(hits, key=lambda v: v["launches"]) if hits else None
             found = [find(n) for n in pmc_names[dom]]
             if all(f is not None for f in found):
                 traffic = sum(f["hbm_bytes_fetch_x2"] for f in found)
+                traffic_stale = pj.get("kernel_source_sha16") != source_sha16()
         # whole hot path: B_alg(trial) = 120 E3 + 96 E2 + 288 L + 2 * 288 nblk, achieved = B_alg x trials / t_hot.
         # The PCG's re-reads of the (L2 / Infinity-Cache resident) reduced matrix are deliberately NOT counted as HBM bytes.
         b_trial = 120 * fp.E3 + 96 * fp.E2 + 288 * fp.Lt + 2 * 288 * nblk
@@ -248,6 +351,7 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "traffic_source": os.path.basename(pmc_path) if traffic else None,
+                "traffic_stale": traffic_stale, "kernel_source_sha16": source_sha16(),
                 "kernels": kernels, "path": path}
         out = {
             "metric": "edges/sec (edge-iterations/s = E x LM iterations / wall, graph resident in HBM) + 10-iter LM wall-clock "
@@ -266,6 +370,9 @@ def main():
             "pcg_host_looks": c1["pcg_host_looks"] - c0["pcg_host_looks"], "coarse_refreshes": c1["coarse_refreshes"] - c0["coarse_refreshes"],
             "lm_trials": trials, "hsc_blocks": nblk, "schur_products": c1["schur_products"],
             "final_chi2": float(chi2[-1]),
+            "repeats": ({"blocks": len(block_ms), "steps_per_block": args.steps, "ms_per_step_median": float(np.median(block_ms)) / args.steps,
+                         "ms_per_step_min": min(block_ms) / args.steps, "ms_per_step_max": max(block_ms) / args.steps,
+                         "value_median": E * args.steps * graphs / (float(np.median(block_ms)) * 1e-3)} if block_ms else None),
             "roofline": roof,
         }
         # ---- CPU baseline + parity leg (rank 0, N = 1 only): the oracle on the host cores ------------
@@ -308,6 +415,9 @@ def main():
         # (samples/sample_comparison_with_g2o.cpp:74-79, 303-307).  Reported next to `value`, never as `value`.
         if world == 1 and not args.no_end_to_end:
             out["contract_wall"] = contract_wall_leg(args.shape, E)
+        # ---- the other single-GPU BASELINE configurations, driver-timed in the same line ----------------------------------
+        if world == 1 and not args.no_shapes and args.shape == "kitti00":
+            out["shapes"] = shapes_leg(rk, device_index, torch.cuda.current_stream().cuda_stream, cpu=not args.no_cpu_baseline)
     # ---- N > 1, independent-graphs mode: also measure BASELINE config 5's mode -- ONE graph of this shape, landmark-partitioned
     # over the ranks by the native driver with RCCL all-reduces -- and report it inside the same line as `partitioned`.  It is the
     # first place a multi-rank RCCL communicator of this library runs, so it is fenced: a watchdog on every rank prints the line

@@ -4,6 +4,7 @@
 // CudaBundleAdjustmentImpl::optimize (/root/reference/src/cuda_bundle_adjustment.cpp:793-857).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -48,6 +49,14 @@ struct cuba_hip_dist
 	double* hostScalars = nullptr;                  // pinned staging of the evaluation read-back
 	long long nLarge = 0, nSmall = 0, largeElems = 0, nTrials = 0;
 	std::string lastError;
+	bool partitionSet = false;
+
+	// (also the failure path of create(): whatever bind() already acquired is released)
+	~cuba_hip_dist()
+	{
+		if (ownComm && comm) (void)ncclCommDestroy(comm);
+		if (hostScalars) (void)hipHostFree(hostScalars);
+	}
 
 	void allreduce(void* buf, size_t count, bool max)
 	{
@@ -85,9 +94,12 @@ void bind(cuba_hip_dist* d, cuba_hip_solver* s, int rank, int world, int lb, int
 	d->lmTotal = sizes[2];
 	if (lb < 0 || le > d->lmTotal || lb > le) throw Fail{ CUBA_HIP_ERR_INVALID_ARGUMENT, "bad landmark range" };
 	SOLVER_TRY(cuba_hip_set_partition(s, lb, le));
+	d->partitionSet = true;
 	SOLVER_TRY(cuba_hip_build_structure(s));
 	SOLVER_TRY(cuba_hip_reduction_buffer(s, &d->red, &d->redCount));
 	HIP_TRY(hipHostMalloc((void**)&d->hostScalars, 64, hipHostMallocDefault));
+	// fault injection for tests/test_dist.py: a failure AFTER the handle was bound (what a refused ncclCommInitRank looks like)
+	if (std::getenv("CUBA_HIP_DIST_TEST_FAIL_AFTER_BIND")) throw Fail{ CUBA_HIP_ERR_RUNTIME, "injected failure after bind" };
 }
 
 template <class F>
@@ -107,7 +119,15 @@ int create(cuba_hip_dist** out, F&& init)
 	cuba_hip_dist* d = new (std::nothrow) cuba_hip_dist;
 	if (!d) return CUBA_HIP_ERR_RUNTIME;
 	const int rc = guarded(d, [&] { init(d); });
-	if (rc != CUBA_HIP_OK) { std::fprintf(stderr, "[cuba_hip_dist] create failed: %s\n", d->lastError.c_str()); delete d; return rc; }
+	if (rc != CUBA_HIP_OK)
+	{
+		std::fprintf(stderr, "[cuba_hip_dist] create failed: %s\n", d->lastError.c_str());
+		// the caller's solver handle gets its full landmark range back: left restricted it would silently optimise a subset
+		// of the landmarks when used single-GPU afterwards
+		if (d->partitionSet && d->s) (void)cuba_hip_set_partition(d->s, 0, -1);
+		delete d;
+		return rc;
+	}
 	*out = d;
 	return CUBA_HIP_OK;
 }
@@ -264,9 +284,7 @@ int cuba_hip_dist_destroy(cuba_hip_dist* d)
 {
 	if (!d) return CUBA_HIP_ERR_INVALID_ARGUMENT;
 	if (d->stream) (void)hipStreamSynchronize(d->stream);
-	if (d->ownComm && d->comm) (void)ncclCommDestroy(d->comm);
-	if (d->hostScalars) (void)hipHostFree(d->hostScalars);
-	delete d;
+	delete d;            // (the destructor releases the communicator and the pinned block; the solver handle is the caller's)
 	return CUBA_HIP_OK;
 }
 

@@ -1547,7 +1547,7 @@ __device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int m
 	rzk = wave_sum(load_parts(rz_slot(sys, k), rz_count(sys, k), lane));
 	const Scalar rz0 = wave_sum(load_parts(sys.rz, sys.nrz0, lane));
 	const bool on = k < maxIter && *sys.fail == 0 && rzk > tol2 * rz0 && rzk == rzk;
-	if (!on && blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+	if (!on && blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: a failed solve, not a converged one
 	return on;
 }
 
@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
 	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
 	{
-		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
 		return;
 	}
 	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
@@ -1855,7 +1855,7 @@ __global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, 
 	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
 	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
 	{
-		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
 		return;
 	}
 	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
@@ -2512,7 +2512,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		for (int w = 0; w < PCG2_T / 64; w++) { rzk += wsum[w]; rz0 += wsum[8 + w]; pqk += wsum[16 + w]; }
 		if (!(kabs < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
 		{
-			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.done = 1;
+			if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }
 			return;
 		}
 		if (!(pqk > 0))

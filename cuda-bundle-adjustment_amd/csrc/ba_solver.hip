@@ -890,7 +890,7 @@ struct cuba_hip_solver
 	{
 		int agg = pcgAggregate;
 		const int cl = coarseLinear ? 2 : 1;
-		// automatic size: coarse dimension <= ~700-960 (scripts/agg_sweep.py: iterations vs the O(Nc^3) inversion)
+		// automatic size: coarse dimension <= ~700-960 (scripts/experiments/agg_sweep.py: iterations vs the O(Nc^3) inversion)
 		// (small graphs want smaller aggregates: KITTI-07, 247 free poses: 24 / 16 / 12 / 8 / 6 / 4 poses -> 8.6 / 7.0 / 6.4 / 6.3 / 6.5 / 7.9 ms)
 		// (large graphs, inversion hidden under the PCG of earlier trials: S2M 44 / 40 / 36 / 32 poses -> 27.1 / 26.35 / 26.7 / 26.4 ms,
 		// G4M 88 / 72 / 64 / 56 / 48 -> 65.1 / 59.6 / 54.8 / 54.0 / 58.3 ms: the aggregate count may grow from 115 to 180 with the graph)
@@ -1010,7 +1010,7 @@ struct cuba_hip_solver
 	// Strongest-neighbour walk over the pose graph weighted by the number of Schur products per block (= co-visible landmarks):
 	// start at the pose of smallest weighted degree, always step to the heaviest unvisited neighbour, when stuck continue from
 	// the unvisited pose most strongly tied to the visited ones.  On a keyframe trajectory this IS the trajectory order, loop
-	// closures included (consecutive frames share far more landmarks than revisits do); scripts/precond_experiment6.py.
+	// closures included (consecutive frames share far more landmarks than revisits do); scripts/experiments/precond_experiment6.py.
 	// (A bandwidth-minimising order is the wrong tool: RCM interleaves the laps of a revisited stretch, the coarse space then
 	// cannot move one lap against the other and the PCG needs 1358 instead of 74 iterations.)
 	std::vector<int> chainOrder(const std::vector<int>& rowptr, const std::vector<int>& colind, const std::vector<int>& prodPtr) const
@@ -1225,7 +1225,9 @@ struct cuba_hip_solver
 		// 7. symmetric adjacency: the lower part of every row comes from the (column, row)-sorted list of the off-diagonal blocks
 		const int nAdj = std::max(0, 2 * nblk - Pf);
 		d_lowerPtr.resize((size_t)Pf + 1); d_adjPtr.resize((size_t)Pf + 1); d_adjBlk.resize(nAdj); d_adjCol.resize(nAdj); d_adjRow.resize(nAdj);
-		d_tmpI0.resize(std::max((size_t)nblk, d_tmpI0.size())); d_tmpI1.resize(std::max((size_t)nAdj, d_tmpI1.size()));
+		// (both scratch arrays serve step 8 as well: head flags / their scan over the nAdj = 2 nblk - Pf adjacency entries, which
+		// exceeds E and Pf + npairs when most pose pairs share a single landmark)
+		d_tmpI0.resize(std::max(std::max((size_t)nblk, (size_t)nAdj), d_tmpI0.size())); d_tmpI1.resize(std::max((size_t)nAdj, d_tmpI1.size()));
 		d_k64a.resize(std::max((size_t)nblk, d_k64a.size())); d_k64b.resize(std::max((size_t)nblk, d_k64b.size()));
 		topo::launch_transpose_keys(d_colind.data(), d_blkrow.data(), nblk, d_k64a.data(), d_v32a.data(), stream);
 		if (nblk) HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), d_topoTemp.size(), d_k64a.data(), d_k64b.data(), d_v32a.data(), d_v32b.data(), nblk, 64, stream));
@@ -1322,7 +1324,10 @@ struct cuba_hip_solver
 	// [hsc | bsc | bp] needs zeroing only where a block may have no writer: the atomic Schur kernel accumulates, and a landmark
 	// partition leaves blocks without local products; on the default path the pose pass writes every diagonal block, bp and bsc
 	// and the block pass every off-diagonal block
-	void zeroReduced() { waitAssembled(); if (schurAtomic || partHi >= 0 || !reducedZeroed) { d_red.zero(stream); reducedZeroed = true; } }
+	// (force: the assemble-only mode writes the diagonal blocks' upper triangles and bp only -- off-diagonal blocks, bsc and the lower
+	// triangles would otherwise keep a previous trial's values, which the stage API exposes through cuba_hip_get_array /
+	// cuba_hip_reduction_buffer and a multi-GPU driver sums)
+	void zeroReduced(bool force = false) { waitAssembled(); if (force || schurAtomic || partHi >= 0 || !reducedZeroed) { d_red.zero(stream); reducedZeroed = true; } }
 	bool reducedZeroed = false;
 
 	// withBackup: the state is also copied into its backup (push() of the LM loop) -- inside the landmark pass's launch where possible
@@ -1340,7 +1345,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 3);
-		zeroReduced();
+		zeroReduced(true);
 		d_maxdiag.zero(stream);
 		linearize(0, 0.0);
 	}
@@ -1379,7 +1384,7 @@ struct cuba_hip_solver
 	{
 		need();
 		StageTimer tm(this, 3);
-		zeroReduced();
+		zeroReduced(true);
 		d_maxdiag.zero(stream);
 		linearize(0, 0.0);
 		launch_pose_maxdiag(g, st, sys, stream);
@@ -1530,6 +1535,7 @@ struct cuba_hip_solver
 		runIters.push_back(itersDone);
 		lastSolveIters = itersDone;
 		if (coarseFresh) itersAtRefresh = itersDone;
+		if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);   // drivers that never call set_graph again: keep the latest
 		pcgHistory.push_back(converged ? itersDone : -itersDone);
 		if (!converged)
 		{
@@ -2090,6 +2096,12 @@ int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_
 {
 	return guarded(s, [&] {
 		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		if (landmark_begin == 0 && landmark_end == -1)          // remove the restriction: the handle evaluates the whole graph again
+		{
+			if (s->partHi >= 0) s->haveStructure = false;
+			s->partLo = 0; s->partHi = -1;
+			return;
+		}
 		if (landmark_begin < 0 || landmark_end > s->Lt || landmark_begin > landmark_end) throw ArgError{ "bad landmark range" };
 		s->partLo = landmark_begin; s->partHi = landmark_end;
 		s->haveStructure = false;

@@ -236,6 +236,7 @@ int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUB
    contributions, back-substitution and landmark updates are evaluated for those landmarks only.
    Per trial the driver sums cuba_hip_reduction_buffer() over the ranks between cuba_hip_schur and
    cuba_hip_solve_reduced; chi2 and the landmark parts of max-diagonal / scale are reduced as scalars. */
+/* (landmark_begin, landmark_end) = (0, -1) removes the restriction again. */
 int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_end);
 /* First half of cuba_hip_max_diagonal: accumulate Hpp (diagonal blocks of the reduction buffer), bp, Hll. */
 int cuba_hip_assemble(cuba_hip_solver* s);

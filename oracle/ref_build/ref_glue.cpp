@@ -12,6 +12,36 @@
 
 using namespace cuba;
 
+// Same-node stage baseline (round-2 verdict item 8): with ref_set_timing(reps > 0) every stage below is run `reps` times between
+// two HIP events and its average wall time on the device queue -- the reference's own blocking read-backs included, that is how
+// CudaBlockSolver calls these functions -- is left in ref_get_stage_ms().  Stage outputs of a timing run are NOT parity data
+// (the accumulating stages have then accumulated `reps` times); scripts/ref_stage_times.py is the only caller.
+namespace
+{
+int g_reps = 0;
+double g_stage_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+template <class F> void stage(int idx, F&& fn)
+{
+	if (g_reps <= 0) { fn(); return; }
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	fn();                                   // warm
+	hipDeviceSynchronize();
+	hipEventRecord(e0, 0);
+	for (int r = 0; r < g_reps; r++) fn();
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+	g_stage_ms[idx] = (double)ms / g_reps;
+	hipEventDestroy(e0); hipEventDestroy(e1);
+}
+}  // namespace
+
+extern "C" void ref_set_timing(int reps) { g_reps = reps; }
+// [0] computeActiveErrors x2  [1] fillZero + constructQuadraticForm x2  [2] maxDiagonal x2  [3] addLambda x2
+// [4] computeBschure  [5] computeHschure  [6] schurComplementPost  [7] computeScale + updatePoses + updateLandmarks
+extern "C" void ref_get_stage_ms(double* out8) { for (int i = 0; i < 8; i++) out8[i] = g_stage_ms[i]; }
+
 extern "C" int ref_run_trial(
 	int Pt, int Pf, int Lt, int Lf, const double* q, const double* t, const double* cam, const double* Xw,
 	int E2, int E3, const int* eP, const int* eL, const double* meas3, const double* omega,
@@ -81,38 +111,49 @@ extern "C" int ref_run_trial(
 	gpu::findHschureMulBlockIndices(d_Hpl, d_Hsc, d_mulIds);
 
 	// ---- one trial, stage by stage ------------------------------------------------------------------
-	const Scalar c2 = gpu::computeActiveErrors(d_qs, d_ts, d_cameras, d_Xws, d_meas2, d_om2, d_pl2, k2, d_err2, d_Xcs2, d_chi);
-	const Scalar c3 = gpu::computeActiveErrors(d_qs, d_ts, d_cameras, d_Xws, d_meas3, d_om3, d_pl3, k3, d_err3, d_Xcs3, d_chi);
+	Scalar c2 = 0, c3 = 0;
+	stage(0, [&] {
+		c2 = gpu::computeActiveErrors(d_qs, d_ts, d_cameras, d_Xws, d_meas2, d_om2, d_pl2, k2, d_err2, d_Xcs2, d_chi);
+		c3 = gpu::computeActiveErrors(d_qs, d_ts, d_cameras, d_Xws, d_meas3, d_om3, d_pl3, k3, d_err3, d_Xcs3, d_chi);
+	});
 	*chi2 = c2 + c3;
-	d_Hpp.fillZero(); d_Hll.fillZero(); d_bp.fillZero(); d_bl.fillZero();
-	gpu::constructQuadraticForm(d_Xcs2, d_qs, d_cameras, d_err2, d_om2, d_pl2, d_e2h2, d_fl2, k2, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl);
-	gpu::constructQuadraticForm(d_Xcs3, d_qs, d_cameras, d_err3, d_om3, d_pl3, d_e2h3, d_fl3, k3, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl);
+	stage(1, [&] {
+		d_Hpp.fillZero(); d_Hll.fillZero(); d_bp.fillZero(); d_bl.fillZero();
+		gpu::constructQuadraticForm(d_Xcs2, d_qs, d_cameras, d_err2, d_om2, d_pl2, d_e2h2, d_fl2, k2, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl);
+		gpu::constructQuadraticForm(d_Xcs3, d_qs, d_cameras, d_err3, d_om3, d_pl3, d_e2h3, d_fl3, k3, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl);
+	});
 	cudaMemcpy(Hpp, d_Hpp.values(), sizeof(double) * 36 * Pf, cudaMemcpyDeviceToHost);
 	cudaMemcpy(bp, d_bp.values(), sizeof(double) * 6 * Pf, cudaMemcpyDeviceToHost);
 	cudaMemcpy(Hll, d_Hll.values(), sizeof(double) * 9 * Lf, cudaMemcpyDeviceToHost);
 	cudaMemcpy(bl, d_bl.values(), sizeof(double) * 3 * Lf, cudaMemcpyDeviceToHost);
 	{
 		DeviceBuffer<Scalar> d_buffer(16);
-		const Scalar a = gpu::maxDiagonal(d_Hpp, d_buffer), b = gpu::maxDiagonal(d_Hll, d_buffer);
+		Scalar a = 0, b = 0;
+		stage(2, [&] { a = gpu::maxDiagonal(d_Hpp, d_buffer); b = gpu::maxDiagonal(d_Hll, d_buffer); });
 		*maxdiag = a > b ? a : b;
+	}
+	if (g_reps > 0)
+	{
+		// timing only: add + restore so that the diagonals end up damped exactly once
+		stage(3, [&] { gpu::addLambda(d_Hpp, lambda, d_HppBak); gpu::addLambda(d_Hll, lambda, d_HllBak); gpu::restoreDiagonal(d_Hpp, d_HppBak); gpu::restoreDiagonal(d_Hll, d_HllBak); });
 	}
 	gpu::addLambda(d_Hpp, lambda, d_HppBak);
 	gpu::addLambda(d_Hll, lambda, d_HllBak);
-	gpu::computeBschure(d_bp, d_Hpl, d_Hll, d_bl, d_bsc, d_invHll, d_HplInvHll);
-	gpu::computeHschure(d_Hpp, d_HplInvHll, d_Hpl, d_mulIds, d_Hsc);
+	stage(4, [&] { gpu::computeBschure(d_bp, d_Hpl, d_Hll, d_bl, d_bsc, d_invHll, d_HplInvHll); });
+	stage(5, [&] { gpu::computeHschure(d_Hpp, d_HplInvHll, d_Hpl, d_mulIds, d_Hsc); });
 	cudaMemcpy(bsc, d_bsc.values(), sizeof(double) * 6 * Pf, cudaMemcpyDeviceToHost);
 	cudaMemcpy(hsc, d_Hsc.values(), sizeof(double) * 36 * nblk, cudaMemcpyDeviceToHost);
 	cudaMemcpy(invHll, d_invHll.values(), sizeof(double) * 9 * Lf, cudaMemcpyDeviceToHost);
 	cudaMemcpy(d_xp.values(), xp_in, sizeof(double) * 6 * Pf, cudaMemcpyHostToDevice);   // stands in for cuSOLVER
-	gpu::schurComplementPost(d_invHll, d_bl, d_Hpl, d_xp, d_xl);
+	stage(6, [&] { gpu::schurComplementPost(d_invHll, d_bl, d_Hpl, d_xp, d_xl); });
 	cudaMemcpy(xl, d_xl.values(), sizeof(double) * 3 * Lf, cudaMemcpyDeviceToHost);
-	gpu::computeScale(d_x, d_b, d_chi, lambda);
-	d_chi.download(scale);
-	{
+	stage(7, [&] {
+		gpu::computeScale(d_x, d_b, d_chi, lambda);
+		d_chi.download(scale);
 		// updatePoses covers xp.size() == Pf free poses, updateLandmarks the Lf free landmarks
 		gpu::updatePoses(d_xp, d_qs, d_ts);
 		gpu::updateLandmarks(d_xl, d_Xws);
-	}
+	});
 	d_qs.download((Vec4d*)q_out); d_ts.download((Vec3d*)t_out); d_Xws.download((Vec3d*)Xw_out);
 	const Scalar a2 = gpu::computeActiveErrors(d_qs, d_ts, d_cameras, d_Xws, d_meas2, d_om2, d_pl2, k2, d_err2, d_Xcs2, d_chi);
 	const Scalar a3 = gpu::computeActiveErrors(d_qs, d_ts, d_cameras, d_Xws, d_meas3, d_om3, d_pl3, k3, d_err3, d_Xcs3, d_chi);

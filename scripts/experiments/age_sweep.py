@@ -1,6 +1,6 @@
-"""Coarse-inverse reuse sweep: iterations / wall per 10-iteration run vs (coarse_max_age, coarse_refresh_growth).  python scripts/age_sweep.py [shape]"""
+"""Coarse-inverse reuse sweep: iterations / wall per 10-iteration run vs (coarse_max_age, coarse_refresh_growth).  python scripts/experiments/age_sweep.py [shape]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

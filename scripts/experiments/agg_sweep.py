@@ -1,6 +1,6 @@
-"""Aggregate-size sweep of the two-level preconditioner: iterations / wall per 10-iteration run.  python scripts/agg_sweep.py [shape]"""
+"""Aggregate-size sweep of the two-level preconditioner: iterations / wall per 10-iteration run.  python scripts/experiments/agg_sweep.py [shape]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

@@ -2,7 +2,7 @@
 system for different coarse spaces of (nearly) the same dimension: piecewise constant per aggregate (what the GPU path
 uses), constant + linear per aggregate, and linear hat functions between aggregate centres."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

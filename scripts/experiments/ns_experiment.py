@@ -1,9 +1,9 @@
 """CPU experiment (oracle only, no GPU): can the dense coarse inverse of the two-level preconditioner be carried from
 one LM trial to the next by Newton-Schulz refinement X <- X (2I - Ac X) instead of a fresh Gauss-Jordan inversion?
 For every LM iteration of a 10-iteration run: ||I - Ac_i X_{i-1}||_2, and PCG iterations (tol 1e-7) with the exact
-inverse, with the stale inverse and after 1 / 2 refinement steps.   python scripts/ns_experiment.py [shape] [agg]"""
+inverse, with the stale inverse and after 1 / 2 refinement steps.   python scripts/experiments/ns_experiment.py [shape] [agg]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

@@ -1,7 +1,7 @@
 """A/B of solver options in one process: min and median wall of a 10-iteration run over several repeats.
-   python scripts/option_ab.py kitti00 spin_wait=0 spin_wait=1,speculate_tail=0 ..."""
+   python scripts/experiments/option_ab.py kitti00 spin_wait=0 spin_wait=1,speculate_tail=0 ..."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

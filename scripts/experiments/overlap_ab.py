@@ -1,6 +1,6 @@
-"""A/B of the overlapped coarse inversion (second stream) against the lagged in-stream refresh.  python scripts/overlap_ab.py [shape]"""
+"""A/B of the overlapped coarse inversion (second stream) against the lagged in-stream refresh.  python scripts/experiments/overlap_ab.py [shape]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

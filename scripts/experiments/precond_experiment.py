@@ -1,6 +1,6 @@
 """CPU experiment: PCG iteration counts on the KITTI-00-shaped reduced system for several preconditioners."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

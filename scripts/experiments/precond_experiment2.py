@@ -1,6 +1,6 @@
 """CPU experiment 2: coarse-space variants for the two-level PCG preconditioner on the KITTI-00-shaped system."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

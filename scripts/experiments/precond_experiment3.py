@@ -1,6 +1,6 @@
 """CPU experiment 3: block size of the Jacobi level (1/2/4/8 poses per block) combined with the aggregate coarse level."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

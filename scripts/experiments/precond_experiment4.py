@@ -2,7 +2,7 @@
 parts of the two-level preconditioner: dense aggregate blocks (non-overlapping and overlapping additive Schwarz) next to the
 6x6 block-Jacobi used so far, all with the constant + linear coarse space."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp, scipy.linalg as sl
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

@@ -4,7 +4,7 @@ chart of the poses (T <- exp(d) T, world -> camera) it reads d_i = Ad(T_i) xi --
 the 6 columns of Ad(T_i) (and optionally the same times a linear weight), against the constant (+ linear) functions in the
 chart that round 1 used."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from scipy.spatial.transform import Rotation
 from cuba_amd.synth import synth_named

@@ -2,7 +2,7 @@
 two-level preconditioner, whose aggregates are runs of consecutive pose indices?  Iterations (tol 1e-7) on the KITTI-00-shaped
 reduced system for: the id order (= trajectory order), RCM of it, a random shuffle, RCM of the shuffle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from scipy.sparse.csgraph import reverse_cuthill_mckee
 from cuba_amd.synth import synth_named

@@ -3,7 +3,7 @@ constant + linear functions (as at KITTI-00); its coarse matrix is too large to 
 by its own 12x12 block-Jacobi and corrected by a level 2 of groups of level-1 nodes (dense inverse).  Compared with the current
 two-level scheme whose aggregates grow with the pose count."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

@@ -7,7 +7,7 @@ linear coarse functions as the built two-level preconditioner; compared are the 
 An iteration of the built solver is 12.3 us (5.9 SpMV + 6.4 fused update / coarse level); an extra SpMV-like pass costs ~6 us and an
 extra coarse solve ~6 us more."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

@@ -1,7 +1,7 @@
 """PCG tolerance x coarse-inverse age sweep: iterations, wall, chi2 parity and estimate RMSE vs the oracle.
-   python scripts/tol_sweep.py [shape]"""
+   python scripts/experiments/tol_sweep.py [shape]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cuba_amd.synth import synth_named
 from cuba_amd.graph import flatten

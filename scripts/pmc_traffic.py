@@ -19,7 +19,18 @@ def collect(d, counter):
 
 fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
-out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python scripts/prof_run.py kitti00 1; "
+def source_sha16():
+    """hash of the kernel sources this profile was taken with (bench.py flags a traffic file from other sources as stale)"""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("ba_kernels.hip", "ba_math.hpp", "ba_kernels.hpp"):
+        with open(os.path.join(root, "cuda-bundle-adjustment_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+out = {"kernel_source_sha16": source_sha16(), "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python scripts/prof_run.py kitti00 1; "
                "KiB per launch as reported; FETCH_SIZE under-counts wide coalesced streams by 2x on gfx950 (MI355X_MICROARCH.md), "
                "other access widths uncalibrated -> both the raw sum and the fetch-doubled sum are given",
        "kernels": {}}

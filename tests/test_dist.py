@@ -101,7 +101,7 @@ def test_native_driver_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
-def _run_native_ranks(fp, world, iters, make_comm_args):
+def _run_native_ranks(fp, world, iters, make_comm_args, precision="f64"):
     """Ranks as host threads on one GPU, each with its own solver handle + native driver over an in-process communicator."""
     from cuba_amd.capi import HipSolver
     from cuba_amd.dist import NativeDist
@@ -110,8 +110,8 @@ def _run_native_ranks(fp, world, iters, make_comm_args):
 
     def work(c):
         try:
-            h = HipSolver(fp, RK_HUBER)
-            d = NativeDist(h, fp, c.rank, world, comm=c)
+            h = HipSolver(fp, RK_HUBER, precision=precision)
+            d = NativeDist(h, fp, c.rank, world, comm=c, precision=precision)
             chi2 = d.optimize(iters)
             out[c.rank] = (chi2, d.complete_solution(), d.counters())
             d.close()
@@ -142,6 +142,66 @@ def test_native_driver_emulated_ranks(world):
         assert c["small_allreduces"] == c["lm_trials"] + 1 + 1          # evaluation per trial + first F + max-diagonal
     assert all(np.array_equal(out[0][0], o[0]) for o in out[1:])
     assert all(np.array_equal(a, b) for o in out[1:] for a, b in zip(out[0][1], o[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_native_driver_float32_build_emulated_ranks(world):
+    """BASELINE configs[4] "plus USE_FLOAT32 variant" (ref option: src/scalar.h:25-29, CMakeLists.txt:7): libcuba_hip_dist_f32.so
+    driving libcuba_hip_f32.so handles, 2 and 8 ranks emulated as threads.  Replicas bit-identical (fixed summation orders in
+    fp32 as in fp64), the trajectory follows the fp32 single handle to fp32 resolution and the oracle to the stated fp32
+    tolerance (chi2 1e-4 relative)."""
+    from cuba_amd.capi import HipSolver
+    from oracle.oracle import OracleSolver
+    fp = flatten(synth_ba(120, 6000, 24000, seed=9))
+    ref = OracleSolver(fp, RK_HUBER).optimize(8)["chi2"]
+    single = HipSolver(fp, RK_HUBER, precision="f32")
+    assert single.scalar_size == 4
+    want = single.optimize(8)["chi2"]
+    out = _run_native_ranks(fp, world, 8, None, precision="f32")
+    for chi2, (q, t, X), c in out:
+        m = min(len(chi2), len(ref))
+        assert m >= 6                                                       # fp32 may stop early once the gain is below its resolution
+        assert np.all(np.abs(chi2[:m] - ref[:m]) <= 1e-4 * ref[:m])
+        mm = min(len(chi2), len(want))
+        assert np.all(np.abs(chi2[:mm] - want[:mm]) <= 1e-4 * want[:mm])     # partial sums are added in another order than on one handle
+        assert c["large_allreduces"] == c["lm_trials"] + 1 + 1
+    assert all(np.array_equal(out[0][0], o[0]) for o in out[1:])
+    assert all(np.array_equal(a, b) for o in out[1:] for a, b in zip(out[0][1], o[1]))
+
+
+@pytest.mark.gpu
+def test_failed_driver_creation_leaves_the_solver_handle_unrestricted():
+    """cuba_hip_dist_create_custom with an incomplete collective table fails AFTER it has bound the solver handle; the handle must
+    come back with its full landmark range (round-2 advisor finding) -- a single-GPU optimize on it equals a fresh handle's."""
+    import ctypes as C
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.dist import load_dist_library
+    fp = flatten(synth_ba(**GRAPH))
+    want = HipSolver(fp, RK_HUBER).optimize(5)["chi2"]
+    h = HipSolver(fp, RK_HUBER)
+    lib = load_dist_library()
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+    class Ops(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("allreduce_sum", FN), ("allreduce_max", FN)]
+    d = C.c_void_p()
+    # (a) rejected before binding: incomplete table
+    assert lib.cuba_hip_dist_create_custom(h.h, C.byref(Ops(None, FN(0), FN(0))), 0, 2, 0, fp.Lt // 2, C.byref(d)) != 0 and not d.value
+    # (b) fails after set_partition + build_structure (injected: what a refused ncclCommInitRank looks like)
+    import os
+    os.environ["CUBA_HIP_DIST_TEST_FAIL_AFTER_BIND"] = "1"
+    try:
+        ok = lambda *a: 0      # noqa: E731
+        ops = Ops(None, FN(ok), FN(ok))
+        assert lib.cuba_hip_dist_create_custom(h.h, C.byref(ops), 0, 2, 0, fp.Lt // 2, C.byref(d)) != 0 and not d.value
+    finally:
+        del os.environ["CUBA_HIP_DIST_TEST_FAIL_AFTER_BIND"]
+    got = h.optimize(5)["chi2"]
+    assert np.array_equal(got, want)
+    h.set_partition(0, fp.Lt // 2); h.set_partition(0, -1)          # and the explicit way to lift a restriction
+    h.set_state(fp.q, fp.t, fp.Xw)
+    assert np.array_equal(h.optimize(5)["chi2"], want)
 
 
 @pytest.mark.gpu

@@ -160,3 +160,19 @@ def test_golden_trajectories():
         fp = flatten(synth_ba(**case["graph"]))
         res = OracleSolver(fp, tuple(map(tuple, case["robust"]))).optimize(case["iterations"])
         assert np.allclose(res["chi2"], case["chi2"], rtol=1e-9), case["name"]
+
+
+def test_baseline_shape_golden_kitti07():
+    """tests/golden/baseline_shapes_chi2.json (what bench.py checks its driver-timed KITTI-07 / S2M / G4M runs against) is the
+    oracle's own output: re-derive its KITTI-07 entry here, every CPU run."""
+    import json
+    from cuba_amd.synth import synth_named
+    with open(os.path.join(os.path.dirname(__file__), "golden", "baseline_shapes_chi2.json")) as f:
+        gold = json.load(f)
+    assert set(gold["shapes"]) >= {"kitti07", "kitti00", "s2m", "g4m"}
+    rk = tuple((int(k), float(d)) for k, d in gold["robust"])
+    fp = flatten(synth_named("kitti07"))
+    e = gold["shapes"]["kitti07"]
+    assert (fp.Pt, fp.Lt, fp.E) == (e["P"], e["L"], e["E"])
+    got = OracleSolver(fp, rk).optimize(gold["iterations"])["chi2"]
+    assert len(got) == len(e["chi2"]) and np.allclose(got, e["chi2"], rtol=1e-12)

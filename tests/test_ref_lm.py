@@ -40,6 +40,15 @@ def cases():
     yield "kitti07_like", synth_ba(120, 6000, 24000, seed=9), RK_HUBER, 10
 
 
+def full_size_cases():
+    """BASELINE configs[0] and configs[1] at full size (round-2 verdict: the reference-run pins stopped at 120 poses).
+    KITTI-07 shape: n = 1482, the reference's stand-in linear solver factorises it on the host as before; KITTI-00 shape:
+    n = 7986, the same exact dense Cholesky through rocSOLVER on the device (oracle/ref_build/ref_linear_solver.cpp)."""
+    from cuba_amd.synth import synth_named
+    yield "kitti07_full", synth_named("kitti07"), RK_HUBER, 10
+    yield "kitti00_full", synth_named("kitti00"), RK_HUBER, 10
+
+
 def in_graph_order(fp, g, state):
     """solver-order (q, t, X) -> the graph's row order (vertices the solver left out keep the graph's values)"""
     h = copy.deepcopy(g)
@@ -94,3 +103,49 @@ def test_warm_start_protocol_follows_the_reference():
     fp2 = flatten(g2); h2 = HipSolver(fp2, RK_HUBER, pcg_tol=1e-11)
     got = h2.optimize(10)["chi2"]
     assert len(got) == len(ref2["chi2"]) and np.all(np.abs(got - ref2["chi2"]) <= HIP_TOL * ref2["chi2"])
+
+
+@pytest.mark.parametrize("name", ["kitti07_full", "kitti00_full"])
+def test_full_size_lm_trajectory_follows_the_reference(name):
+    """The reference's own optimiser (its LM loop, block solver and all kernels, compiled in place) at the full BASELINE
+    shapes, under the samples' protocol (sample_comparison_with_g2o.cpp:303-307): initialize() + optimize(1) warm-up, then
+    initialize() + optimize(10) from the written-back estimates.  The CPU oracle must follow it to <= 1e-9 on every
+    per-iteration chi2, the HIP path to <= 1e-8 at pcg_tol = 1e-11 and to <= 1e-6 (the north star's bar) at the default
+    tolerance; final estimates and per-edge chi2 likewise.  All deviations are printed before anything is asserted."""
+    from cuba_amd.capi import HipSolver
+    from oracle.oracle import OracleSolver
+    g, rk, iters = {c[0]: c[1:] for c in full_size_cases()}[name]
+    # warm-up run of the reference, then the timed-protocol run from its written-back estimates
+    warm = ref_lm.run(g, rk, 1)
+    g1 = copy.deepcopy(g); g1.pose_q, g1.pose_t, g1.lm_X = warm["q"], warm["t"], warm["Xw"]
+    ref = ref_lm.run(g1, rk, iters)
+    assert len(ref["chi2"]) == iters
+    fp0 = flatten(g)
+    # every implementation runs its OWN warm-up iteration (that is the protocol), then 10 iterations from its own state
+    dev = {}
+    o0 = OracleSolver(fp0, rk); o0.optimize(1)
+    go = copy.deepcopy(g); write_back(go, fp0, *o0.state())
+    fpo = flatten(go); o = OracleSolver(fpo, rk); ro = o.optimize(iters)["chi2"]
+    dev["oracle chi2"] = float(np.abs(ro / ref["chi2"] - 1).max()) if len(ro) == iters else np.inf
+    runs = {}
+    for label, opts in (("hip tight", dict(pcg_tol=1e-11)), ("hip default", dict())):
+        h0 = HipSolver(fp0, rk, **opts); h0.optimize(1)
+        gh = copy.deepcopy(g); write_back(gh, fp0, *h0.state())
+        fph = flatten(gh); h = HipSolver(fph, rk, **opts); rh = h.optimize(iters)["chi2"]
+        dev[label + " chi2"] = float(np.abs(rh / ref["chi2"] - 1).max()) if len(rh) == iters else np.inf
+        runs[label] = (fph, h)
+        assert h.pcg_history()[1] == 0
+    est = {}
+    for label, fp, solver in (("oracle", fpo, o), ("hip tight", *runs["hip tight"]), ("hip default", *runs["hip default"])):
+        for nm, a, b in zip("qtX", in_graph_order(fp, g, solver.state()), (ref["q"], ref["t"], ref["Xw"])):
+            est[f"{label} {nm}"] = float(np.abs(a - b).max())
+    fph, h = runs["hip tight"]
+    per_edge = np.zeros(g.nedges); per_edge[fph.edge_src] = h.chi_squares()
+    want = np.concatenate([ref["chi_mono"], ref["chi_stereo"]])
+    dev["hip tight per-edge chi2 (abs / max)"] = float(np.abs(per_edge - want).max() / max(1.0, np.abs(want).max()))
+    print(f"\n[{name}] vs the reference's own optimiser: " + ", ".join(f"{k} {v:.2e}" for k, v in {**dev, **est}.items()))
+    assert dev["oracle chi2"] <= 1e-9 and dev["hip tight chi2"] <= 1e-8 and dev["hip default chi2"] <= 1e-6, dev
+    for k, v in est.items():
+        lim = 1e-7 if k.startswith("oracle") else 1e-6 if "tight" in k else (1e-8 if k.endswith(" q") else 1e-6) * 10
+        assert v <= lim, (k, v, lim)
+    assert dev["hip tight per-edge chi2 (abs / max)"] <= 1e-6
