@@ -1005,12 +1005,13 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	for (int p = (on ? st.prod_ptr[blk] : 0) + gl; p < p1; p += BP_GROUP)
 	{
 		EdgeLinT<ET> La, Lb; ET wa, wb, Xa[3], Xb[3]; int il, il2;
-		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_ea[p], Ra, cama, La, wa, il, Xa);
-		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_eb[p], Rb, camb, Lb, wb, il2, Xb);
-		const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+		// the landmark comes from the product list, not from record a: all three gathers of a product are issued together
+		const Scalar* ls = sys.lm_sys + 9 * (size_t)st.prod_lm[p];
 		ET inv[6];
 #pragma unroll
 		for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
+		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_ea[p], Ra, cama, La, wa, il, Xa);
+		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_eb[p], Rb, camb, Lb, wb, il2, Xb);
 		// S = wa wb JL_a inv JL_b^T  (measurement x measurement)
 		ET M1[3][3], S[3][3];
 #pragma unroll
@@ -1240,7 +1241,11 @@ __global__ __launch_bounds__(256) void big_back_substitute_kernel(DeviceGraph g,
 {
 	__shared__ Scalar red[4][3];
 	const int il = st.big_lm[blockIdx.x];
-	if (il >= g.Lf) return;
+	if (il >= g.Lf)
+	{
+		if (threadIdx.x == 0) sys.parts[st.nWaves + blockIdx.x] = 0;      // (a fixed landmark has no increment, but its partial is summed)
+		return;
+	}
 	const int e0 = g.lm_ptr[il], e1 = g.lm_ptr[il + 1];
 	Scalar acc[3] = { 0, 0, 0 };
 	for (int e = e0 + threadIdx.x; e < e1; e += 256)
@@ -1424,6 +1429,270 @@ void launch_update_state(const DeviceGraph& g, const DeviceSystem& sys, hipStrea
 {
 	const int pb = (g.Pf + 255) / 256, lb = (g.Lf * 3 + 255) / 256;
 	if (pb + lb > 0) hipLaunchKernelGGL(update_state_kernel, dim3(pb + lb), dim3(256), 0, s, g, sys, pb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused tail of an LM trial (optimize() only): back-substitution, update and evaluation of the trial in ONE pass over the edges.
+// A landmark's wave computes xl from the PRE-update estimate (read from the state backup the landmark pass of this trial made,
+// so the pose-update workgroups of the same launch may overwrite the live state meanwhile), stores xl and Xw + xl, and then every
+// lane evaluates its own edge at the updated estimate: its pose is updated in registers by the very code the pose-update
+// workgroups run (pose_exp_update on the same inputs), its landmark comes through LDS from the head lane.  Replaces
+// schurComplementPostKernel + updatePosesKernel + updateLandmarksKernel + computeActiveErrorsKernel + computeScaleKernel
+// (cuda_block_solver.cu:1029-1091, 733-786) for one trial: the edge stream is read twice per trial instead of three times.
+// Roles by workgroup index: [0, nLmGroups) landmark waves, then poseBlocks pose-update workgroups, then nScale workgroups for the
+// pose part of the gain-ratio denominator.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Scalar finish_landmark_x(const DeviceSystem& sys, int il, const Scalar csum[3], Scalar lambda, Scalar xl[3])
+{
+	const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+	Scalar inv[6], bl[3], cl[3];
+#pragma unroll
+	for (int k = 0; k < 6; k++) inv[k] = ls[k];
+#pragma unroll
+	for (int k = 0; k < 3; k++) { bl[k] = ls[6 + k]; cl[k] = bl[k] - csum[k]; }
+	Scalar sc = 0;
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+	{
+		xl[i] = inv[sym3_idx(i, 0)] * cl[0] + inv[sym3_idx(i, 1)] * cl[1] + inv[sym3_idx(i, 2)] * cl[2];
+		sys.xl[3 * (size_t)il + i] = xl[i];
+		sc += xl[i] * (lambda * xl[i] + bl[i]);
+	}
+	return sc;
+}
+
+// robust chi2 term of an edge at the UPDATED estimate: (q0, t0) is the pre-update pose, upd its increment (poseFree = false: fixed pose)
+__device__ __forceinline__ Scalar updated_edge_rho(const DeviceGraph& g, const Scalar q0[4], const Scalar t0[3], const Scalar cam[5], const Scalar upd[6], bool poseFree,
+	const Scalar Xn[3], const Scalar meas[3], Scalar w, bool stereo)
+{
+	Scalar q[4] = { q0[0], q0[1], q0[2], q0[3] }, t[3] = { t0[0], t0[1], t0[2] }, r[3], Xc[3];
+	if (poseFree) pose_exp_update(upd, q, t);
+	const Scalar ee = w * edge_residual(q, t, cam, Xn, meas, stereo, r, Xc);
+	return robust_rho(stereo ? g.rk[1].kind : g.rk[0].kind, stereo ? g.rk[1].delta : g.rk[0].delta, ee);
+}
+
+__device__ __forceinline__ void update_pose_rows(const DeviceGraph& g, const DeviceSystem& sys, const Scalar* __restrict__ old, int i)
+{
+	Scalar upd[6], q[4], t[3];
+#pragma unroll
+	for (int k = 0; k < 6; k++) upd[k] = sys.xp[6 * (size_t)i + k];
+#pragma unroll
+	for (int k = 0; k < 4; k++) q[k] = old[4 * (size_t)i + k];
+#pragma unroll
+	for (int k = 0; k < 3; k++) t[k] = old[4 * (size_t)g.Pt + 3 * (size_t)i + k];
+	pose_exp_update(upd, q, t);
+#pragma unroll
+	for (int k = 0; k < 4; k++) g.q[4 * (size_t)i + k] = q[k];
+#pragma unroll
+	for (int k = 0; k < 3; k++) g.t[3 * (size_t)i + k] = t[k];
+}
+
+__global__ __launch_bounds__(LIN_BLOCK) void trial_tail_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
+	const Scalar* __restrict__ old, Scalar* __restrict__ scParts, Scalar* __restrict__ chiParts, int nLmGroups, int poseBlocks, Scalar* __restrict__ scaleParts, int nScale)
+{
+	if ((int)blockIdx.x >= nLmGroups)
+	{
+		const int b = blockIdx.x - nLmGroups;
+		if (b < poseBlocks)
+		{
+			const int i = b * LIN_BLOCK + threadIdx.x;
+			if (i < g.Pf) update_pose_rows(g, sys, old, i);
+		}
+		else pose_scale_body(g, sys, lambda, scaleParts, b - poseBlocks, nScale);
+		return;
+	}
+	__shared__ Scalar lds_all[(LIN_BLOCK / WAVE) * WAVE * 3];
+	__shared__ Scalar wpart[2][LIN_BLOCK / WAVE];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int wave = blockIdx.x * (LIN_BLOCK / WAVE) + wv;
+	const bool waveOn = wave < st.nWaves;
+	Scalar* lds = lds_all + wv * WAVE * 3;
+	const Scalar* qo = old; const Scalar* to = old + 4 * (size_t)g.Pt; const Scalar* Xo = old + 7 * (size_t)g.Pt;
+	const int lm0 = waveOn ? st.wave_lm[2 * wave] : 0, lm1 = waveOn ? st.wave_lm[2 * wave + 1] : 0;
+	const int e0 = waveOn ? g.lm_ptr[lm0] : 0, e1 = waveOn ? g.lm_ptr[lm1] : 0;
+	const int e = e0 + lane;
+	const bool valid = waveOn && e < e1;
+	int il = lm0, ip = 0, seg0 = 0, seg1 = 0;
+	bool stereo = false, poseFree = false;
+	Scalar q[4] = { 0, 0, 0, 1 }, t[3] = { 0, 0, 0 }, cam[5] = { 1, 1, 0, 0, 0 }, Xw[3] = { 0, 0, 1 }, meas[3] = { 0, 0, 0 }, xp[6] = { 0, 0, 0, 0, 0, 0 }, w = 0;
+	Scalar c[3] = { 0, 0, 0 };
+	if (valid)
+	{
+		const int pe = g.e_pose[e];
+		stereo = (pe & STEREO_BIT) != 0;
+		ip = pe & ~STEREO_BIT;
+		il = g.e_lm[e];
+		poseFree = ip < g.Pf;
+#pragma unroll
+		for (int i = 0; i < 4; i++) q[i] = qo[4 * (size_t)ip + i];
+#pragma unroll
+		for (int i = 0; i < 3; i++) t[i] = to[3 * (size_t)ip + i];
+#pragma unroll
+		for (int i = 0; i < 5; i++) cam[i] = g.cam[5 * (size_t)ip + i];
+#pragma unroll
+		for (int i = 0; i < 3; i++) Xw[i] = Xo[3 * (size_t)il + i];
+		meas[0] = g.e_mu[e]; meas[1] = g.e_mv[e]; meas[2] = g.e_mr[e];
+		w = g.e_w[e];
+		if (poseFree)
+		{
+#pragma unroll
+			for (int r = 0; r < 6; r++) xp[r] = sys.xp[6 * (size_t)ip + r];
+		}
+		if (il < g.Lf)
+		{
+			seg0 = g.lm_ptr[il] - e0;
+			seg1 = g.lm_ptr[il + 1] - e0;
+			if (poseFree)
+			{
+				// Hpl^T xp at the linearisation point (the pre-update estimate), exactly as back_substitute_kernel forms it
+				LaneEdge le;
+				Scalar Xc[3];
+				const Scalar ss = edge_residual(q, t, cam, Xw, meas, stereo, le.lin.r, Xc);
+				le.wr = w * robust_weight(stereo ? g.rk[1].kind : g.rk[0].kind, stereo ? g.rk[1].delta : g.rk[0].delta, w * ss);
+				const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
+				edge_jacobians(Xc, R, cam, stereo, le.lin);
+				edge_hplT_x(le, xp, c);
+			}
+		}
+	}
+	const bool lmFree = valid && il < g.Lf;
+#pragma unroll
+	for (int k = 0; k < 3; k++) lds[lane * 3 + k] = c[k];
+	wave_lds_sync();
+	Scalar sc = 0, xl[3] = { 0, 0, 0 };
+	if (lmFree && lane == seg0)
+	{
+		Scalar cs[3] = { 0, 0, 0 };
+		for (int j = seg0; j < seg1; j++)
+		{
+			cs[0] += lds[j * 3 + 0]; cs[1] += lds[j * 3 + 1]; cs[2] += lds[j * 3 + 2];
+		}
+		sc = finish_landmark_x(sys, il, cs, lambda, xl);
+#pragma unroll
+		for (int k = 0; k < 3; k++) g.Xw[3 * (size_t)il + k] = Xw[k] + xl[k];     // (= update_landmarks: Xw += xl)
+	}
+	wave_lds_sync();                     // every segment sum has been read: the head lanes may reuse their own LDS slots
+	if (lmFree && lane == seg0)
+	{
+#pragma unroll
+		for (int k = 0; k < 3; k++) lds[lane * 3 + k] = xl[k];
+	}
+	wave_lds_sync();
+	Scalar rho = 0;
+	if (valid)
+	{
+		Scalar Xn[3] = { Xw[0], Xw[1], Xw[2] };
+		if (lmFree)
+		{
+#pragma unroll
+			for (int k = 0; k < 3; k++) Xn[k] = Xw[k] + lds[seg0 * 3 + k];
+		}
+		rho = updated_edge_rho(g, q, t, cam, xp, poseFree, Xn, meas, w, stereo);
+	}
+	sc = wave_sum(sc); rho = wave_sum(rho);
+	if (lane == 0) { wpart[0][wv] = sc; wpart[1][wv] = rho; }
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		scParts[blockIdx.x] = (wpart[0][0] + wpart[0][1]) + (wpart[0][2] + wpart[0][3]);
+		chiParts[blockIdx.x] = (wpart[1][0] + wpart[1][1]) + (wpart[1][2] + wpart[1][3]);
+	}
+}
+
+// landmarks with more than 64 observations: one workgroup each (free or fixed: their edges are evaluated either way)
+__global__ __launch_bounds__(256) void big_trial_tail_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
+	const Scalar* __restrict__ old, Scalar* __restrict__ scParts, Scalar* __restrict__ chiParts)
+{
+	__shared__ Scalar red[4][3];
+	__shared__ Scalar xsh[3];
+	__shared__ Scalar rsh[4];
+	DeviceGraph go = g;                   // the pre-update estimate
+	go.q = const_cast<Scalar*>(old); go.t = go.q + 4 * (size_t)g.Pt; go.Xw = go.q + 7 * (size_t)g.Pt;
+	const int il = st.big_lm[blockIdx.x];
+	const int e0 = g.lm_ptr[il], e1 = g.lm_ptr[il + 1];
+	const bool lmFree = il < g.Lf;
+	Scalar acc[3] = { 0, 0, 0 };
+	if (lmFree)
+	{
+		for (int e = e0 + threadIdx.x; e < e1; e += 256)
+		{
+			const int ip = g.e_pose[e] & ~STEREO_BIT;
+			if (ip >= g.Pf) continue;
+			LaneEdge le;
+			linearize_edge(go, e, le);
+			Scalar xp[6], c[3];
+#pragma unroll
+			for (int r = 0; r < 6; r++) xp[r] = sys.xp[6 * (size_t)ip + r];
+			edge_hplT_x(le, xp, c);
+			acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+	if ((threadIdx.x & 63) == 0)
+#pragma unroll
+		for (int k = 0; k < 3; k++) red[threadIdx.x >> 6][k] = acc[k];
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		Scalar xl[3] = { 0, 0, 0 }, sc = 0;
+		if (lmFree)
+		{
+			Scalar cs[3];
+#pragma unroll
+			for (int k = 0; k < 3; k++) cs[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+			sc = finish_landmark_x(sys, il, cs, lambda, xl);
+#pragma unroll
+			for (int k = 0; k < 3; k++) g.Xw[3 * (size_t)il + k] = go.Xw[3 * (size_t)il + k] + xl[k];
+		}
+		scParts[blockIdx.x] = sc;
+#pragma unroll
+		for (int k = 0; k < 3; k++) xsh[k] = xl[k];
+	}
+	__syncthreads();
+	Scalar Xn[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) Xn[k] = go.Xw[3 * (size_t)il + k] + xsh[k];
+	Scalar rho = 0;
+	for (int e = e0 + threadIdx.x; e < e1; e += 256)
+	{
+		const int pe = g.e_pose[e];
+		const bool stereo = (pe & STEREO_BIT) != 0;
+		const int ip = pe & ~STEREO_BIT;
+		Scalar q[4], t[3], cam[5], meas[3], xp[6];
+		load_pose(go, ip, q, t, cam);
+		meas[0] = g.e_mu[e]; meas[1] = g.e_mv[e]; meas[2] = g.e_mr[e];
+		const bool poseFree = ip < g.Pf;
+#pragma unroll
+		for (int r = 0; r < 6; r++) xp[r] = poseFree ? sys.xp[6 * (size_t)ip + r] : Scalar(0);
+		rho += updated_edge_rho(g, q, t, cam, xp, poseFree, Xn, meas, g.e_w[e], stereo);
+	}
+	rho = wave_sum(rho);
+	if ((threadIdx.x & 63) == 0) rsh[threadIdx.x >> 6] = rho;
+	__syncthreads();
+	if (threadIdx.x == 0) chiParts[blockIdx.x] = (rsh[0] + rsh[1]) + (rsh[2] + rsh[3]);
+}
+
+size_t trial_tail_parts(const DeviceGraph& g, const DeviceStructure& st)
+{
+	const size_t nA = ((size_t)(st.nWaves + LIN_BLOCK / WAVE - 1) / (LIN_BLOCK / WAVE) + st.nBig + 63) / 64 * 64;
+	return 2 * nA + 4 * 256 + 64;
+}
+
+void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, const Scalar* old, hipStream_t s)
+{
+	const int nLm = (st.nWaves + LIN_BLOCK / WAVE - 1) / (LIN_BLOCK / WAVE);
+	const int nA = nLm + st.nBig;
+	Scalar* scParts = sys.parts;
+	Scalar* chiParts = sys.parts + (size_t)(nA + 63) / 64 * 64;
+	Scalar* scaleParts = chiParts + (size_t)(nA + 63) / 64 * 64;
+	const int poseBlocks = (g.Pf + LIN_BLOCK - 1) / LIN_BLOCK;
+	const int nScale = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
+	if (nLm + poseBlocks + nScale > 0)
+		hipLaunchKernelGGL(trial_tail_kernel, dim3(nLm + poseBlocks + nScale), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, old, scParts, chiParts, nLm, poseBlocks, scaleParts, nScale);
+	if (st.nBig > 0) hipLaunchKernelGGL(big_trial_tail_kernel, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda, old, scParts + nLm, chiParts + nLm);
+	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, scParts, nA, sys.slots + NSLOT, chiParts, nA, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT);
 }
 
 // Everything between a converged reduced solve and the LM decision in four launches: back-substitution, update, evaluation of

@@ -63,6 +63,8 @@ struct DeviceStructure
 	int* od_blocks = nullptr;          // [nOd] their ids, largest product count first
 	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
 	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)
+	int* prod_lm = nullptr;            // landmark of each product (= e_lm[prod_ea]): the block pass then fetches inv(Hll + lambda) beside the
+	                                   // two edge records instead of after them (one memory round trip per product instead of two)
 	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
 	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
 	int nCb = 0;                       // non-empty coarse blocks
@@ -143,6 +145,11 @@ void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, con
 void launch_pose_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
 // back-substitution + update + evaluation of the trial + second stage of their three sums + report to the host: four launches
 void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);
+// the same in two launches: back-substitution, update and evaluation fused into one pass over the edges (`old` = copy of the state
+// [q | t | Xw] made before the trial: the pass reads the pre-update estimate from it while it writes the updated one), then the sums
+// + report.  trial_tail_parts(): numbers of partial-sum scratch (sys.parts) it needs.
+void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, const Scalar* old, hipStream_t s);
+size_t trial_tail_parts(const DeviceGraph& g, const DeviceStructure& st);
 // landmark-side part recomputed from xl and the stored bl (stage API; the fused path gets it from back_substitute)
 void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
 

@@ -167,6 +167,18 @@ __device__ __forceinline__ constexpr int sym3_idx(int i, int j)
 	return i <= j ? (i == 0 ? j : (i == 1 ? 2 + j : 5)) : (j == 0 ? i : (j == 1 ? 2 + i : 5));
 }
 
+// rotation matrix -> quaternion, the branch for a non-positive trace with i the largest diagonal entry, j = i + 1, k = j + 1 (mod 3)
+template <int I, int J, int K>
+__device__ __forceinline__ void shepperd_branch(const Scalar (&R)[3][3], Scalar (&qe)[4])
+{
+	Scalar tr = sqrt(R[I][I] - R[J][J] - R[K][K] + 1);
+	qe[I] = Scalar(0.5) * tr;
+	tr = Scalar(0.5) / tr;
+	qe[3] = (R[K][J] - R[J][K]) * tr;
+	qe[J] = (R[J][I] + R[I][J]) * tr;
+	qe[K] = (R[K][I] + R[I][K]) * tr;
+}
+
 // SE3 exponential + left-multiplicative pose update T <- exp([omega; upsilon]) * T.
 // Ref: updateExp / updatePose and helpers, cuda_block_solver.cu:454-592.
 __device__ __forceinline__ void pose_exp_update(const Scalar upd[6], Scalar q[4], Scalar t[3])
@@ -214,16 +226,13 @@ __device__ __forceinline__ void pose_exp_update(const Scalar upd[6], Scalar q[4]
 	}
 	else
 	{
-		int i = 0;
-		if (R[1][1] > R[0][0]) i = 1;
-		if (R[2][2] > R[i][i]) i = 2;
-		const int j = (i + 1) % 3, k = (j + 1) % 3;
-		tr = sqrt(R[i][i] - R[j][j] - R[k][k] + 1);
-		qe[i] = Scalar(0.5) * tr;
-		tr = Scalar(0.5) / tr;
-		qe[3] = (R[k][j] - R[j][k]) * tr;
-		qe[j] = (R[j][i] + R[i][j]) * tr;
-		qe[k] = (R[k][i] + R[i][k]) * tr;
+		// i = index of the largest diagonal entry (same comparisons as the reference); three explicit cases so that every
+		// index is a compile-time constant (a runtime index would put R and qe into scratch memory)
+		const bool c1 = R[1][1] > R[0][0];
+		const bool c2 = R[2][2] > (c1 ? R[1][1] : R[0][0]);
+		if (c2) shepperd_branch<2, 0, 1>(R, qe);
+		else if (c1) shepperd_branch<1, 2, 0>(R, qe);
+		else shepperd_branch<0, 1, 2>(R, qe);
 	}
 	// t <- t_exp + R(q_exp) t ; q <- normalise(q_exp * q), w >= 0   (:523-539, :581-592)
 	Scalar u[3];

@@ -152,7 +152,7 @@ struct cuba_hip_solver
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
 	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
-	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_pePtr, d_peEdge;
+	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
 	DevBuf<Scalar> d_cbWi, d_cbWj;
@@ -302,6 +302,7 @@ struct cuba_hip_solver
 	bool failDirty = true;       // the device-side failure flag of the PCG may be non-zero
 	int expectedTicket = 0;
 	bool spinWait = true;
+	bool fusedTail = true;       // optimize(): back-substitution, update and evaluation of a trial in one pass over the edges (option "fused_tail")
 	bool speculateTail = false;  // optimize(): enqueue back-substitution/update/evaluation behind the first PCG batch. Measured with
 	                             // spin_wait on: 12.01 vs 11.95 ms (the saved host look is cheap now, a misprediction is not) -> off
 	void noteReport() { expectedTicket++; }
@@ -550,7 +551,7 @@ struct cuba_hip_solver
 			HIP_TRY(hipHostGetDevicePointer(&dev, h_pinned, 0));
 			slotsDev = (Scalar*)dev; flagsDev = (int*)((char*)dev + 1024);
 		}
-		d_parts.resize(4096 + (size_t)E / 2 + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1); d_ticket.resize(1);
+		d_parts.resize(8192 + (size_t)E + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1); d_ticket.resize(1);
 		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream); d_ticket.zero(stream);
 		sync(); expectedTicket = 0; ((volatile int*)((char*)h_pinned + 1024))[3] = 0;
 		sync();   // host staging vectors go out of scope
@@ -940,6 +941,9 @@ struct cuba_hip_solver
 		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data();
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
+		d_prodLm.resize(d_prodEa.size());
+		topo::launch_gather_int(d_prodEa.data(), d_elm.data(), d_prodEa.size(), d_prodLm.data(), stream);
+		st.prod_lm = d_prodLm.data();
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
@@ -1616,6 +1620,13 @@ struct cuba_hip_solver
 				const bool ok = speculateTail ? solveReduced(&tail, &undo, &tailValid) : solveReduced();
 				double Fhat = 0, scale = 0;
 				if (ok && tailValid) readEvaluate(true, &Fhat, &scale);     // already there: it came with the solver's flags
+				else if (ok && !profile && partHi < 0 && fusedTail && !schurAtomic && trial_tail_parts(g, st) <= d_parts.size())
+				{
+					// back-substitution + update + evaluation in one pass over the edges (reads the pre-trial estimate from the backup
+					// schur(true) has just made), then sums + report: two launches, one host look
+					launch_trial_tail_fused(g, st, sys, (Scalar)lam, d_backup.data(), stream); noteReport();
+					readEvaluate(true, &Fhat, &scale);
+				}
 				else if (ok && !profile && partHi < 0 && (size_t)st.nWaves + st.nBig + 64 + 3072 <= d_parts.size())
 				{
 					// back-substitution, update, evaluation, sums and report in four launches, one host look
@@ -1885,6 +1896,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
+		else if (k == "fused_tail") s->fusedTail = value != 0;
 		else if (k == "coarse_overlap_period") s->coarseOverlapPeriod = (int)value;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }

@@ -415,6 +415,17 @@ void launch_pose_keys(const int* e_pose, int E, int Pf, uint32_t* keys, uint32_t
 	if (E > 0) hipLaunchKernelGGL(pose_keys_kernel, grid_for(E), dim3(T), 0, s, e_pose, E, Pf, keys, vals);
 }
 
+__global__ void gather_int_kernel(const int* __restrict__ idx, const int* __restrict__ src, size_t n, int* __restrict__ dst)
+{
+	const size_t i = (size_t)blockIdx.x * T + threadIdx.x;
+	if (i < n) dst[i] = src[idx[i]];
+}
+
+void launch_gather_int(const int* idx, const int* src, size_t n, int* dst, hipStream_t s)
+{
+	if (n > 0) hipLaunchKernelGGL(gather_int_kernel, grid_for(n), dim3(T), 0, s, idx, src, n, dst);
+}
+
 void launch_copy_u32_to_int(const uint32_t* in, int* out, int n, hipStream_t s)
 {
 	if (n > 0) hipLaunchKernelGGL(copy_u32_int_kernel, grid_for(n), dim3(T), 0, s, in, out, n);

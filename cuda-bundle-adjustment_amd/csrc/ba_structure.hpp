@@ -50,6 +50,7 @@ void launch_lm_pairs(const int* lm_ptr, const int* e_pose, int Lf, int Pf, int* 
 // pose key of every sorted edge (Pf for edges whose pose is fixed) + identity values, for the per-pose edge lists
 void launch_pose_keys(const int* e_pose, int E, int Pf, uint32_t* keys, uint32_t* vals, hipStream_t s);
 void launch_copy_u32_to_int(const uint32_t* in, int* out, int n, hipStream_t s);
+void launch_gather_int(const int* idx, const int* src, size_t n, int* dst, hipStream_t s);     // dst[i] = src[idx[i]]
 // pattern entries: Pf diagonal seeds first, then every pair (a < c) of free-pose edges of every free landmark in
 // product-id order: key = row << 32 | column, value = (edge a + 1) << 32 | (edge c + 1), 0 for a seed
 void launch_pattern_entries(const int* lm_ptr, const int* e_pose, const int* e_lm, const int* nfree, const long long* pairBase,

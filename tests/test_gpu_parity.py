@@ -144,8 +144,8 @@ def test_lm_parity_pose_only_and_landmark_only(solvers, small_graph):
     compare_lm(*solvers, fp2, RK_HUBER, 5)
 
 
-def test_landmarks_with_more_than_64_observations(solvers):
-    """Landmarks seen by > 64 poses leave the one-lane-per-edge wave path (big_* kernels)."""
+def graph_with_big_landmarks():
+    """synth graph + up to six far landmarks observed by > 64 poses each"""
     from scipy.spatial.transform import Rotation
     g = synth_ba(300, 3000, 12000, seed=21)
     rng = np.random.default_rng(0)
@@ -172,6 +172,12 @@ def test_landmarks_with_more_than_64_observations(solvers):
     g.lm_X = np.concatenate([g.lm_X, np.array(extra_X)])
     g.stereo_vp = np.concatenate([g.stereo_vp] + vp); g.stereo_vl = np.concatenate([g.stereo_vl] + vl)
     g.stereo_meas = np.concatenate([g.stereo_meas] + meas); g.stereo_info = np.concatenate([g.stereo_info] + info)
+    return g, len(extra_X)
+
+
+def test_landmarks_with_more_than_64_observations(solvers):
+    """Landmarks seen by > 64 poses leave the one-lane-per-edge wave path (big_* kernels)."""
+    g, _ = graph_with_big_landmarks()
     fp = flatten(g)
     assert np.bincount(fp.eL).max() > 64
     HipSolver, OracleSolver = solvers
@@ -185,6 +191,44 @@ def test_landmarks_with_more_than_64_observations(solvers):
     assert rel(v[~diag], vo[~diag]) < ASM_TOL
     assert rel(h.array("bsc"), o.array("bsc")) < ASM_TOL
     compare_lm(HipSolver, OracleSolver, fp, RK_HUBER, 5)
+
+
+@pytest.mark.parametrize("case", ["small", "fixed_vertices", "big_landmarks", "fixed_big_landmark", "pose_only", "landmark_only"])
+def test_fused_trial_tail_equals_the_four_launch_tail(solvers, small_graph, case):
+    """optimize() runs back-substitution + update + evaluation of a trial as one pass over the edges (option fused_tail, default);
+    the four-launch tail (fused_tail = 0: the stage kernels one after the other) must give the same trajectory to summation-order
+    noise, and both must follow the oracle.  Covers the > 64-observation kernels, a FIXED landmark with > 64 observations (its
+    edges are evaluated but it has no increment -- the four-launch tail used to leave its partial sum unwritten) and the
+    degenerate modes."""
+    from conftest import with_fixed
+    HipSolver, OracleSolver = solvers
+    if case == "small":
+        fp = flatten(small_graph)
+    elif case == "fixed_vertices":
+        fp = flatten(with_fixed(small_graph, fixed_pose_rows=[3, 4, 20], fixed_lm_rows=list(range(0, 300, 7))))
+    elif case == "pose_only":
+        fp = flatten(with_fixed(small_graph, fixed_lm_rows=range(small_graph.nlandmarks)))
+    elif case == "landmark_only":
+        fp = flatten(with_fixed(small_graph, fixed_pose_rows=range(small_graph.nposes)))
+    else:
+        g, nbig = graph_with_big_landmarks()
+        if case == "fixed_big_landmark":
+            g.lm_fixed[-1] = True; g.lm_fixed[-2] = True
+        fp = flatten(g)
+        assert np.bincount(fp.eL).max() > 64
+        if case == "fixed_big_landmark":
+            assert np.bincount(fp.eL)[fp.Lf:].max() > 64
+    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
+    a = HipSolver(fp, RK_HUBER, pcg_tol=1e-11); ra = a.optimize(6)["chi2"]
+    b = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, fused_tail=0); rb = b.optimize(6)["chi2"]
+    assert len(ra) == len(rb) == len(ref)
+    assert np.all(np.abs(ra - rb) <= 1e-11 * rb), np.abs(ra / rb - 1).max()
+    assert np.all(np.abs(ra - ref) <= 1e-8 * ref), np.abs(ra / ref - 1).max()
+    for x, y in zip(a.state(), b.state()):
+        assert np.abs(x - y).max() <= 1e-9
+    assert rel(a.chi_squares(), b.chi_squares()) < 1e-9
+    again = HipSolver(fp, RK_HUBER, pcg_tol=1e-11).optimize(6)["chi2"]
+    assert np.array_equal(again, ra)                                        # the fused pass keeps the run bit-reproducible
 
 
 def test_schur_paths_agree_and_default_is_reproducible(solvers, small_graph):
