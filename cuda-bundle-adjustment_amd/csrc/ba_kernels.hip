@@ -19,6 +19,8 @@
 
 #include "ba_kernels.hpp"
 
+#include <type_traits>
+
 namespace cubahip
 {
 
@@ -2617,16 +2619,30 @@ __device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
 // AC2: further column pairs per lane and row, fetched in a second batch once the restricted sums have freed their registers
 // (coarse dimensions beyond 128 AC = 1536: large graphs with small aggregates; a column-by-column tail would pay one memory
 // round trip per 64 columns)
-template <int CL, int AC, int AC2>
+// W: numbers per 16-byte load of the coarse inverse = 2 when it is stored in the library's Scalar, 4 when the fp64 library keeps it
+// in fp32 (option "precond_fp32": the preconditioner only has to be a fixed SPD operator close to the inverse, so its storage
+// precision changes the iteration count by nothing measurable and the solution not at all, while its bytes and its load
+// instructions -- what bounds this kernel on the one CU a workgroup runs on -- halve).  With W = 4 the rows are padded to a
+// multiple of 4 numbers (zeros), and so are the two coarse vectors in LDS.
+template <typename T, int W> struct InvVec;
+template <typename T> struct InvVec<T, 2> { typedef T type __attribute__((ext_vector_type(2))); };
+template <typename T> struct InvVec<T, 4> { typedef T type __attribute__((ext_vector_type(4))); };
+
+template <int CL, int AC, int AC2, int W>
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
 	constexpr int QV = 16;             // SpMV-workgroup partials prefetched per coarse unknown
+	typedef typename std::conditional<W == 4, float, Scalar>::type PT;       // storage type of the coarse inverse
+	typedef typename InvVec<PT, W>::type AV;
 	extern __shared__ __align__(16) unsigned char pcg2_lds[];
 	const int Nc = CD * sys.nc;
+	const int NcP = (Nc + 3) & ~3;     // padded length of the coarse vectors in LDS (and of the rows of a W = 4 inverse)
+	const int ld = W == 4 ? NcP : Nc;
+	const PT* acinv = W == 4 ? reinterpret_cast<const PT*>(sys.acinv32) : reinterpret_cast<const PT*>(sys.acinv);
 	Scalar* sR = reinterpret_cast<Scalar*>(pcg2_lds);
-	Scalar* sQ = sR + Nc;
-	Scalar* part = sQ + Nc;           // [8 waves][CD], reused for the 8 x CD partial sums of P^T r_{k+1}
+	Scalar* sQ = sR + NcP;
+	Scalar* part = sQ + NcP;          // [8 waves][CD], reused for the 8 x CD partial sums of P^T r_{k+1}
 	Scalar* yc = part + 8 * CD;
 	Scalar* wsum = yc + CD;           // [4][8]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
 	Scalar* rown = wsum + 32;
@@ -2658,7 +2674,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	// AC = prefetched column PAIRS per lane and row (covers a coarse dimension of 128 AC; the rest is read later): 6 for
 	// coarse dimensions up to 768 (KITTI-00: 672), 12 beyond -- every prefetch slot past the row's end is still a load
 	// instruction on the workgroup's one CU, which is what bounds this kernel
-	Scalar2 ainv[AR][AC];
+	AV ainv[AR][AC];
 #pragma unroll
 	for (int m = 0; m < QV; m++) qv[m] = Scalar2{ 0, 0 };
 	if (doUpdate)
@@ -2688,12 +2704,12 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	for (int a = 0; a < AR; a++)
 	{
 #pragma unroll
-		for (int m = 0; m < AC; m++) ainv[a][m] = Scalar2{ 0, 0 };
+		for (int m = 0; m < AC; m++) ainv[a][m] = AV(0);
 		if (wv + 8 * a < CD)                               // wave-uniform
 		{
-			const Scalar* Arow = sys.acinv + (size_t)(CD * I + wv + 8 * a) * Nc;
+			const PT* Arow = acinv + (size_t)(CD * I + wv + 8 * a) * ld;
 #pragma unroll
-			for (int m = 0; m < AC; m++) ainv[a][m] = *reinterpret_cast<const Scalar2*>(Arow + min(2 * lane + 128 * m, Nc - 2));   // Nc is even
+			for (int m = 0; m < AC; m++) ainv[a][m] = *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * m, ld - W));   // ld is a multiple of W
 		}
 	}
 	TRACE_MARK();      // (trace build only: waits for every load issued above)
@@ -2736,6 +2752,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			*reinterpret_cast<Scalar2*>(sR + 2 * pj) = s1;
 			*reinterpret_cast<Scalar2*>(sQ + 2 * pj) = s2;
 		}
+		if (t < NcP - Nc) { sR[Nc + t] = 0; sQ[Nc + t] = 0; }      // padding of the coarse vectors (a 4-wide last load of a row)
 	}
 	else
 	{
@@ -2755,16 +2772,17 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			}
 			sR[jc] = s1; sQ[jc] = 0;
 		}
+		if (t < NcP - Nc) { sR[Nc + t] = 0; sQ[Nc + t] = 0; }
 	}
-	Scalar2 ainv2[AR][AC2 > 0 ? AC2 : 1];
-	if (AC2 > 0 && Nc > 128 * AC)                       // (uniform over the grid)
+	AV ainv2[AR][AC2 > 0 ? AC2 : 1];
+	if (AC2 > 0 && Nc > 64 * W * AC)                    // (uniform over the grid)
 	{
 #pragma unroll
 		for (int a = 0; a < AR; a++)
 		{
-			const Scalar* Arow = sys.acinv + (size_t)(CD * I + min(wv + 8 * a, CD - 1)) * Nc;
+			const PT* Arow = acinv + (size_t)(CD * I + min(wv + 8 * a, CD - 1)) * ld;
 #pragma unroll
-			for (int m = 0; m < AC2; m++) ainv2[a][m] = *reinterpret_cast<const Scalar2*>(Arow + min(2 * lane + 128 * (AC + m), Nc - 2));
+			for (int m = 0; m < AC2; m++) ainv2[a][m] = *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * (AC + m), ld - W));
 		}
 	}
 	TRACE_MARK();
@@ -2813,20 +2831,28 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 		for (int m = 0; m < AC; m++)
 		{
-			const int j = 2 * lane + 128 * m;
-			if (j < Nc) acc += ainv[a][m].x * (sR[j] - alpha * sQ[j]) + ainv[a][m].y * (sR[j + 1] - alpha * sQ[j + 1]);
+			const int j = W * lane + 64 * W * m;
+			if (j < Nc)
+			{
+#pragma unroll
+				for (int i = 0; i < W; i++) acc += (Scalar)ainv[a][m][i] * (sR[j + i] - alpha * sQ[j + i]);
+			}
 		}
-		if (AC2 > 0 && Nc > 128 * AC)
+		if (AC2 > 0 && Nc > 64 * W * AC)
 		{
 #pragma unroll
 			for (int m = 0; m < AC2; m++)
 			{
-				const int j = 2 * lane + 128 * (AC + m);
-				if (j < Nc) acc += ainv2[a][m].x * (sR[j] - alpha * sQ[j]) + ainv2[a][m].y * (sR[j + 1] - alpha * sQ[j + 1]);
+				const int j = W * lane + 64 * W * (AC + m);
+				if (j < Nc)
+				{
+#pragma unroll
+					for (int i = 0; i < W; i++) acc += (Scalar)ainv2[a][m][i] * (sR[j + i] - alpha * sQ[j + i]);
+				}
 			}
 		}
 		if (row < CD)
-			for (int j = lane + 128 * (AC + AC2); j < Nc; j += 64) acc += sys.acinv[(size_t)(CD * I + row) * Nc + j] * (sR[j] - alpha * sQ[j]);
+			for (int j = lane + 64 * W * (AC + AC2); j < Nc; j += 64) acc += (Scalar)acinv[(size_t)(CD * I + row) * ld + j] * (sR[j] - alpha * sQ[j]);
 		acc = wave_sum(acc);
 		if (lane == 0 && row < CD) yc[row] = acc;
 	}
@@ -2881,15 +2907,39 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 
 static void* pcg2_kernel_for(const DeviceSystem& sys)
 {
-	const bool small = 6 * sys.cl * sys.nc <= 768;
-	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0> : (void*)pcg2_fused_kernel<2, 12, 6>;
-	return small ? (void*)pcg2_fused_kernel<1, 6, 0> : (void*)pcg2_fused_kernel<1, 12, 6>;
+	const int Nc = 6 * sys.cl * sys.nc;
+	if (sys.acinv32 && sizeof(Scalar) == 8)
+	{
+		// fp32 storage of the coarse inverse: a 16-byte load carries 4 columns, 3 / 6 / 6 + 3 loads per lane and row cover 768 / 1536 / 2304
+		if (sys.cl == 2) return Nc <= 768 ? (void*)pcg2_fused_kernel<2, 3, 0, 4> : Nc <= 1536 ? (void*)pcg2_fused_kernel<2, 6, 0, 4> : (void*)pcg2_fused_kernel<2, 6, 3, 4>;
+		return Nc <= 768 ? (void*)pcg2_fused_kernel<1, 3, 0, 4> : Nc <= 1536 ? (void*)pcg2_fused_kernel<1, 6, 0, 4> : (void*)pcg2_fused_kernel<1, 6, 3, 4>;
+	}
+	const bool small = Nc <= 768;
+	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0, 2> : (void*)pcg2_fused_kernel<2, 12, 6, 2>;
+	return small ? (void*)pcg2_fused_kernel<1, 6, 0, 2> : (void*)pcg2_fused_kernel<1, 12, 6, 2>;
 }
 
 static size_t pcg2_lds_bytes(const DeviceSystem& sys)
 {
 	const size_t cd = 6 * (size_t)sys.cl;
-	return sizeof(Scalar) * (2 * cd * sys.nc + 8 * cd + cd + 32 + 12 * (size_t)sys.agg);
+	const size_t ncp = (cd * sys.nc + 3) & ~(size_t)3;
+	return sizeof(Scalar) * (2 * ncp + 8 * cd + cd + 32 + 12 * (size_t)sys.agg);
+}
+
+// fp64 coarse inverse (n x n, column-major, symmetric up to rounding) -> fp32, symmetrised exactly, rows padded with zeros to ld
+__global__ __launch_bounds__(256) void coarse_to_fp32_kernel(const Scalar* __restrict__ src, float* __restrict__ dst, int n, int ld)
+{
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= (size_t)n * ld) return;
+	const int row = (int)(t / ld), j = (int)(t - (size_t)row * ld);
+	dst[t] = j < n ? (float)(Scalar(0.5) * (src[(size_t)row * n + j] + src[(size_t)j * n + row])) : 0.0f;
+}
+
+void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s)
+{
+	const int ld = (n + 3) & ~3;
+	const size_t total = (size_t)n * ld;
+	if (total) hipLaunchKernelGGL(coarse_to_fp32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, n, ld);
 }
 
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)

@@ -110,6 +110,8 @@ struct DeviceSystem
 	int cl = 1;                // coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose
 	                           // index (coarse dimension = 6*cl*nc)
 	Scalar* acinv = nullptr;   // [(6nc)^2] explicit inverse of the coarse matrix P^T A P, column-major
+	float* acinv32 = nullptr;  // fp64 library, option "precond_fp32": the same inverse in fp32 (symmetrised, rows padded to a multiple of 4
+	                           // numbers) -- what the iteration kernels then read instead of acinv
 	Scalar* gj_pivots = nullptr;   // [2][32 x 32] scratch of the Gauss-Jordan sweep (inverse of the current / next pivot block)
 	Scalar* rc = nullptr;      // [2*6nc] restricted residual P^T r_k, ping-pong by the parity of k like r / r2 (each
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
@@ -168,6 +170,7 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
+void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s);   // n x n inverse -> sys.acinv32 layout
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
 // Adds `chunk` PCG iterations (chunk-local k = 0..chunk-1) and the kbase advance to `graph` as a chain of kernel nodes.

@@ -152,6 +152,10 @@ struct cuba_hip_solver
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
 	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
+	DevBuf<float> d_coarse32[2];  // option precond_fp32 (fp64 library): the inverse in use in fp32 [0] + the staging copy an overlapped inversion leaves [1]
+	bool precondFp32 = sizeof(Scalar) == 8;
+	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
+	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -806,6 +810,9 @@ struct cuba_hip_solver
 			auto flush = [&](int end) { if (start >= 0 && cnt > 0) { waveLm.push_back(start); waveLm.push_back(end); } start = -1; cnt = 0; };
 			for (int l = lo; l < hi; l++)
 			{
+				// (the device pipeline packs chunks of WAVE_CHUNK landmarks independently: the same cuts here, so that both
+				// pipelines produce the same waves -- the per-wave partial sums of the fused trial tail depend on them)
+				if ((l - lo) % topo::WAVE_CHUNK == 0) flush(l);
 				const int n = h_lmptr[l + 1] - h_lmptr[l];
 				if (n > WAVE)
 				{
@@ -919,6 +926,10 @@ struct cuba_hip_solver
 		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
 		reducedZeroed = true;
 		for (auto& b : d_coarse) b.resize((size_t)36 * c.cl * c.cl * c.nc * c.nc);
+		{
+			const size_t n = (size_t)6 * c.cl * c.nc;
+			for (auto& b : d_coarse32) b.resize(fp32Inverse() ? n * ((n + 3) & ~(size_t)3) : 0);
+		}
 		d_rc.resize((size_t)12 * c.cl * c.nc); d_r2.resize((size_t)6 * Pf);
 		maxIterAlloc = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		const int gridSetup = (Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + c.spmvRows - 1) / c.spmvRows;
@@ -962,6 +973,7 @@ struct cuba_hip_solver
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
 		sys.spmv_rows = spmvRows;
 		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
+		sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
 		haveStructure = true;
 	}
 	bool hostPatternValid = false;     // h_rowptr / h_colind describe the current structure (the device-built one downloads them on demand)
@@ -1434,10 +1446,14 @@ struct cuba_hip_solver
 		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
 		if (takeInverse && separateCopies)
 		{
-			HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invCount * sizeof(Scalar), hipMemcpyDeviceToDevice, stream));
+			if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_coarse32[0].data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream));
+			else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invCount * sizeof(Scalar), hipMemcpyDeviceToDevice, stream));
 			takeInverse = false;
 		}
-		launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
+		if (fp32Inverse())     // the overlapped inversion left an fp32 copy in the staging buffer: that is what moves into the buffer in use
+			launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? reinterpret_cast<const Scalar*>(d_coarse32[1].data()) : nullptr,
+				reinterpret_cast<Scalar*>(d_coarse32[0].data()), inv32Count() / 2);
+		else launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
 		if (twoLevel)
 		{
 			// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
@@ -1453,7 +1469,8 @@ struct cuba_hip_solver
 					// first solve of a run: nothing to overlap with, invert here
 					drainInversion();
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
-					HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
+					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
+					else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
 					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
 				}
 				sys.acinv = d_coarse[2].data();
@@ -1465,6 +1482,7 @@ struct cuba_hip_solver
 					HIP_TRY(hipEventRecord(evSetup, stream));
 					HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
+					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[1].data(), 6 * sys.cl * sys.nc, gjStream);   // (staging: the iteration graphs read [0])
 					HIP_TRY(hipEventRecord(evInverse, gjStream));
 					pendingInv = 0; sideAge = 0;
 					assemblePending = true; cntCoarseRefresh++;
@@ -1478,6 +1496,7 @@ struct cuba_hip_solver
 				{
 					drainInversion();
 					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
+					if (fp32Inverse()) launch_coarse_to_fp32(sys.acinv, d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
 					coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
 				}
 				else coarseAge++;
@@ -1743,6 +1762,7 @@ struct cuba_hip_solver
 		{
 			drainInversion();
 			sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
+			if (fp32Inverse()) launch_coarse_to_fp32(sys.acinv, d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
 			coarseValid = false;
 			launch_pcg2_fused(g, sys, 0, 0, 1 << 30, -1.0, 0, stream);
 		}
@@ -1897,6 +1917,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
+		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "coarse_overlap_period") s->coarseOverlapPeriod = (int)value;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }

@@ -98,7 +98,9 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    inverse of the two-level preconditioner is reused for up to three further solves of a run; 0 = rebuild it for every
    solve), "coarse_refresh_growth" (in-line mode; default 1.6: rebuild early once a solve needs that many times the iterations of
    the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
-   the device writes into mapped host memory, not from hipStreamSynchronize), "fused_tail" (default 1: optimize() runs back-substitution, update and evaluation of a trial
+   the device writes into mapped host memory, not from hipStreamSynchronize), "precond_fp32" (fp64 library only, default 1: the explicit coarse inverse of the two-level
+   preconditioner is STORED in fp32 -- symmetrised, applied with fp64 accumulation; it only has to be a fixed SPD operator, so neither parity
+   nor bit-reproducibility change, while the bytes and load instructions of the kernel that applies it halve; 0 = fp64 storage), "fused_tail" (default 1: optimize() runs back-substitution, update and evaluation of a trial
    as ONE pass over the edges -- two launches between a converged solve and the LM decision instead of four; 0 = the four-launch tail), "speculate_tail" (default 0; 1 = optimize()
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
    was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "schur_atomic"

@@ -276,6 +276,26 @@ def test_preconditioner_modes_agree(solvers, small_fp):
     assert its[16] < its[0] and its[5] < its[0] and its[2] < its[5], its       # the coarse level must pay off on a keyframe chain
 
 
+def test_coarse_inverse_storage_precision(solvers):
+    """Option precond_fp32 (default 1 in the fp64 library): the explicit coarse inverse of the two-level preconditioner is stored in
+    fp32 and applied with fp64 accumulation.  A preconditioner only has to be a fixed SPD operator: same solutions to the solver
+    tolerance, iteration counts within a few per cent of the fp64-stored inverse, runs still bit-reproducible; every refresh path
+    (in line, overlapped + staged copy, every coarse-dimension class of the kernel) is exercised."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
+    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
+    for opts in (dict(), dict(coarse_overlap=0), dict(pcg_aggregate=2), dict(pcg_aggregate=2, coarse_linear=0), dict(pcg_aggregate=3, coarse_linear=0),
+                 dict(pcg_aggregate=1)):
+        a = HipSolver(fp, RK_HUBER, pcg_tol=1e-10, **opts); ra = a.optimize(6)["chi2"]
+        b = HipSolver(fp, RK_HUBER, pcg_tol=1e-10, precond_fp32=0, **opts); rb = b.optimize(6)["chi2"]
+        assert rel(ra, ref) < 1e-8 and rel(rb, ref) < 1e-8, opts
+        ia, ib = a.pcg_history()[0], b.pcg_history()[0]
+        assert a.pcg_history()[1] == 0 and b.pcg_history()[1] == 0
+        assert abs(int(ia.sum()) - int(ib.sum())) <= max(3, 0.05 * ib.sum()), (opts, ia.tolist(), ib.tolist())
+        a2 = HipSolver(fp, RK_HUBER, pcg_tol=1e-10, **opts)
+        assert np.array_equal(a2.optimize(6)["chi2"], ra), opts
+
+
 def test_coarse_refresh_modes(solvers):
     """The coarse inverse of trial k is built on a second stream for a later trial (default: under every trial for a coarse dimension
     up to 512, under every second up to 1024, every third beyond); coarse_overlap=0 inverts in line and reuses the inverse for up to coarse_max_age solves.
