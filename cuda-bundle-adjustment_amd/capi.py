@@ -85,6 +85,8 @@ def load_library(precision="f64"):
         "cuba_hip_compute_scale": [H, C.c_double, _dp],
         "cuba_hip_push": [H],
         "cuba_hip_pop": [H],
+        "cuba_hip_snapshot_state": [H],
+        "cuba_hip_restore_state": [H],
         "cuba_hip_optimize": [H, C.c_int, _dp, C.POINTER(C.c_int)],
         "cuba_hip_get_solution": [H, _dp, _dp, _dp],
         "cuba_hip_set_solution": [H, _dp, _dp, _dp],
@@ -240,6 +242,8 @@ class HipSolver:
 
     def push(self): self._ck(self.lib.cuba_hip_push(self.h))
     def pop(self): self._ck(self.lib.cuba_hip_pop(self.h))
+    def snapshot_state(self): self._ck(self.lib.cuba_hip_snapshot_state(self.h))
+    def restore_state(self): self._ck(self.lib.cuba_hip_restore_state(self.h))
 
     def optimize(self, niter):
         chi2 = np.zeros(max(niter, 1))

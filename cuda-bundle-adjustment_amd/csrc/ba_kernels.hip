@@ -2980,8 +2980,22 @@ void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const De
 
 // last node of an iteration graph: advance the iteration offset and report the solver's flags straight into the
 // device-mapped host block the host looks at after synchronising (no copy kernels on the way)
-__global__ void pcg_advance_kernel(DeviceSystem sys, int n, int report)
+// (one wave.  tol2 >= 0: the node also runs the stop test on the residual the chunk's last iteration left -- r.z of iteration
+// kbase + n lives in the ring slot of chunk-local index 0, chunk lengths being multiples of 4 -- so that a batch of exactly as many
+// iterations as the solve needs is recognised as converged without a further iteration launch)
+__global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n, int report, Scalar tol2)
 {
+	if (tol2 >= 0 && n > 0)
+	{
+		const int lane = threadIdx.x;
+		const Scalar rzk = wave_sum(load_parts(rz_slot(sys, 0), sys.nrz, lane)), rz0 = wave_sum(load_parts(sys.rz, sys.nrz0, lane));
+		if (lane == 0 && *sys.done == 0 && *sys.fail == 0 && !(rzk > tol2 * rz0))
+		{
+			*sys.done = 1;
+			if (!(rzk == rzk)) *sys.fail = 3;
+		}
+	}
+	if (threadIdx.x != 0) return;
 	*sys.kbase += n;
 	if (report && sys.host_flags)
 	{
@@ -3005,12 +3019,12 @@ void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s)
 
 void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, 0, 1);
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, 0, 1, Scalar(-1));
 }
 
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s)
 {
-	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(1), 0, s, sys, n, 1);
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, n, 1, Scalar(-1));
 }
 
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
@@ -3050,7 +3064,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		}
 		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
 	}
-	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(1), 0, sys, chunk, report);
+	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(64), 0, sys, chunk, report, tol2);
 	return e;
 }
 

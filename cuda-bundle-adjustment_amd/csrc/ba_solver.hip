@@ -139,7 +139,8 @@ struct cuba_hip_solver
 	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
 
 	// device: state [q | t | Xw] contiguous (push/pop = one copy), edges, structure, system
-	DevBuf<Scalar> d_state, d_backup, d_cam;
+	DevBuf<Scalar> d_state, d_backup, d_cam, d_snapshot;
+	bool haveSnapshot = false;
 	DevBuf<int> d_epose, d_elm, d_lmptr;
 	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
 	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_pairBlk, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
@@ -543,6 +544,7 @@ struct cuba_hip_solver
 		}
 		d_state.upload(state, stream);
 		d_backup.resize(state.size());
+		haveSnapshot = false;
 		d_cam.upload(camv, stream);
 		d_perEdge.resize(E);
 		if (!h_pinned)
@@ -1517,14 +1519,20 @@ struct cuba_hip_solver
 		int k0 = 0, looks = 0;
 		// prediction: within an LM run the damping shrinks geometrically and the iteration count grows by a fairly steady
 		// factor from solve to solve, so extrapolate the last two counts of this run
+		// (the larger of a linear and a geometric extrapolation, + 1 for the iteration in which the stop test fires: small graphs grow
+		// by a few iterations per solve, large ones by a factor; every iteration enqueued past convergence costs ~5 us, a batch that
+		// falls short costs a host look and is continued with a short one)
 		int predicted = 32;
 		if (runIters.size() >= 2)
 		{
 			const double a = runIters[runIters.size() - 2], b = runIters.back();
-			predicted = (int)(b * std::min(1.35, std::max(1.0, b / std::max(1.0, a)))) + 4;
+			const double lin = b + std::max(0.0, b - a), geo = b * std::min(1.35, std::max(1.0, b / std::max(1.0, a)));
+			predicted = (int)std::max(lin, geo) + 1;
 		}
-		else if (runIters.size() == 1) predicted = (int)(1.35 * runIters[0]) + 4;
-		else if (firstSolveIters > 0) predicted = firstSolveIters + 4;
+		else if (runIters.size() == 1) predicted = (int)(1.35 * runIters[0]) + 2;
+		else if (firstSolveIters > 0) predicted = firstSolveIters + 1;
+		// (the last node of every iteration graph runs the stop test on the residual its chunk left: a batch of exactly the needed
+		// length is recognised as converged)
 		int target = fixedChunk ? fixedChunk : (predicted + 3) / 4 * 4;
 		while (k0 < maxIter && !converged)
 		{
@@ -1548,7 +1556,7 @@ struct cuba_hip_solver
 				if (converged || k0 >= maxIter) *tailValid = true;
 				else (*undo)();
 			}
-			target = k0 + (fixedChunk ? fixedChunk : std::max(8, k0 / 8 / 4 * 4));
+			target = k0 + (fixedChunk ? fixedChunk : (looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
 			looks++; cntPcgLooks++;
 		}
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued, %d host looks (prediction %d)\n", hInts[1], k0, looks, predicted);
@@ -1988,6 +1996,25 @@ int cuba_hip_compute_scale(cuba_hip_solver* s, double lambda, double* scale)
 	return guarded(s, [&] {
 		if (!scale) throw ArgError{ "null output" };
 		*scale = s->computeScale(lambda);
+	});
+}
+
+int cuba_hip_snapshot_state(cuba_hip_solver* s)
+{
+	return guarded(s, [&] {
+		s->need();
+		s->d_snapshot.resize(s->d_state.size());
+		HIP_TRY(hipMemcpyAsync(s->d_snapshot.data(), s->d_state.data(), s->d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, s->stream));
+		s->haveSnapshot = true;
+	});
+}
+
+int cuba_hip_restore_state(cuba_hip_solver* s)
+{
+	return guarded(s, [&] {
+		s->need();
+		if (!s->haveSnapshot || s->d_snapshot.size() != s->d_state.size()) throw StateError{ "no snapshot of this graph's estimates (cuba_hip_snapshot_state)" };
+		HIP_TRY(hipMemcpyAsync(s->d_state.data(), s->d_snapshot.data(), s->d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, s->stream));
 	});
 }
 

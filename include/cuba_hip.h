@@ -179,6 +179,13 @@ int cuba_hip_compute_scale(cuba_hip_solver* s, double lambda, double* scale);
 int cuba_hip_push(cuba_hip_solver* s);
 int cuba_hip_pop(cuba_hip_solver* s);
 
+/* A second, caller-controlled copy of the estimates on the device (push / pop above are the LM loop's own and are overwritten by
+   every trial of cuba_hip_optimize): snapshot keeps [q | t | Xw] as they are now, restore brings them back with one device-to-device
+   copy on the handle's stream -- repeated runs from one starting point (benchmarks, parameter sweeps) need no host round trip.
+   No counterpart in the reference, whose callers re-upload through initialize(). */
+int cuba_hip_snapshot_state(cuba_hip_solver* s);
+int cuba_hip_restore_state(cuba_hip_solver* s);
+
 /* ---- whole Levenberg-Marquardt run -------------------------------------------------------------- */
 
 /* Replaces: the loop of CudaBundleAdjustmentImpl::optimize (src/cuda_bundle_adjustment.cpp:793-857)

@@ -113,6 +113,19 @@ def test_push_pop_and_set_state(solvers, small_fp):
     for a, b in zip(h.state(), (q0, t0, X0)):
         assert np.array_equal(a, b)
     assert h.compute_errors() == c0
+    # the caller's own device-side copy of the estimates (cuba_hip_snapshot_state / cuba_hip_restore_state) survives whole LM runs,
+    # which overwrite the push / pop backup with every trial
+    from cuba_amd.capi import CubaHipError
+    with pytest.raises(CubaHipError):
+        h.restore_state()                                   # nothing saved yet
+    h.optimize(1)
+    s1 = h.state()
+    h.snapshot_state()
+    r1 = h.optimize(4)["chi2"]
+    assert not np.array_equal(h.state()[2], s1[2])
+    h.restore_state()
+    assert all(np.array_equal(a, b) for a, b in zip(h.state(), s1))
+    assert np.array_equal(h.optimize(4)["chi2"], r1)        # the same run again, bit for bit
 
 
 @pytest.mark.parametrize("rk", [RK_NONE, RK_HUBER, RK_TUKEY])
