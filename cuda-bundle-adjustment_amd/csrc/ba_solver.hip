@@ -451,12 +451,16 @@ struct cuba_hip_solver
 		haveStructure = false;
 		Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
 		lap(nullptr);
+		// the estimates and cameras go up straight from the caller's arrays when they need neither a conversion (fp64 build) nor a
+		// row permutation (internal pose order): no staging copy, and page-locked caller memory (cuba_hip_host_alloc) moves by DMA
 		std::vector<Scalar>&state = h_stage[4], &camv = h_stage[5];
-		state.resize((size_t)7 * Pt + (size_t)3 * Lt);
-		for (size_t i = 0; i < (size_t)4 * Pt; i++) state[i] = (Scalar)q[i];
-		for (size_t i = 0; i < (size_t)3 * Pt; i++) state[4 * (size_t)Pt + i] = (Scalar)t[i];
-		for (size_t i = 0; i < (size_t)3 * Lt; i++) state[7 * (size_t)Pt + i] = (Scalar)Xw[i];
-		camv.assign(cam, cam + 5 * (size_t)Pt);
+		auto stageState = [&] {
+			state.resize((size_t)7 * Pt + (size_t)3 * Lt);
+			for (size_t i = 0; i < (size_t)4 * Pt; i++) state[i] = (Scalar)q[i];
+			for (size_t i = 0; i < (size_t)3 * Pt; i++) state[4 * (size_t)Pt + i] = (Scalar)t[i];
+			for (size_t i = 0; i < (size_t)3 * Lt; i++) state[7 * (size_t)Pt + i] = (Scalar)Xw[i];
+			camv.assign(cam, cam + 5 * (size_t)Pt);
+		};
 		const DeviceGraph gOld = g;
 		bool sameTopology = false;
 		const bool useDev = deviceSetup && !schurAtomic && E > 0;
@@ -486,7 +490,7 @@ struct cuba_hip_solver
 			}
 			sameTopology = sameCounts && reuseSort;
 			devTopology = true; hostTopoValid = false;
-			if (reorderActive) permuteStateRows(state, camv);          // the caller's rows -> the internal pose order kept from the last call
+			if (reorderActive) { stageState(); permuteStateRows(state, camv); }          // the caller's rows -> the internal pose order kept from the last call
 			lap("set_graph: device sort + gather enqueued");
 		}
 		else
@@ -542,10 +546,27 @@ struct cuba_hip_solver
 		d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
 		devTopology = false; hostTopoValid = true;
 		}
-		d_state.upload(state, stream);
-		d_backup.resize(state.size());
+		const size_t nState = (size_t)7 * Pt + (size_t)3 * Lt;
+		if (sizeof(Scalar) == sizeof(double) && !reorderActive)
+		{
+			d_state.resize(nState); d_cam.resize((size_t)5 * Pt);
+			Scalar* ds = d_state.data();
+			if (Pt)
+			{
+				HIP_TRY(hipMemcpyAsync(ds, q, sizeof(double) * 4 * (size_t)Pt, hipMemcpyHostToDevice, stream));
+				HIP_TRY(hipMemcpyAsync(ds + 4 * (size_t)Pt, t, sizeof(double) * 3 * (size_t)Pt, hipMemcpyHostToDevice, stream));
+				HIP_TRY(hipMemcpyAsync(d_cam.data(), cam, sizeof(double) * 5 * (size_t)Pt, hipMemcpyHostToDevice, stream));
+			}
+			if (Lt) HIP_TRY(hipMemcpyAsync(ds + 7 * (size_t)Pt, Xw, sizeof(double) * 3 * (size_t)Lt, hipMemcpyHostToDevice, stream));
+		}
+		else
+		{
+			if (!reorderActive) stageState();
+			d_state.upload(state, stream);
+			d_cam.upload(camv, stream);
+		}
+		d_backup.resize(nState);
 		haveSnapshot = false;
-		d_cam.upload(camv, stream);
 		d_perEdge.resize(E);
 		if (!h_pinned)
 		{

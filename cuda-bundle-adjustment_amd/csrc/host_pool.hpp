@@ -47,7 +47,7 @@ private:
 	HostPool()
 	{
 		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-		const int n = (int)std::min(16u, hw) - 1;
+		const int n = (int)std::min(32u, hw) - 1;       // (the loops are pointer chases: they scale with the number of outstanding misses, not with flops)
 		for (int w = 0; w < n; w++) workers_.emplace_back([this, w] { loop(w); });
 	}
 	~HostPool()

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <new>
@@ -200,8 +201,11 @@ public:
 			const size_t nAct = activeEdges_.size();
 			const unsigned T = hostThreads(nAct);
 			forThreads(T, [&](unsigned t) {
-				for (size_t o = nAct * t / T; o < nAct * (t + 1) / T; o++)
+				const size_t oEnd = nAct * (t + 1) / T;
+				for (size_t o = nAct * t / T; o < oEnd; o++)
 				{
+					// every edge object is its own cache miss: keep a dozen of them in flight
+					if (o + kPrefetch < oEnd) { const char* nx = reinterpret_cast<const char*>(activeEdges_[o + kPrefetch]); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
 					if (edgeDim_[o] == 2)
 					{
 						const MonoEdge* m = static_cast<const MonoEdge*>(activeEdges_[o]);
@@ -229,7 +233,11 @@ public:
 		auto chunk = [&](unsigned t) { return std::make_pair(nAll * t / T, nAll * (t + 1) / T); };
 		forThreads(T, [&](unsigned t) {
 			size_t c = 0;
-			for (size_t k = chunk(t).first; k < chunk(t).second; k++) c += isActive(edgeAt(k));
+			for (size_t k = chunk(t).first; k < chunk(t).second; k++)
+			{
+				if (k + kPrefetch < chunk(t).second) if (const BaseEdge* nx = edgeAt(k + kPrefetch)) __builtin_prefetch(nx);
+				c += isActive(edgeAt(k));
+			}
 			cnt[t + 1] = c;
 		});
 		for (unsigned t = 0; t < T; t++) cnt[t + 1] += cnt[t];
@@ -241,6 +249,7 @@ public:
 			size_t o = cnt[t];
 			for (size_t k = chunk(t).first; k < chunk(t).second; k++)
 			{
+				if (k + kPrefetch < chunk(t).second) if (const BaseEdge* nx = edgeAt(k + kPrefetch)) { __builtin_prefetch(nx); __builtin_prefetch(reinterpret_cast<const char*>(nx) + 64); }
 				BaseEdge* e = edgeAt(k);
 				if (!isActive(e)) continue;
 				activeEdges_[o] = e;
@@ -274,6 +283,15 @@ public:
 	void optimize(int niterations) override
 	{
 		if (!initialized_) throw std::runtime_error("optimize() called before initialize()");
+		static const bool dbg = std::getenv("CUBA_HIP_DEBUG") != nullptr;      // phase breakdown of the contract wall on stderr
+		auto tl = std::chrono::steady_clock::now();
+		auto lap = [&](const char* what) {
+			if (!dbg) return;
+			const auto now = std::chrono::steady_clock::now();
+			std::fprintf(stderr, "[cuba host] %-28s %7.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - tl).count());
+			tl = now;
+		};
+		if (dbg) std::fprintf(stderr, "[cuba host] %-28s %7.3f ms\n", "initialize()", 1e3 * initSeconds_);
 		if (!solver_)
 		{
 			const char* dev = std::getenv("CUBA_HIP_DEVICE");
@@ -290,13 +308,16 @@ public:
 				"cuba_hip_set_graph");
 			graphDirty_ = false;
 		}
+		lap("create + set_graph");
 		std::vector<double> chi2(std::max(niterations, 1), 0.0);
 		int done = 0;
 		check(cuba_hip_optimize(solver_, niterations, chi2.data(), &done), "cuba_hip_optimize");
 		for (int i = 0; i < done; i++) stats_.push_back({ i, chi2[i] });
+		lap("cuba_hip_optimize");
 
 		// finalize (ref :512-526): estimates back into the caller's vertices
 		check(cuba_hip_get_solution(solver_, q_.data(), t_.data(), Xw_.data()), "cuba_hip_get_solution");
+		lap("get_solution");
 		for (size_t i = 0; i < activePoses_.size(); i++)
 		{
 			double* qc = activePoses_[i]->q.coeffs().data();
@@ -307,14 +328,20 @@ public:
 			const size_t nL = activeLandmarks_.size();
 			const unsigned T = hostThreads(nL);
 			forThreads(T, [&](unsigned t) {       // one scattered store per landmark object: split over the pool
-				for (size_t i = nL * t / T; i < nL * (t + 1) / T; i++)
+				const size_t iEnd = nL * (t + 1) / T;
+				for (size_t i = nL * t / T; i < iEnd; i++)
+				{
+					if (i + kPrefetch < iEnd) __builtin_prefetch(activeLandmarks_[i + kPrefetch]->Xw.data(), 1);
 					for (int k = 0; k < 3; k++) activeLandmarks_[i]->Xw.data()[k] = Xw_[3 * i + k];
+				}
 			});
 		}
 
+		lap("write-back into vertices");
 		// per-edge chi2 (ref getChiSqs :528-543)
 		perEdgeChi_.resize(activeEdges_.size());
 		check(cuba_hip_chi_squares(solver_, perEdgeChi_.data()), "cuba_hip_chi_squares");
+		lap("chi_squares");
 		chiSqs_.clear();
 		chiEdges_.clear();
 		chiIndexBuilt_ = false;          // the edge -> value index is built on the first chiSquared() query
@@ -345,6 +372,7 @@ public:
 	}
 
 private:
+	static constexpr size_t kPrefetch = 12;      // objects ahead of the one being read in the pointer-chasing loops
 	static unsigned hostThreads(size_t items)
 	{
 		return (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)cubahip::HostPool::instance().maxThreads(), items / 20000 + 1));
@@ -366,8 +394,10 @@ private:
 		std::vector<size_t> nFree(T + 1, 0), nFixed(T + 1, 0);
 		forThreads(T, [&](unsigned t) {
 			size_t a = 0, b = 0;
-			for (size_t k = n * t / T; k < n * (t + 1) / T; k++)
+			const size_t kEnd = n * (t + 1) / T;
+			for (size_t k = n * t / T; k < kEnd; k++)
 			{
+				if (k + kPrefetch < kEnd) { const char* nx = reinterpret_cast<const char*>(list[k + kPrefetch]); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
 				const V* v = list[k];
 				if (v->edges.empty()) continue;
 				(v->fixed ? b : a)++;
@@ -380,8 +410,10 @@ private:
 		resize(active.size());
 		forThreads(T, [&](unsigned t) {
 			size_t a = nFree[t], b = freeTotal + nFixed[t];
-			for (size_t k = n * t / T; k < n * (t + 1) / T; k++)
+			const size_t kEnd = n * (t + 1) / T;
+			for (size_t k = n * t / T; k < kEnd; k++)
 			{
+				if (k + kPrefetch < kEnd) { const char* nx = reinterpret_cast<const char*>(list[k + kPrefetch]); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
 				V* v = list[k];
 				if (v->edges.empty()) continue;
 				const size_t i = v->fixed ? b++ : a++;
