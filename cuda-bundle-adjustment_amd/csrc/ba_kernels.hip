@@ -911,8 +911,8 @@ __device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const Devic
 	Scalar acc[33];
 #pragma unroll
 	for (int k = 0; k < 33; k++) acc[k] = 0;
-	const int p1 = st.pe_ptr[ip + 1];
-	for (int p = st.pe_ptr[ip] + lane; p < p1; p += 64)
+	const int p1 = st.pe_end[ip];
+	for (int p = st.pe_beg[ip] + lane; p < p1; p += 64)
 	{
 		const int e = st.pe_edge[p];
 		EdgeLinT<ET> L; ET wr, Xc[3]; int il;
@@ -1003,8 +1003,8 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	for (int r = 0; r < 6; r++)
 #pragma unroll
 		for (int c = 0; c < 6; c++) T[r][c] = 0;
-	const int p1 = on ? st.prod_ptr[blk + 1] : 0;
-	for (int p = (on ? st.prod_ptr[blk] : 0) + gl; p < p1; p += BP_GROUP)
+	const int p1 = on ? st.prod_end[blk] : 0;
+	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
 	{
 		EdgeLinT<ET> La, Lb; ET wa, wb, Xa[3], Xb[3]; int il, il2;
 		// the landmark comes from the product list, not from record a: all three gathers of a product are issued together

@@ -63,6 +63,9 @@ struct DeviceStructure
 	int* od_blocks = nullptr;          // [nOd] their ids, largest product count first
 	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
 	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)
+	// the ranges of the two lists above that THIS handle walks: prod_ptr / prod_ptr + 1 and pe_ptr / pe_ptr + 1 for a whole graph,
+	// sub-ranges (the lists are in landmark order) for a landmark partition built on the device
+	const int *prod_beg = nullptr, *prod_end = nullptr, *pe_beg = nullptr, *pe_end = nullptr;
 	int* prod_lm = nullptr;            // landmark of each product (= e_lm[prod_ea]): the block pass then fetches inv(Hll + lambda) beside the
 	                                   // two edge records instead of after them (one memory round trip per product instead of two)
 	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids

@@ -158,6 +158,8 @@ struct cuba_hip_solver
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
+	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
+	bool localRanges = false;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
 	DevBuf<Scalar> d_cbWi, d_cbWj;
@@ -622,8 +624,9 @@ struct cuba_hip_solver
 		if (!haveGraph) throw StateError{ "set_graph must be called first" };
 		if (haveStructure) return;
 		if (gjStream) { HIP_TRY(hipStreamSynchronize(gjStream)); pendingInv = -1; assemblePending = false; }   // an overlapped coarse inversion uses the old structure
-		if (devTopology && deviceSetup && partHi < 0 && !schurAtomic) { buildStructureDevice(); return; }
-		if (reorderActive) { std::vector<int> id(Pf); for (int i = 0; i < Pf; i++) id[i] = i; applyPoseOrder(id); }   // the host pipeline (partitions) runs in the caller's order
+		if (devTopology && deviceSetup && !schurAtomic) { buildStructureDevice(); return; }      // (landmark partitions included)
+		localRanges = false;
+		if (reorderActive) { std::vector<int> id(Pf); for (int i = 0; i < Pf; i++) id[i] = i; applyPoseOrder(id); }   // the host pipeline runs in the caller's order
 		ensureHostTopology();
 		const auto t0 = Clock::now();
 		std::vector<int> nfree(Lf, 0);
@@ -975,9 +978,10 @@ struct cuba_hip_solver
 		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data();
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
-		d_prodLm.resize(d_prodEa.size());
-		topo::launch_gather_int(d_prodEa.data(), d_elm.data(), d_prodEa.size(), d_prodLm.data(), stream);
+		if (!localRanges) fillProdLm();          // (a device-built partition needed it earlier)
 		st.prod_lm = d_prodLm.data();
+		st.prod_beg = localRanges ? d_prodBeg.data() : d_prodPtr.data(); st.prod_end = localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1;
+		st.pe_beg = localRanges ? d_peBeg.data() : d_pePtr.data(); st.pe_end = localRanges ? d_peEnd.data() : d_pePtr.data() + 1;
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
@@ -1000,6 +1004,11 @@ struct cuba_hip_solver
 		haveStructure = true;
 	}
 	bool hostPatternValid = false;     // h_rowptr / h_colind describe the current structure (the device-built one downloads them on demand)
+	void fillProdLm()
+	{
+		d_prodLm.resize(d_prodEa.size());
+		topo::launch_gather_int(d_prodEa.data(), d_elm.data(), d_prodEa.size(), d_prodLm.data(), stream);
+	}
 
 	// ---- internal pose order ------------------------------------------------------------------------------------------
 	int farOffset() const { return std::max(24, Pf / 8); }      // "far from the diagonal", in block columns
@@ -1210,9 +1219,15 @@ struct cuba_hip_solver
 		topo::launch_copy_u32_to_int(d_k32b.data(), d_tmpI0.data(), E, stream);
 		topo::launch_segment_ptr(d_tmpI0.data(), E, Pf, d_pePtr.data(), stream);
 		// 3. wave work list, pass 1 (counts per chunk of landmarks) + scan
-		const int nChunks = (Lt + topo::WAVE_CHUNK - 1) / topo::WAVE_CHUNK;
+		// landmark partition (multi-GPU): the block PATTERN, the adjacency and the coarse lists are global -- every rank must hold the same
+		// reduced-system layout --, the wave list covers the landmarks [lo, hi) only, and the product / pose-edge lists (in landmark
+		// order) are walked over the sub-ranges that belong to those landmarks
+		const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
+		localRanges = partHi >= 0;
+		const int nChunks = (hi - lo + topo::WAVE_CHUNK - 1) / topo::WAVE_CHUNK;
 		d_chunk.resize((size_t)3 * std::max(1, nChunks));
-		topo::launch_wave_count(d_lmptr.data(), 0, Lt, d_chunk.data(), stream);
+		if (nChunks == 0) d_chunk.zero(stream);
+		topo::launch_wave_count(d_lmptr.data(), lo, hi, d_chunk.data(), stream);
 		topo::launch_wave_scan(d_chunk.data(), nChunks, cnt, stream);
 		// ---- synchronisation 1: number of products, of free-pose edges, of waves ------------------------------------------
 		int hc[topo::CNT_COUNT];
@@ -1220,6 +1235,12 @@ struct cuba_hip_solver
 		HIP_TRY(hipMemcpyAsync(&npairs, d_lmPairBase.data() + Lf, sizeof(long long), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipMemcpyAsync(&nFreeEdges, d_freeScan.data() + Lf, sizeof(long long), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, stream));
+		int eRange[2] = { 0, E };
+		if (localRanges)
+		{
+			HIP_TRY(hipMemcpyAsync(&eRange[0], d_lmptr.data() + lo, sizeof(int), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(&eRange[1], d_lmptr.data() + hi, sizeof(int), hipMemcpyDeviceToHost, stream));
+		}
 		sync();
 		lap("structure (device): pairs, pose lists, wave counts");
 		if (Lf == 0) npairs = 0;
@@ -1228,8 +1249,13 @@ struct cuba_hip_solver
 		const int nWaves = hc[topo::CNT_NWAVES], nBig = hc[topo::CNT_NBIG];
 		const long long bigEdges = (long long)hc[topo::CNT_BIGEDGES_LO] | ((long long)hc[topo::CNT_BIGEDGES_HI] << 31);
 		d_waveLm.resize((size_t)2 * nWaves); d_bigLm.resize(nBig); d_bigOfs.resize(nBig); d_bigHpl.resize((size_t)bigEdges * 18);
-		topo::launch_wave_write(d_lmptr.data(), 0, Lt, d_chunk.data(), d_waveLm.data(), d_bigLm.data(), d_bigOfs.data(), stream);
-		g.e_begin = 0; g.e_end = E;
+		topo::launch_wave_write(d_lmptr.data(), lo, hi, d_chunk.data(), d_waveLm.data(), d_bigLm.data(), d_bigOfs.data(), stream);
+		g.e_begin = eRange[0]; g.e_end = eRange[1];
+		if (localRanges)
+		{
+			d_peBeg.resize(Pf); d_peEnd.resize(Pf);
+			topo::launch_segment_subrange(d_pePtr.data(), Pf, d_peEdge.data(), g.e_begin, g.e_end, d_peBeg.data(), d_peEnd.data(), stream);
+		}
 		// 4. pattern entries (diagonal seeds + one per product), sorted by (row, column); head flags; block index of every entry
 		const size_t nEnt = (size_t)Pf + (size_t)npairs;
 		d_k64a.resize(nEnt); d_k64b.resize(nEnt); d_v64a.resize(nEnt); d_v64b.resize(nEnt);
@@ -1258,7 +1284,14 @@ struct cuba_hip_solver
 		d_k32a.resize(n32); d_k32b.resize(n32); d_v32a.resize(n32); d_v32b.resize(n32);
 		sortTemp(n32);
 		d_odBlocks.resize(nblk);
-		topo::launch_od_keys(d_prodPtr.data(), d_blkrow.data(), d_colind.data(), nblk, farOffset(), d_k32a.data(), d_v32a.data(), cnt, stream);
+		if (localRanges)
+		{
+			fillProdLm();
+			d_prodBeg.resize(nblk); d_prodEnd.resize(nblk);
+			topo::launch_segment_subrange(d_prodPtr.data(), nblk, d_prodLm.data(), lo, hi, d_prodBeg.data(), d_prodEnd.data(), stream);
+		}
+		topo::launch_od_keys(localRanges ? d_prodBeg.data() : d_prodPtr.data(), localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1,
+			d_blkrow.data(), d_colind.data(), nblk, farOffset(), d_k32a.data(), d_v32a.data(), cnt, stream);
 		if (nblk) HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), nblk, 32, stream));
 		topo::launch_copy_u32_to_int(d_v32b.data(), d_odBlocks.data(), nblk, stream);
 		// 7. symmetric adjacency: the lower part of every row comes from the (column, row)-sorted list of the off-diagonal blocks

@@ -182,14 +182,36 @@ __global__ __launch_bounds__(T) void blocks_from_entries_kernel(const uint64_t* 
 	if (j == n - 1) prod_ptr[b + 1] = (int)(n - (size_t)Pf);
 }
 
-__global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters)
+// For every segment s of a list (items ptr[s] .. ptr[s + 1], their values ascending): the sub-range whose values lie in [vlo, vhi).
+// A landmark partition keeps the global lists and walks these sub-ranges: the products of a block are in landmark order, a pose's
+// edges in edge (= landmark) order.
+__global__ __launch_bounds__(T) void segment_subrange_kernel(const int* __restrict__ ptr, int nseg, const int* __restrict__ vals, int vlo, int vhi,
+	int* __restrict__ beg, int* __restrict__ end)
+{
+	const int sgm = blockIdx.x * T + threadIdx.x;
+	if (sgm >= nseg) return;
+	const int a0 = ptr[sgm], a1 = ptr[sgm + 1];
+	int lo = a0, hi = a1;
+	while (lo < hi) { const int m = (lo + hi) >> 1; if (vals[m] < vlo) lo = m + 1; else hi = m; }
+	const int b = lo;
+	hi = a1;
+	while (lo < hi) { const int m = (lo + hi) >> 1; if (vals[m] < vhi) lo = m + 1; else hi = m; }
+	beg[sgm] = b; end[sgm] = lo;
+}
+
+void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s)
+{
+	if (nseg > 0) hipLaunchKernelGGL(segment_subrange_kernel, grid_for(nseg), dim3(T), 0, s, ptr, nseg, vals, vlo, vhi, beg, end);
+}
+
+__global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters)
 {
 	const int k = blockIdx.x * T + threadIdx.x;
 	int cnt = 0, far = 0, dup = 0;
 	if (k < nblk)
 	{
 		far = colind[k] - blkrow[k] > farOffset;
-		cnt = prod_ptr[k + 1] - prod_ptr[k];
+		cnt = prod_end[k] - prod_beg[k];
 		dup = cnt > 0 && colind[k] == blkrow[k];
 		keys[k] = cnt > 0 ? 0x7fffffffu - (uint32_t)cnt : 0xffffffffu;          // longest list first; blocks without products last
 		vals[k] = (uint32_t)k;
@@ -449,9 +471,9 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 	if (n > 0) hipLaunchKernelGGL(blocks_from_entries_kernel, grid_for(n), dim3(T), 0, s, keys, vals, blkOfEntry, n, Pf, colind, blkrow, prod_ptr, prod_ea, prod_eb);
 }
 
-void launch_od_keys(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)
+void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)
 {
-	if (nblk > 0) hipLaunchKernelGGL(od_keys_kernel, grid_for(nblk), dim3(T), 0, s, prod_ptr, blkrow, colind, nblk, farOffset, keys, vals, counters);
+	if (nblk > 0) hipLaunchKernelGGL(od_keys_kernel, grid_for(nblk), dim3(T), 0, s, prod_beg, prod_end, blkrow, colind, nblk, farOffset, keys, vals, counters);
 }
 
 void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s)

@@ -62,7 +62,10 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 // blocks with products, longest list first (stable): sort keys + values; counters[CNT_NOD] = their number
 // counters[CNT_FARBLOCKS] = number of blocks more than farOffset block columns off the diagonal (pose order check)
 // counters[CNT_DIAGPROD] = number of DIAGONAL blocks with products (a landmark observed twice by one pose)
-void launch_od_keys(const int* prod_ptr, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
+// (prod_beg[k] .. prod_end[k] = the product range of block k this handle evaluates: prod_ptr / prod_ptr + 1 for the whole graph)
+void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
+// beg[s] .. end[s] = the items of segment s (ptr[s] .. ptr[s + 1], values ascending) whose value lies in [vlo, vhi)
+void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s);
 // pose indices of the caller-order edge array through a map of the free poses (fixed poses keep their index)
 void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s);
 // transposed view of the off-diagonal blocks: key = column << 32 | row (diagonal blocks get the largest key)

@@ -163,6 +163,14 @@ public:
 	void initialize() override
 	{
 		const auto t0 = std::chrono::steady_clock::now();
+		static const bool dbg = std::getenv("CUBA_HIP_DEBUG") != nullptr;
+		auto tl = t0;
+		auto lap = [&](const char* what) {
+			if (!dbg) return;
+			const auto now = std::chrono::steady_clock::now();
+			std::fprintf(stderr, "[cuba host]   initialize: %-22s %7.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - tl).count());
+			tl = now;
+		};
 		// (results of the previous optimize() stay queryable: when the edge list is rebuilt below, the old one is set aside
 		// -- a move -- instead of being indexed here: the index over 561 k edges costs more than the rest of initialize())
 		// the previous flattening is kept for comparison: when neither the edge set nor the active vertices (and their
@@ -186,6 +194,7 @@ public:
 				const double c[5] = { v->camera.fx, v->camera.fy, v->camera.cx, v->camera.cy, v->camera.bf };
 				std::copy(c, c + 5, cam_.begin() + 5 * i);
 			});
+		lap("poses");
 		numFreeLandmarks_ = indexVertices(landmarkList_, activeLandmarks_, [&](size_t n) { Xw_.resize(3 * n); },
 			[&](LandmarkVertex* v, size_t i) {
 				v->iL = static_cast<int>(i);
@@ -194,8 +203,10 @@ public:
 		// edges: mono first, then stereo, insertion order inside each type; edges with both ends fixed are inactive
 		// (ref :204-243).  561 k edges mean 561 k dependent pointer loads (edge -> vertex -> index), so the sweep is
 		// split over a few host threads: count the active edges per chunk, prefix-sum, fill.
+		lap("landmarks");
 		const bool sameTopology = !edgesDirty_ && !activeEdges_.empty() && prevFreeP == numFreePoses_ && prevFreeL == numFreeLandmarks_ &&
 			prevPoses == activePoses_ && prevLandmarks == activeLandmarks_;
+		lap("same-topology check");
 		if (sameTopology)
 		{
 			const size_t nAct = activeEdges_.size();
@@ -272,6 +283,7 @@ public:
 		});
 		}
 		edgesDirty_ = false;
+		lap("edges");
 
 		stats_.clear();
 		graphDirty_ = true;
