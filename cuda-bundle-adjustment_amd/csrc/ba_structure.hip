@@ -199,11 +199,6 @@ __global__ __launch_bounds__(T) void segment_subrange_kernel(const int* __restri
 	beg[sgm] = b; end[sgm] = lo;
 }
 
-void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s)
-{
-	if (nseg > 0) hipLaunchKernelGGL(segment_subrange_kernel, grid_for(nseg), dim3(T), 0, s, ptr, nseg, vals, vlo, vhi, beg, end);
-}
-
 __global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters)
 {
 	const int k = blockIdx.x * T + threadIdx.x;
@@ -469,6 +464,11 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 	int* prod_ea, int* prod_eb, hipStream_t s)
 {
 	if (n > 0) hipLaunchKernelGGL(blocks_from_entries_kernel, grid_for(n), dim3(T), 0, s, keys, vals, blkOfEntry, n, Pf, colind, blkrow, prod_ptr, prod_ea, prod_eb);
+}
+
+void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s)
+{
+	if (nseg > 0) hipLaunchKernelGGL(segment_subrange_kernel, grid_for(nseg), dim3(T), 0, s, ptr, nseg, vals, vlo, vhi, beg, end);
 }
 
 void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)

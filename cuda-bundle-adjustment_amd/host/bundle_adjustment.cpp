@@ -183,9 +183,12 @@ public:
 		// vertices in id order (the reference walks its std::maps), free ones first, vertices without edges left out
 		// (ref :128-200).  The id-ordered pointer lists are cached between calls as long as no vertex was added or
 		// removed, and the sweep over them (one dependent load per vertex) is split over a few host threads.
+		// (no vertex and no edge added or removed since the last call: the active lists can only have changed through `fixed` flags,
+		// which the single-pass variant of indexVertices checks while it reads the values)
+		const bool stableP = !posesDirty_ && !edgesDirty_ && !prevPoses.empty(), stableL = !landmarksDirty_ && !edgesDirty_ && !prevLandmarks.empty();
 		if (posesDirty_) { poseList_.clear(); for (const auto& kv : poses_) poseList_.push_back(kv.second); posesDirty_ = false; }
 		if (landmarksDirty_) { landmarkList_.clear(); for (const auto& kv : landmarks_) landmarkList_.push_back(kv.second); landmarksDirty_ = false; }
-		numFreePoses_ = indexVertices(poseList_, activePoses_, [&](size_t n) { q_.resize(4 * n); t_.resize(3 * n); cam_.resize(5 * n); },
+		numFreePoses_ = indexVertices(poseList_, activePoses_, stableP ? &prevPoses : nullptr, prevFreeP, [&](size_t n) { q_.resize(4 * n); t_.resize(3 * n); cam_.resize(5 * n); },
 			[&](PoseVertex* v, size_t i) {
 				v->iP = static_cast<int>(i);
 				const double* qc = v->q.coeffs().data();       // (x, y, z, w)
@@ -195,7 +198,7 @@ public:
 				std::copy(c, c + 5, cam_.begin() + 5 * i);
 			});
 		lap("poses");
-		numFreeLandmarks_ = indexVertices(landmarkList_, activeLandmarks_, [&](size_t n) { Xw_.resize(3 * n); },
+		numFreeLandmarks_ = indexVertices(landmarkList_, activeLandmarks_, stableL ? &prevLandmarks : nullptr, prevFreeL, [&](size_t n) { Xw_.resize(3 * n); },
 			[&](LandmarkVertex* v, size_t i) {
 				v->iL = static_cast<int>(i);
 				std::copy(v->Xw.data(), v->Xw.data() + 3, Xw_.begin() + 3 * i);
@@ -398,9 +401,31 @@ private:
 
 	// active = [free vertices in list order | fixed vertices in list order], vertices without edges skipped;
 	// emit(v, solver index) runs once per active vertex.  Returns the number of free ones.
+	// prev (optional): the active list of the previous call, valid as long as no `fixed` flag changed -- then ONE pass over it
+	// re-reads the values (and checks the flags); otherwise the two passes over the whole list.
 	template <class V, class Resize, class Emit>
-	static int indexVertices(const std::vector<V*>& list, std::vector<V*>& active, Resize&& resize, Emit&& emit)
+	static int indexVertices(const std::vector<V*>& list, std::vector<V*>& active, const std::vector<V*>* prev, int prevFree, Resize&& resize, Emit&& emit)
 	{
+		if (prev)
+		{
+			const size_t m = prev->size();
+			const unsigned Tp = hostThreads(m);
+			resize(m);
+			std::vector<char> bad(Tp, 0);
+			forThreads(Tp, [&](unsigned t) {
+				const size_t iEnd = m * (t + 1) / Tp;
+				for (size_t i = m * t / Tp; i < iEnd; i++)
+				{
+					if (i + kPrefetch < iEnd) { const char* nx = reinterpret_cast<const char*>((*prev)[i + kPrefetch]); __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
+					V* v = (*prev)[i];
+					if (v->edges.empty() || v->fixed != (i >= (size_t)prevFree)) { bad[t] = 1; break; }
+					emit(v, i);
+				}
+			});
+			bool ok = true;
+			for (char b : bad) ok = ok && !b;
+			if (ok) { active = *prev; return prevFree; }
+		}
 		const size_t n = list.size();
 		const unsigned T = hostThreads(n);
 		std::vector<size_t> nFree(T + 1, 0), nFixed(T + 1, 0);
