@@ -990,8 +990,9 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 {
 	const int gl = threadIdx.x & (BP_GROUP - 1);
 	const int grp = (bid * 256 + threadIdx.x) / BP_GROUP;
-	const bool on = grp < st.nOd;
-	const int blk = on ? st.od_blocks[grp] : 0;
+	const int blk0 = grp < st.nOd ? st.od_blocks[grp] : -1;      // (-1: unused slot of an XCD-aware order)
+	const bool on = blk0 >= 0;
+	const int blk = on ? blk0 : 0;
 	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
 	ET qa[4], cama[5], qb[4], camb[5];
 	load_pose_as<ET>(g, a, qa, cama);
@@ -1003,6 +1004,10 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	for (int r = 0; r < 6; r++)
 #pragma unroll
 		for (int c = 0; c < 6; c++) T[r][c] = 0;
+	// (Round 3, measured: an XCD-aware block order cuts the HBM-side fetch of this pass from 243 to 87 MB per launch and changes its
+	// time by nothing, so latency at two waves per SIMD bounds it, not bytes; but the loop sits exactly at the 256-register cliff --
+	// prefetching the next product's index triple, or touching its cache lines one trip ahead, costs 6-14 spilled registers and
+	// 20-50 us: profiles/r03j_block_order.txt, r03k_block_touch.txt.)
 	const int p1 = on ? st.prod_end[blk] : 0;
 	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
 	{

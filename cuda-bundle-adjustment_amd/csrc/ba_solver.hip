@@ -154,6 +154,12 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
 	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<float> d_coarse32[2];  // option precond_fp32 (fp64 library): the inverse in use in fp32 [0] + the staging copy an overlapped inversion leaves [1]
+	// The inverse the FIRST solve of the previous LM run was given (same damping regime: lambda_0 = tau * max diagonal): it serves the first
+	// solve of the next run on this structure, so that no run waits for an in-line inversion -- the fresh one runs on the second stream
+	// under that solve like every other.  A preconditioner only changes iteration counts; results stay a deterministic function of the
+	// call sequence (and identical when a run is repeated from the same estimate: the cached inverse IS the fresh one then).
+	DevBuf<Scalar> d_firstInv; DevBuf<float> d_firstInv32;
+	bool firstInvValid = false, firstInvPending = false, coarseFirstReuse = true;
 	bool precondFp32 = sizeof(Scalar) == 8;
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
@@ -813,6 +819,24 @@ struct cuba_hip_solver
 			odBlocks.resize(start[maxCnt + 1]);
 			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) odBlocks[start[maxCnt - c]++] = k; }
 			if (std::getenv("CUBA_HIP_BLOCK_ORDER_ROW")) { odBlocks.clear(); for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k); }   // A/B: row order (measured slower: 174 vs 135 us at KITTI-00, the long lists must start first)
+			if (const char* xe = std::getenv("CUBA_HIP_BLOCK_ORDER_XCD"))
+			{
+				// A/B (host pipeline only): blocks of the x-th eighth of the rows go to the workgroups that land on XCD x (workgroup w of the
+				// merged Schur launch runs on XCD (w + pose workgroups) mod 8), row-major inside an XCD (mode 1) or longest first inside
+				// an XCD (mode 2); unused slots hold -1
+				const int mode = std::atoi(xe), np = (Pf + 3) / 4;
+				std::vector<std::vector<int>> per(8);
+				for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) per[std::min(7, (int)((long long)blkRow[k] * 8 / std::max(1, Pf)))].push_back(k);
+				if (mode == 2) for (auto& v : per) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return prodPtr[a + 1] - prodPtr[a] > prodPtr[b + 1] - prodPtr[b]; });
+				size_t slots = 0;
+				for (auto& v : per) slots = std::max(slots, (v.size() + 15) / 16);
+				odBlocks.assign(slots * 8 * 16, -1);
+				for (int x = 0; x < 8; x++)
+				{
+					const int lane8 = ((x - np) % 8 + 8) % 8;            // workgroup indices w with (w + np) % 8 == x are w = 8 s + lane8
+					for (size_t i = 0; i < per[x].size(); i++) odBlocks[((i / 16) * 8 + lane8) * 16 + (i % 16)] = per[x][i];
+				}
+			}
 		}
 		lap("structure: product lists");
 		// per free pose: its edges inside this handle's landmark range (a contiguous run of the global list)
@@ -911,7 +935,7 @@ struct cuba_hip_solver
 		d_cbI.upload(cbI, stream); d_cbJ.upload(cbJ, stream); d_cbPtr.upload(cbPtr, stream); d_cbBlk.upload(cbBlk, stream); d_cbWi.upload(cbWi, stream); d_cbWj.upload(cbWj, stream);
 		sync();
 		lap("structure: coarse lists + sync");
-		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += blkRow[k] == h_colind[k];
+		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += k >= 0 && blkRow[k] == h_colind[k];
 		publishStructure(nblk, (int)waveLm.size() / 2, (int)bigLm.size(), (int)odBlocks.size(), (int)cbI.size(), ellM, ellOver, cc);
 		hostPatternValid = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -928,8 +952,10 @@ struct cuba_hip_solver
 		// (small graphs want smaller aggregates: KITTI-07, 247 free poses: 24 / 16 / 12 / 8 / 6 / 4 poses -> 8.6 / 7.0 / 6.4 / 6.3 / 6.5 / 7.9 ms)
 		// (large graphs, inversion hidden under the PCG of earlier trials: S2M 44 / 40 / 36 / 32 poses -> 27.1 / 26.35 / 26.7 / 26.4 ms,
 		// G4M 88 / 72 / 64 / 56 / 48 -> 65.1 / 59.6 / 54.8 / 54.0 / 58.3 ms: the aggregate count may grow from 115 to 180 with the graph)
-		const int ncMax = std::min(180, std::max(115, (Pf + 39) / 40));
-		if (agg < 0) agg = cl == 2 ? (Pf >= 1320 ? std::max(24, (Pf + ncMax - 1) / ncMax) : std::max(8, (Pf + 27) / 55)) : std::max(12, (Pf + 159) / 160);
+		// (round 3, coarse inverse stored in fp32 -- its apply costs half: KITTI-00 24 / 20 / 16 poses -> 8.16 / 8.00 / 7.81 ms, S2M 44 / 40 / 36 /
+		// 32 / 28 -> 25.8 / 25.0 / 24.8 / 24.6 / 26.0 ms, G4M 64 / 56 / 48 / 40 -> 51.7 / 50.5 / 52.8 / 58.2 ms: profiles/r03i_agg_sweep.txt)
+		const int ncMax = std::min(180, std::max(115, (Pf + 31) / 32));
+		if (agg < 0) agg = cl == 2 ? (Pf >= 1320 ? std::max(16, (Pf + ncMax - 1) / ncMax) : std::max(8, (Pf + 27) / 55)) : std::max(12, (Pf + 159) / 160);
 		const int spmvRows = spmv_rows_for(Pf);
 		if (agg > 0) agg = (agg + spmvRows - 1) / spmvRows * spmvRows;   // aggregates = whole SpMV workgroups (sys.qpart)
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
@@ -991,6 +1017,7 @@ struct cuba_hip_solver
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
 		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data(); sys.ticket = d_ticket.data();
 		dropPcgGraph();
+		firstInvValid = false; firstInvPending = false;
 		sys.rzStride = rzStrideCfg; sys.pqStride = pqStrideCfg; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
@@ -1497,6 +1524,13 @@ struct cuba_hip_solver
 		{
 			HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done
 			takeInverse = true; pendingInv = -1;
+			if (firstInvPending)
+			{
+				// (the inversion that ran under the first solve of this run: the next run's first solve starts with it)
+				if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream));
+				else HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invCount * sizeof(Scalar), hipMemcpyDeviceToDevice, stream));
+				firstInvPending = false; firstInvValid = true;
+			}
 		}
 		// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
 		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
@@ -1520,13 +1554,28 @@ struct cuba_hip_solver
 				// the work buffers of the sweep, which leaves its result in d_coarse[0].
 				ensureOverlapObjects();
 				const size_t invBytes = sizeof(Scalar) * (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
-				if (!coarseValid)
+				if (!coarseValid && coarseFirstReuse && firstInvValid)
 				{
-					// first solve of a run: nothing to overlap with, invert here
+					// first solve of a run on a structure that has seen a run before: start with the inverse that run's first solve had
+					// and let this trial's own inversion run on the other stream right away
+					if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_coarse32[0].data(), d_firstInv32.data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream));
+					else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_firstInv.data(), invBytes, hipMemcpyDeviceToDevice, stream));
+					pendingInv = -1;                 // (a sweep the previous run left behind is simply overtaken: the streams order themselves)
+					coarseValid = true; sideAge = overlapPeriod(); firstInvPending = true;
+				}
+				else if (!coarseValid)
+				{
+					// first solve on this structure: nothing to overlap with, invert here
 					drainInversion();
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
 					else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
+					if (coarseFirstReuse)
+					{
+						if (fp32Inverse()) { d_firstInv32.resize(inv32Count()); HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[0].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream)); }
+						else { d_firstInv.resize(invCount); HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream)); }
+						firstInvValid = true; firstInvPending = false;
+					}
 					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
 				}
 				sys.acinv = d_coarse[2].data();
@@ -1603,7 +1652,7 @@ struct cuba_hip_solver
 			if (speculate) (*tail)();                                             // ends with its own report
 			else if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (the graphs end with this report)
 			waitReport();
-			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; lastSolveIters = 0; failDirty = true; return false; }
+			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; lastSolveIters = 0; failDirty = true; return false; }
 			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 			if (speculate)
 			{
@@ -1979,6 +2028,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
+		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "coarse_overlap_period") s->coarseOverlapPeriod = (int)value;
 		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }

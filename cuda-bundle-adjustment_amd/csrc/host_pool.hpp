@@ -4,6 +4,8 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -35,6 +37,7 @@ public:
 			std::lock_guard<std::mutex> lk(m_);
 			job_ = [&fn](int t) { fn(t); };
 			want_ = T - 1; pending_ = T - 1; generation_++;
+			hint_.store(generation_, std::memory_order_release);
 		}
 		start_.notify_all();
 		fn(T - 1);
@@ -65,6 +68,19 @@ private:
 		for (;;)
 		{
 			std::function<void(int)> job;
+			// parallel regions come in bursts (initialize() + set_graph run five in a row): a worker that has just finished one spins
+			// for a moment before it goes back to sleep, so that the next region of the burst does not pay a futex wake-up per thread
+			if (seen != 0)
+			{
+				const auto t0 = std::chrono::steady_clock::now();
+				for (int spins = 0; hint_.load(std::memory_order_acquire) == seen; spins++)
+				{
+					if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+#if defined(__x86_64__) || defined(__i386__)
+					__builtin_ia32_pause();
+#endif
+				}
+			}
 			{
 				std::unique_lock<std::mutex> lk(m_);
 				start_.wait(lk, [&] { return stop_ || generation_ != seen; });
@@ -87,6 +103,7 @@ private:
 	std::function<void(int)> job_;
 	int want_ = 0, pending_ = 0;
 	unsigned long generation_ = 0;
+	std::atomic<unsigned long> hint_{ 0 };     // copy of generation_ the spinning workers watch without the mutex
 	bool stop_ = false;
 };
 

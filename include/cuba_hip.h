@@ -89,11 +89,13 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 /* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
    (default 4*6*Pf capped at 32768), "pcg_check_every" (PCG iterations between host looks at the device stop flag; default 0 =
    batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
-   preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses and max(24, Pf/min(180, max(115, Pf/40))) above with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
+   preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses and max(16, Pf/min(180, max(115, Pf/32))) above with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
    only), "coarse_linear" (default 1: constant + linear-in-pose-index coarse functions per aggregate, 12 unknowns each;
    0 = constant only, 6 unknowns), "coarse_overlap" (default 1: the coarse matrix of a trial is assembled and inverted on a second,
    low-priority stream under that trial's PCG and serves from the next trial on -- only the first solve of a run inverts in line;
-   0 = invert in line, on the policy of the next two options), "coarse_overlap_period" (trials between two overlapped inversions;
+   0 = invert in line, on the policy of the next two options), "coarse_first_reuse" (default 1: the first solve of an LM run starts with the
+   inverse the first solve of the PREVIOUS run on this structure had -- same damping regime -- while its own inversion runs on the second stream, so
+   that only the very first run on a structure inverts in line; 0 = every run inverts in line for its first solve), "coarse_overlap_period" (trials between two overlapped inversions;
    -1 = automatic: every trial up to a coarse dimension of 512, every second up to 1024, every third beyond), "coarse_max_age" (in-line mode; default 3: the coarse
    inverse of the two-level preconditioner is reused for up to three further solves of a run; 0 = rebuild it for every
    solve), "coarse_refresh_growth" (in-line mode; default 1.6: rebuild early once a solve needs that many times the iterations of

@@ -10,7 +10,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "kitti00"
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 RK = ((1, np.sqrt(5.991)), (1, np.sqrt(7.815)))
 fp = flatten(synth_named(name))
-h = HipSolver(fp, RK)
+opts = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in os.environ.get("CUBA_PROF_OPTS", "").split(",") if kv)   # e.g. CUBA_PROF_OPTS=device_setup=0
+h = HipSolver(fp, RK, **opts)
 h.build_structure()
 q0, t0, X0 = h.state()
 for r in range(runs + 1):
