@@ -259,7 +259,7 @@ struct cuba_hip_solver
 		return coarseOverlapPeriod > 0 ? coarseOverlapPeriod : Nc <= 512 ? 1 : Nc <= 1024 ? 2 : 3;
 	}
 	hipStream_t gjStream = nullptr;
-	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr;
+	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr, evFirstInv = nullptr;
 	int liveInv = 0, pendingInv = -1;   // buffer with the inverse in use / buffer the running inversion will leave its result in
 	bool assemblePending = false;       // the other stream may still be reading hsc
 	void ensureOverlapObjects()
@@ -271,6 +271,8 @@ struct cuba_hip_solver
 		HIP_TRY(hipEventCreateWithFlags(&evSetup, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&evAssembled, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&evInverse, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&evFirstInv, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(evFirstInv, gjStream));
 	}
 	// the work stream must not touch what a running inversion still uses
 	void waitAssembled() { if (assemblePending) { HIP_TRY(hipStreamWaitEvent(stream, evAssembled, 0)); assemblePending = false; } }
@@ -302,7 +304,7 @@ struct cuba_hip_solver
 	~cuba_hip_solver()
 	{
 		dropPcgGraph();
-		if (gjStream) { (void)hipStreamSynchronize(gjStream); (void)hipStreamDestroy(gjStream); (void)hipEventDestroy(evSetup); (void)hipEventDestroy(evAssembled); (void)hipEventDestroy(evInverse); }
+		if (gjStream) { (void)hipStreamSynchronize(gjStream); (void)hipStreamDestroy(gjStream); (void)hipEventDestroy(evSetup); (void)hipEventDestroy(evAssembled); (void)hipEventDestroy(evInverse); (void)hipEventDestroy(evFirstInv); }
 		if (captureStream) (void)hipStreamDestroy(captureStream);
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
@@ -1524,13 +1526,6 @@ struct cuba_hip_solver
 		{
 			HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done
 			takeInverse = true; pendingInv = -1;
-			if (firstInvPending)
-			{
-				// (the inversion that ran under the first solve of this run: the next run's first solve starts with it)
-				if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream));
-				else HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invCount * sizeof(Scalar), hipMemcpyDeviceToDevice, stream));
-				firstInvPending = false; firstInvValid = true;
-			}
 		}
 		// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
 		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
@@ -1558,10 +1553,11 @@ struct cuba_hip_solver
 				{
 					// first solve of a run on a structure that has seen a run before: start with the inverse that run's first solve had
 					// and let this trial's own inversion run on the other stream right away
+					HIP_TRY(hipStreamWaitEvent(stream, evFirstInv, 0));       // (the copy the previous run's first trial left on the other stream: long done)
 					if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_coarse32[0].data(), d_firstInv32.data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream));
 					else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_firstInv.data(), invBytes, hipMemcpyDeviceToDevice, stream));
 					pendingInv = -1;                 // (a sweep the previous run left behind is simply overtaken: the streams order themselves)
-					coarseValid = true; sideAge = overlapPeriod(); firstInvPending = true;
+					coarseValid = true; sideAge = overlapPeriod(); firstInvPending = true;      // (this trial's own matrix is inverted on the other stream, below)
 				}
 				else if (!coarseValid)
 				{
@@ -1570,26 +1566,41 @@ struct cuba_hip_solver
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
 					else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
+					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
 					if (coarseFirstReuse)
 					{
-						if (fp32Inverse()) { d_firstInv32.resize(inv32Count()); HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[0].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream)); }
-						else { d_firstInv.resize(invCount); HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream)); }
-						firstInvValid = true; firstInvPending = false;
+						// every run keeps ONE schedule of overlapped inversions -- under trial 1, 1 + period, ... --, whether its first solve was
+						// given an in-line inverse (here: the first run on a structure; the sweep under trial 1 then repeats this inversion) or
+						// the carried-over one: repeating a run from the same estimate reproduces it bit for bit.  The sweep under trial 1
+						// leaves its result for the next run's first solve.
+						if (fp32Inverse()) d_firstInv32.resize(inv32Count()); else d_firstInv.resize(invCount);
+						sideAge = overlapPeriod(); firstInvPending = true;
 					}
-					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
 				}
 				sys.acinv = d_coarse[2].data();
 				// this trial's matrix -> the inverse the next trial will use, on the other stream (after the copy above): every
 				// trial for small coarse dimensions, every overlapPeriod()-th one beyond (the sweep's share of the CUs slows
 				// the latency-bound PCG kernels it runs under)
-				if (++sideAge >= overlapPeriod())
+				// (a run that started with the carried-over inverse inverts its first trial's matrix on the other stream IN ADDITION to
+				// the regular schedule, which stays that of a run that inverted in line: repeating a run from the same estimate
+				// reproduces it bit for bit)
+				const bool regular = ++sideAge >= overlapPeriod();
+				if (regular) sideAge = 0;
+				if (regular)
 				{
 					HIP_TRY(hipEventRecord(evSetup, stream));
 					HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
 					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[1].data(), 6 * sys.cl * sys.nc, gjStream);   // (staging: the iteration graphs read [0])
+					if (firstInvPending)
+					{
+						if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, gjStream));
+						else HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, gjStream));
+						HIP_TRY(hipEventRecord(evFirstInv, gjStream));
+						firstInvPending = false; firstInvValid = true;
+					}
 					HIP_TRY(hipEventRecord(evInverse, gjStream));
-					pendingInv = 0; sideAge = 0;
+					pendingInv = 0;
 					assemblePending = true; cntCoarseRefresh++;
 				}
 				coarseFresh = false;
