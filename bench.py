@@ -49,14 +49,15 @@ LM_RUN = 10               # iterations per LM run (the reference protocol: optim
 def algorithmic_bytes(fp, nblk, nc):
     """Compulsory bytes per launch of each hot kernel. nc = coarse aggregates."""
     E, Pf, Pt, Lf, Lt = fp.E, fp.Pf, fp.Pt, fp.Lf, fp.Lt
-    Nc = 6 * nc
+    Nc = int(round(6 * nc))
     edge_in = 40 * E                     # pose idx 4 + landmark idx 4 + 3 x 8 measurement + 8 information
     return {
         "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
         "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
         "pcg_spmv": 288 * nblk + 4 * 48 * Pf + 8 * (2 * nblk - Pf),     # blocks + z, p in / p, q out + (block, column) index pairs
-        # two-level: fused update + restrict + preconditioner (one read of r, q, p, x, Minv, one of the coarse inverse)
-        "pcg_update": (288 + 6 * 48) * Pf if nc == 0 else (288 + 7 * 48) * Pf + 8 * Nc * Nc,
+        # two-level: fused update + restrict + preconditioner (one read of r, q, p, x, Minv, one of the coarse inverse -- stored in fp32,
+        # rows padded to a multiple of 4 numbers: option precond_fp32, the fp64 library's default)
+        "pcg_update": (288 + 6 * 48) * Pf if nc == 0 else (288 + 7 * 48) * Pf + 4 * Nc * ((Nc + 3) // 4 * 4),
         "pcg_precond": 8 * Nc * Nc + 8 * Nc + (288 + 2 * 48) * Pf,
         "coarse_setup": 288 * nblk + 3 * 8 * Nc * Nc,          # read Hsc once, write Ac, read+write it once more for the inverse
         "back_substitute": edge_in + (24 + 72 + 24) * Lf + (96 + 48) * Pt,
