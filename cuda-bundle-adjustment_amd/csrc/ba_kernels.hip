@@ -2953,6 +2953,395 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
+// ===================================================================================================
+// Single-kernel PCG iteration (round 3).  The two-kernel iteration above pays two dependent launches and two round trips of
+// freshly written cross-XCD data per iteration (~15.6 us at KITTI-00 size, 2/3 of a run).  Here ONE launch does a whole iteration:
+//   * Chronopoulos-Gear recurrences -- u = M^-1 r, w = A u, p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s, with
+//     gamma = r.u and delta = w.u reduced together, alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1}) -- need one global
+//     reduction per iteration, and the kernel boundary is that reduction's synchronisation;
+//   * a workgroup owns one coarse aggregate.  It recomputes r_{k+1} and u_{k+1} = M^-1 r_{k+1} on its HALO (the poses its block rows
+//     touch: r_k, w_k, s_{k-1} of ~50 poses from the previous launches), which needs the coarse correction of the few aggregates the
+//     halo poses belong to: those rows of the explicit coarse inverse (fp32) times P^T r_{k+1}, the latter again by recurrence from
+//     the restricted vectors P^T r_k, P^T w_k, P^T s_{k-1} that every workgroup left behind (12 numbers each);
+//   * then w_{k+1} = A u_{k+1} on its own rows from the row-ordered matrix copy (wave = block row, as pcg_spmv_row_kernel), the
+//     two dot products, and its 12 entries of the restricted vectors for the next launch.
+// Every address is known at launch (ring slots by k & 3, ping-pong buffers by k & 1): index arrays first, everything else in one
+// batch.  The preconditioner M^-1 = blockdiag^-1 + P Ac^-1 P^T is the same fixed SPD operator as in the two-kernel iteration and the
+// stop test the same quantity (r.u = r.z), so iteration counts and results agree to rounding.
+// ===================================================================================================
+constexpr int PCG1_T = 512;
+
+// NQ: 16-byte loads per lane and coarse-inverse row (covers a coarse dimension of 64 W NQ); RB: rows per wave whose loads are in
+// flight together
+template <int CL, int W, int NQ, int RB>
+__global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	constexpr int CD = 6 * CL;
+	typedef typename std::conditional<W == 4, float, Scalar>::type PT;
+	typedef typename InvVec<PT, W>::type AV;
+	extern __shared__ __align__(16) unsigned char pcg1_lds[];
+	const int Nc = CD * sys.nc, NcP = (Nc + 3) & ~3, ld = W == 4 ? NcP : Nc;
+	const PT* acinv = W == 4 ? reinterpret_cast<const PT*>(sys.acinv32) : reinterpret_cast<const PT*>(sys.acinv);
+	Scalar* sC = reinterpret_cast<Scalar*>(pcg1_lds);    // [NcP] P^T r_{k+1}
+	Scalar* sY = sC + NcP;                                // [jmax][CD] coarse correction of the halo aggregates
+	Scalar* sR = sY + st.jmax * CD;                       // [hmax][6] r_{k+1} on the halo
+	Scalar* sU = sR + 6 * st.hmax;                        // [hmax][6] u_{k+1} on the halo
+	Scalar* sW = sU + 6 * st.hmax;                        // [agg][6]  w_{k+1} on the own rows
+	Scalar* red = sW + 6 * sys.agg;                       // [4][8] per-wave partial sums
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6, I = blockIdx.x;
+	const int pk = k & 1;
+	const Scalar* rin = pk ? sys.r2 : sys.r;       Scalar* rout = pk ? sys.r : sys.r2;
+	const Scalar* win = pk ? sys.w2 : sys.ap;      Scalar* wout = pk ? sys.ap : sys.w2;
+	const Scalar* sin_ = pk ? sys.s0 : sys.s1;     Scalar* sout = pk ? sys.s1 : sys.s0;        // s_{k-1} in, s_k out
+	const Scalar* cRin = sys.rc + (pk ? Nc : 0);   Scalar* cRout = sys.rc + (pk ? 0 : Nc);
+	const Scalar* cWin = sys.cw + (pk ? Nc : 0);   Scalar* cWout = sys.cw + (pk ? 0 : Nc);
+	const Scalar* cSin = sys.cs + (pk ? 0 : Nc);   Scalar* cSout = sys.cs + (pk ? Nc : 0);     // P^T s_{k-1} in, P^T s_k out
+	const int r0 = I * sys.agg, r1 = min(g.Pf, r0 + sys.agg), nOwn = r1 - r0;
+	const int W20 = 20 * st.ell_m;
+
+	// ---- loads: flags, reduction partials, index arrays ------------------------------------------------------------------
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	Scalar e_k = 0, e_m = 0, e_0 = 0, e_d = 0;
+	if (t < sys.nc) { e_k = rz_slot(sys, k)[t]; e_m = rz_slot(sys, k - 1)[t]; e_0 = sys.rz[t]; e_d = pq_slot(sys, k)[t]; }
+	int zero; asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+	const Scalar a_prev_v = sys.alpha[1 - pk + zero];
+	const int nH = st.hal_n[I], nJ = st.hal_nj[I];
+	// halo vectors: thread x = (halo pose, component), two trips cover 170 poses
+	int hp[2]; Scalar hr[2] = { 0, 0 }, hw[2] = { 0, 0 }, hs[2] = { 0, 0 }, hm[2][6]; int hal[2] = { 0, 0 };
+#pragma unroll
+	for (int q = 0; q < 2; q++)
+	{
+		const int x = t + q * PCG1_T;
+		hp[q] = x < 6 * nH ? st.hal_pose[(size_t)I * st.hmax + x / 6] : -1;
+		if (hp[q] >= 0) hal[q] = st.hal_aloc[(size_t)I * st.hmax + x / 6];
+	}
+	// coarse vectors: thread pairs (2 t, 2 t + 1), three trips cover a coarse dimension of 3072
+	Scalar2 vR[3], vW[3], vS[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++)
+	{
+		const int j = 2 * (t + q * PCG1_T);
+		vR[q] = vW[q] = vS[q] = Scalar2{ 0, 0 };
+		if (j < Nc)
+		{
+			vR[q] = *reinterpret_cast<const Scalar2*>(cRin + j); vW[q] = *reinterpret_cast<const Scalar2*>(cWin + j); vS[q] = *reinterpret_cast<const Scalar2*>(cSin + j);
+		}
+	}
+	// own rows: u_k, p_{k-1}, x_k
+	Scalar pre_u = 0, pre_p = 0, pre_x = 0;
+	if (t < 6 * nOwn) { const size_t gi = 6 * (size_t)r0 + t; pre_u = sys.z[gi]; pre_p = sys.p0[gi]; pre_x = sys.xp[gi]; }
+	// halo vectors (second round trip: their addresses come from the static index arrays above)
+#pragma unroll
+	for (int q = 0; q < 2; q++)
+	{
+#pragma unroll
+		for (int c = 0; c < 6; c++) hm[q][c] = 0;
+		if (hp[q] >= 0)
+		{
+			const int comp = (t + q * PCG1_T) % 6;
+			const size_t gi = 6 * (size_t)hp[q] + comp;
+			hr[q] = rin[gi]; hw[q] = win[gi]; hs[q] = sin_[gi];
+#pragma unroll
+			for (int c = 0; c < 6; c++) hm[q][c] = sys.minv[36 * (size_t)hp[q] + c * 6 + comp];
+		}
+	}
+	// first batch of coarse-inverse rows: wave wv takes rows wv, wv + 8, ... of the nJ * CD rows its halo needs
+	const int nRows = nJ * CD;
+	AV ainv[RB][NQ];
+	int rowOf[RB];
+#pragma unroll
+	for (int q = 0; q < RB; q++)
+	{
+		const int ri = wv + 8 * q;
+		rowOf[q] = ri < nRows ? CD * st.hagg_id[(size_t)I * st.jmax + ri / CD] + ri % CD : -1;
+	}
+#pragma unroll
+	for (int q = 0; q < RB; q++)
+	{
+		const PT* Arow = acinv + (size_t)max(rowOf[q], 0) * ld;
+#pragma unroll
+		for (int m = 0; m < NQ; m++) ainv[q][m] = rowOf[q] >= 0 ? *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * m, ld - W)) : AV(0);
+	}
+
+	// ---- scalars ---------------------------------------------------------------------------------------------------------------
+	for (int u = t + PCG1_T; u < sys.nc; u += PCG1_T) { e_k += rz_slot(sys, k)[u]; e_m += rz_slot(sys, k - 1)[u]; e_0 += sys.rz[u]; e_d += pq_slot(sys, k)[u]; }
+	e_k = wave_sum(e_k); e_m = wave_sum(e_m); e_0 = wave_sum(e_0); e_d = wave_sum(e_d);
+	if (lane == 0) { red[wv] = e_k; red[8 + wv] = e_m; red[16 + wv] = e_0; red[24 + wv] = e_d; }
+	__syncthreads();
+	Scalar gk = 0, gm = 0, g0 = 0, dk = 0;
+#pragma unroll
+	for (int w = 0; w < PCG1_T / 64; w++) { gk += red[w]; gm += red[8 + w]; g0 += red[16 + w]; dk += red[24 + w]; }
+	const int kabs = k + __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	if (!(kabs < maxIter && failed == 0 && gk > tol2 * g0 && gk == gk))          // uniform over the grid
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(gk == gk)) *sys.fail = 3; }
+		return;
+	}
+	const Scalar a_prev = to_uniform(a_prev_v);
+	const Scalar beta = kabs > 0 ? gk / gm : Scalar(0);
+	const Scalar den = kabs > 0 ? dk - beta * gk / a_prev : dk;
+	if (!(den > 0))
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;      // not positive definite along the search direction
+		return;
+	}
+	const Scalar alpha = gk / den;
+
+	// ---- restricted vectors: P^T s_k, P^T r_{k+1} ----------------------------------------------------------------------------------
+#pragma unroll
+	for (int q = 0; q < 3; q++)
+	{
+		const int j = 2 * (t + q * PCG1_T);
+		if (j < Nc)
+		{
+			const Scalar2 cs = vW[q] + beta * vS[q];
+			const Scalar2 cr = vR[q] - alpha * cs;
+			*reinterpret_cast<Scalar2*>(sC + j) = cr;
+			if (j >= CD * I && j < CD * I + CD)        // (CD is even: a pair never straddles two aggregates)
+			{
+				*reinterpret_cast<Scalar2*>(cSout + j) = cs; *reinterpret_cast<Scalar2*>(cRout + j) = cr;
+			}
+		}
+	}
+	if (t < NcP - Nc) sC[Nc + t] = 0;
+	__syncthreads();
+
+	// ---- coarse correction of the halo aggregates: yc = Ac^-1[rows] (P^T r_{k+1}) -----------------------------------------------------
+	for (int b = 0; 8 * RB * b < nRows; b++)
+	{
+		if (b > 0)
+		{
+#pragma unroll
+			for (int q = 0; q < RB; q++)
+			{
+				const int ri = wv + 8 * (RB * b + q);
+				rowOf[q] = ri < nRows ? CD * st.hagg_id[(size_t)I * st.jmax + ri / CD] + ri % CD : -1;
+			}
+#pragma unroll
+			for (int q = 0; q < RB; q++)
+			{
+				const PT* Arow = acinv + (size_t)max(rowOf[q], 0) * ld;
+#pragma unroll
+				for (int m = 0; m < NQ; m++) ainv[q][m] = rowOf[q] >= 0 ? *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * m, ld - W)) : AV(0);
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < RB; q++)
+		{
+			Scalar acc = 0;
+#pragma unroll
+			for (int m = 0; m < NQ; m++)
+			{
+				const int j = W * lane + 64 * W * m;
+				if (j < Nc)
+				{
+#pragma unroll
+					for (int i = 0; i < W; i++) acc += (Scalar)ainv[q][m][i] * sC[j + i];
+				}
+			}
+			if (rowOf[q] >= 0)
+				for (int j = lane + 64 * W * NQ; j < Nc; j += 64) acc += (Scalar)acinv[(size_t)rowOf[q] * ld + j] * sC[j];     // (beyond the instantiated width: never in practice)
+			acc = wave_sum(acc);
+			const int ri = wv + 8 * (RB * b + q);
+			if (lane == 0 && ri < nRows) sY[ri] = acc;            // row ri = (local aggregate ri / CD, coarse unknown ri % CD)
+		}
+	}
+
+	// ---- halo: s_k, r_{k+1} ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+	for (int q = 0; q < 2; q++)
+	{
+		if (hp[q] >= 0)
+		{
+			const int x = t + q * PCG1_T;
+			const Scalar sk = hw[q] + beta * hs[q];
+			const Scalar rn = hr[q] - alpha * sk;
+			sR[x] = rn;
+			if (hp[q] >= r0 && hp[q] < r1) { const size_t gi = 6 * (size_t)hp[q] + x % 6; sout[gi] = sk; rout[gi] = rn; }
+		}
+	}
+	__syncthreads();
+	// ---- halo: u_{k+1} = blockdiag^-1 r_{k+1} + P yc -------------------------------------------------------------------------------------
+#pragma unroll
+	for (int q = 0; q < 2; q++)
+	{
+		if (hp[q] >= 0)
+		{
+			const int x = t + q * PCG1_T, hl = x / 6, comp = x - 6 * hl;
+			Scalar u = sY[hal[q] * CD + comp];
+			if (CL == 2) u += agg_weight(hp[q], sys.agg, g.Pf) * sY[hal[q] * CD + 6 + comp];
+#pragma unroll
+			for (int c = 0; c < 6; c++) u += hm[q][c] * sR[6 * hl + c];
+			sU[x] = u;
+		}
+	}
+	__syncthreads();
+
+	// ---- w_{k+1} = A u_{k+1} on the own rows: wave = block row, lane = (slot, pair of block rows) --------------------------------------
+	{
+		const int slot = lane / 3, r2 = lane - 3 * slot;
+		for (int il = wv; il < nOwn; il += PCG1_T / 64)
+		{
+			const int row = r0 + il;
+			Scalar az0 = 0, az1 = 0;
+			int loc[3];
+#pragma unroll
+			for (int m = 0; m < 3; m++) loc[m] = (lane < 60 && m < st.ell_m) ? st.ell_loc[(size_t)row * W20 + m * 20 + slot] : -1;
+			Scalar2 a0v[3][3], a1v[3][3];
+#pragma unroll
+			for (int m = 0; m < 3; m++)
+			{
+				const Scalar2* A2 = reinterpret_cast<const Scalar2*>(sys.hrow + 36 * ((size_t)row * W20 + m * 20 + slot) + 12 * r2);
+#pragma unroll
+				for (int c = 0; c < 3; c++)
+				{
+					a0v[m][c] = loc[m] >= 0 ? A2[c] : Scalar2{ 0, 0 };
+					a1v[m][c] = loc[m] >= 0 ? A2[3 + c] : Scalar2{ 0, 0 };
+				}
+			}
+#pragma unroll
+			for (int m = 0; m < 3; m++)
+			{
+				if (loc[m] >= 0)
+				{
+					const Scalar2* u2 = reinterpret_cast<const Scalar2*>(sU + 6 * loc[m]);
+#pragma unroll
+					for (int c = 0; c < 3; c++)
+					{
+						const Scalar2 uv = u2[c];
+						az0 += a0v[m][c].x * uv.x + a0v[m][c].y * uv.y;
+						az1 += a1v[m][c].x * uv.x + a1v[m][c].y * uv.y;
+					}
+				}
+			}
+			// fold the 20 slots (lanes 3 apart) onto lanes 0..2, then spread the six block rows over lanes 0..5
+			az0 += __shfl_down(az0, 30); az1 += __shfl_down(az1, 30);
+			az0 += __shfl_down(az0, 15); az1 += __shfl_down(az1, 15);
+			Scalar t0 = az0, t1 = az1;
+#pragma unroll
+			for (int d = 3; d <= 12; d += 3) { t0 += __shfl_down(az0, d); t1 += __shfl_down(az1, d); }
+			const Scalar wA = __shfl(t0, lane >> 1), wB = __shfl(t1, lane >> 1);
+			if (lane < 6)
+			{
+				const Scalar wn = (lane & 1) ? wB : wA;
+				sW[6 * il + lane] = wn;
+				wout[6 * (size_t)row + lane] = wn;
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- own rows: p_k, x_{k+1}, u_{k+1}; gamma_{k+1}, delta_{k+1}; P^T w_{k+1} ---------------------------------------------------------
+	Scalar dg = 0, dd = 0;
+	if (t < 6 * nOwn)
+	{
+		const int il = t / 6, comp = t - 6 * il;
+		const size_t gi = 6 * (size_t)r0 + t;
+		const int lo = st.own_loc[r0 + il];
+		const Scalar rn = sR[6 * lo + comp], un = sU[6 * lo + comp], wn = sW[t];
+		const Scalar pkv = pre_u + beta * pre_p;
+		sys.p0[gi] = pkv;
+		sys.xp[gi] = pre_x + alpha * pkv;
+		sys.z[gi] = un;
+		dg = rn * un; dd = wn * un;
+	}
+	dg = wave_sum(dg); dd = wave_sum(dd);
+	__syncthreads();                       // (red is reused)
+	if (lane == 0) { red[wv] = dg; red[8 + wv] = dd; }
+	if (t >= 64 && t < 64 + CD)
+	{
+		const int u = t - 64, a = u / 6, c = u - 6 * a;
+		Scalar s3 = 0;
+		for (int il = 0; il < nOwn; il++) s3 += (a == 0 ? Scalar(1) : agg_weight_local(I, il, sys, g.Pf)) * sW[6 * il + c];
+		cWout[CD * I + u] = s3;
+	}
+	__syncthreads();
+	if (t == 0)
+	{
+		Scalar sg = 0, sd = 0;
+#pragma unroll
+		for (int w = 0; w < PCG1_T / 64; w++) { sg += red[w]; sd += red[8 + w]; }
+		rz_slot_w(sys, k + 1)[I] = sg;
+		pq_slot(sys, k + 1)[I] = sd;
+		if (I == 0) { sys.alpha[pk] = alpha; *sys.iters = kabs + 1; }
+	}
+}
+
+// per-solve start of the single-kernel iteration, after pcg_setup (r_0, blockdiag^-1, x = p = 0), the fused kernel with doUpdate = 0
+// (u_0 = M^-1 r_0 -> z, P^T r_0 -> rc, gamma_0) and the SpMV with k = 0 (w_0 = A u_0 -> ap, its dot-product partials, the row sums of
+// w_0 in qpart): delta_0 as nc partials, P^T w_0, and zeros for s_{-1}, P^T s_{-1}
+__global__ __launch_bounds__(256) void pcg1_init_kernel(DeviceGraph g, DeviceSystem sys)
+{
+	const int Nc = 6 * sys.cl * sys.nc;
+	const int gt = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+	const int per = sys.agg / sys.spmv_rows;
+	for (int j = gt; j < Nc; j += stride)
+	{
+		Scalar s2 = 0;
+		for (int m = 0; m < per; m++) s2 += sys.qpart[(size_t)m * Nc + j];
+		sys.cw[j] = s2;               // P^T w_0 (k = 0 reads the first halves)
+		sys.cs[Nc + j] = 0;           // P^T s_{-1}
+	}
+	for (int i = gt; i < 6 * g.Pf; i += stride) sys.s1[i] = 0;      // s_{-1}
+	if (blockIdx.x == 0)
+	{
+		__shared__ Scalar sh[4];
+		Scalar v = 0;
+		for (int u = threadIdx.x; u < sys.npq; u += 256) v += pq_slot(sys, 0)[u];
+		v = wave_sum(v);
+		if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+		__syncthreads();
+		const Scalar tot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+		__syncthreads();
+		for (int u = threadIdx.x; u < sys.nc; u += 256) pq_slot(sys, 0)[u] = u == 0 ? tot : Scalar(0);
+		if (threadIdx.x == 0) { sys.alpha[0] = 0; sys.alpha[1] = 0; }
+	}
+}
+
+struct Pcg1Variant { void* fn; int width; };       // width = coarse dimension the instantiation covers
+static Pcg1Variant pcg1_kernel_for(const DeviceSystem& sys)
+{
+	const int Nc = 6 * sys.cl * sys.nc;
+	const bool f32 = sys.acinv32 && sizeof(Scalar) == 8;
+	if (sys.cl == 2)
+	{
+		if (f32) return Nc <= 1024 ? Pcg1Variant{ (void*)pcg1_kernel<2, 4, 4, 6>, 1024 } : Nc <= 1536 ? Pcg1Variant{ (void*)pcg1_kernel<2, 4, 6, 4>, 1536 } : Pcg1Variant{ (void*)pcg1_kernel<2, 4, 9, 3>, 2304 };
+		return Nc <= 768 ? Pcg1Variant{ (void*)pcg1_kernel<2, 2, 6, 4>, 768 } : Pcg1Variant{ (void*)pcg1_kernel<2, 2, 12, 2>, 1536 };
+	}
+	if (f32) return Nc <= 1024 ? Pcg1Variant{ (void*)pcg1_kernel<1, 4, 4, 6>, 1024 } : Pcg1Variant{ (void*)pcg1_kernel<1, 4, 9, 3>, 2304 };
+	return Nc <= 768 ? Pcg1Variant{ (void*)pcg1_kernel<1, 2, 6, 4>, 768 } : Pcg1Variant{ (void*)pcg1_kernel<1, 2, 12, 2>, 1536 };
+}
+
+static size_t pcg1_lds_bytes(const DeviceStructure& st, const DeviceSystem& sys)
+{
+	const size_t cd = 6 * (size_t)sys.cl;
+	const size_t ncp = (cd * sys.nc + 3) & ~(size_t)3;
+	return sizeof(Scalar) * (ncp + (size_t)st.jmax * cd + 12 * (size_t)st.hmax + 6 * (size_t)sys.agg + 32);
+}
+
+bool pcg1_supported(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys)
+{
+	if (sys.agg <= 0 || sys.nc <= 0 || st.ell_over || st.ell_m < 1 || st.ell_m > 3 || !st.hal_n) return false;
+	const int Nc = 6 * sys.cl * sys.nc;
+	if (6 * sys.agg > PCG1_T || 6 * st.hmax > 2 * PCG1_T || Nc > 6 * PCG1_T || sys.nc > sys.rzStride || sys.nc > sys.pqStride) return false;
+	if (Nc > pcg1_kernel_for(sys).width) return false;
+	return pcg1_lds_bytes(st, sys) <= 64 * 1024;
+}
+
+void launch_pcg1_init(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s)
+{
+	const int n = max(6 * sys.cl * sys.nc, 6 * g.Pf);
+	hipLaunchKernelGGL(pcg1_init_kernel, dim3(min(256, (n + 255) / 256)), dim3(256), 0, s, g, sys);
+}
+
+void launch_pcg1(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
+{
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar))pcg1_kernel_for(sys).fn, dim3(sys.nc), dim3(PCG1_T),
+		pcg1_lds_bytes(st, sys), s, g, st, sys, k, maxIter, tol2);
+}
+
 static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
 int spmv_rows_for(int Pf)
 {
@@ -3058,7 +3447,9 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 {
 	hipGraphNode_t last = nullptr;
 	hipError_t e = hipSuccess;
-	for (int k = 0; k < chunk && e == hipSuccess; k++)
+	for (int k = 0; k < chunk && e == hipSuccess && sys.cg1; k++)
+		e = add_kernel_node(graph, last, pcg1_kernel_for(sys).fn, dim3(sys.nc), dim3(PCG1_T), (unsigned)pcg1_lds_bytes(st, sys), g, st, sys, k, maxIter, tol2);
+	for (int k = 0; k < chunk && e == hipSuccess && !sys.cg1; k++)
 	{
 		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;

@@ -73,6 +73,13 @@ struct DeviceStructure
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
 	Scalar *cb_wi = nullptr, *cb_wj = nullptr;                                    // weights of the fine (row, column) poses of every list entry in the linear coarse functions
+	// halo lists of the coarse aggregates (ba_structure.hip: halo_lists_kernel) for the single-kernel PCG iteration
+	int *hal_n = nullptr, *hal_nj = nullptr;       // [nc] poses / aggregates in the halo of each aggregate
+	int *hal_pose = nullptr, *hal_aloc = nullptr;  // [nc * hmax] the poses (ascending) and the local index of each one's aggregate
+	int* hagg_id = nullptr;                        // [nc * jmax] the aggregates
+	int* ell_loc = nullptr;                        // parallel to ell: local (halo) index of the entry's column
+	int* own_loc = nullptr;                        // [Pf] local index of a pose in its OWN aggregate's halo list
+	int hmax = 0, jmax = 0;
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo (integer bits)}
 	int mixed = 0;                     // fp64 library only: 1 = records and the per-edge arithmetic of the pose / block passes in fp32
 };
@@ -124,6 +131,10 @@ struct DeviceSystem
 	                           // indexed by the workgroup's position inside its aggregate (P^T q is summed from these:
 	                           // aggregates are whole multiples of spmv_rows rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
+	// single-kernel iteration (pcg1_kernel, Chronopoulos-Gear recurrences): w = A u (ping-pong with ap), s = A p (ping-pong),
+	// the restricted vectors P^T w and P^T s (ping-pong, 2 x coarse dimension each; P^T r lives in rc), alpha of the last two iterations
+	int cg1 = 0;               // 1: the iteration graphs hold one pcg1_kernel per iteration instead of SpMV + fused kernel
+	Scalar *w2 = nullptr, *s0 = nullptr, *s1 = nullptr, *cw = nullptr, *cs = nullptr, *alpha = nullptr;
 };
 
 // residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
@@ -173,6 +184,11 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
+// single-kernel PCG iteration: can this configuration run it (kernel instantiation + LDS)?  / the per-solve initialisation that
+// follows pcg_setup + fused(doUpdate = 0) + SpMV(k = 0) / one iteration (eager launch; the graphs add the same node)
+bool pcg1_supported(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys);
+void launch_pcg1_init(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
+void launch_pcg1(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s);   // n x n inverse -> sys.acinv32 layout
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 

@@ -165,6 +165,10 @@ struct cuba_hip_solver
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
 	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
+	// single-kernel PCG iteration: halo lists of the aggregates + its vectors
+	DevBuf<int> d_halN, d_halNJ, d_halPose, d_halAloc, d_haggId, d_ellLoc, d_ownLoc;
+	DevBuf<Scalar> d_w2, d_s0, d_s1, d_cw, d_cs, d_alpha;
+	int pcgSingleKernel = 1;     // option "pcg_single_kernel": 1 = one launch per PCG iteration where the configuration allows it
 	bool localRanges = false;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -205,7 +209,8 @@ struct cuba_hip_solver
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
 	{
-		if (sys.agg > 0)
+		if (sys.agg > 0 && sys.cg1) launch_pcg1(g, st, sys, k, maxIter, tol2, s);
+		else if (sys.agg > 0)
 		{
 			launch_pcg_spmv(g, st, sys, k, maxIter, tol2, s);
 			launch_pcg2_fused(g, sys, k, k + 1, maxIter, tol2, 1, s);
@@ -249,6 +254,7 @@ struct cuba_hip_solver
 	// tile products): 9.43 -> 9.09 ms at KITTI-00 with a refresh under every trial; at S2M ten 0.85 ms sweeps per run cost the
 	// latency-bound PCG kernels more than they save (28.7 vs 28.4 ms), one under every third trial does pay (27.1 ms; G4M 67.6 -> 65.3).
 	int coarseOverlap = -1;       // -1 automatic, 0 off, 1 on
+	int coarseCuMask = 0;         // > 1: the second stream may use every n-th CU only (set before the first solve)
 	int coarseOverlapPeriod = -1; // trials between two overlapped refreshes: -1 automatic (1 up to a coarse dimension of 512, 2 up to 1024, 3 beyond)
 	int sideAge = 0;
 	bool overlapActive() const { return coarseOverlap != 0; }
@@ -267,7 +273,20 @@ struct cuba_hip_solver
 		if (gjStream) return;
 		int prioLow = 0, prioHigh = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-		HIP_TRY(hipStreamCreateWithPriority(&gjStream, hipStreamNonBlocking, prioLow));   // fills the gaps of the latency-bound PCG kernels, must not delay them
+		// The sweep must not delay the latency-bound PCG kernels it runs under.  A low priority alone does not do it: a Gauss-Jordan
+		// step is ~1000 workgroups that fill every CU for ~10 us, and a PCG kernel that arrives meanwhile waits for them (gaps of
+		// 18-59 us inside the iteration graphs, profiles/r03p_*).  Option "coarse_cu_mask" = n > 1 confines the second stream to every
+		// n-th compute unit instead (hipExtStreamCreateWithCUMask): the sweep takes longer, the other CUs stay free.
+		if (coarseCuMask > 1)
+		{
+			hipDeviceProp_t prop;
+			HIP_TRY(hipGetDeviceProperties(&prop, device));
+			const int nCu = prop.multiProcessorCount;
+			std::vector<uint32_t> mask((size_t)(nCu + 31) / 32, 0u);
+			for (int c = 0; c < nCu; c += coarseCuMask) mask[c >> 5] |= 1u << (c & 31);
+			HIP_TRY(hipExtStreamCreateWithCUMask(&gjStream, (uint32_t)mask.size(), mask.data()));
+		}
+		else HIP_TRY(hipStreamCreateWithPriority(&gjStream, hipStreamNonBlocking, prioLow));   // fills the gaps of the latency-bound PCG kernels
 		HIP_TRY(hipEventCreateWithFlags(&evSetup, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&evAssembled, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&evInverse, hipEventDisableTiming));
@@ -1030,6 +1049,30 @@ struct cuba_hip_solver
 		sys.spmv_rows = spmvRows;
 		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
+		// single-kernel iteration: halo lists of the aggregates (two small launches + one read-back of their maximal lengths)
+		sys.cg1 = 0;
+		if (agg > 0 && pcgSingleKernel && !ellOver && ellM >= 1 && topo::halo_lds_bytes(Pf, nc) <= 48 * 1024)
+		{
+			d_counters.resize(topo::CNT_COUNT);
+			HIP_TRY(hipMemsetAsync(d_counters.data() + topo::CNT_MAXH, 0, 2 * sizeof(int), stream));
+			d_halN.resize(nc); d_halNJ.resize(nc);
+			topo::launch_halo_count(d_ell.data(), Pf, ellM, agg, nc, d_halN.data(), d_halNJ.data(), d_counters.data(), stream);
+			int mx[2] = { 0, 0 };
+			HIP_TRY(hipMemcpyAsync(mx, d_counters.data() + topo::CNT_MAXH, sizeof mx, hipMemcpyDeviceToHost, stream));
+			sync();
+			st.hmax = mx[0]; st.jmax = mx[1];
+			d_halPose.resize((size_t)nc * st.hmax); d_halAloc.resize((size_t)nc * st.hmax); d_haggId.resize((size_t)nc * st.jmax);
+			d_ellLoc.resize((size_t)Pf * ellM * 20); d_ownLoc.resize(Pf);
+			topo::launch_halo_fill(d_ell.data(), Pf, ellM, agg, nc, st.hmax, st.jmax, d_halPose.data(), d_halAloc.data(), d_haggId.data(), d_ellLoc.data(), d_ownLoc.data(), stream);
+			st.hal_n = d_halN.data(); st.hal_nj = d_halNJ.data(); st.hal_pose = d_halPose.data(); st.hal_aloc = d_halAloc.data();
+			st.hagg_id = d_haggId.data(); st.ell_loc = d_ellLoc.data(); st.own_loc = d_ownLoc.data();
+			const size_t Ncs = (size_t)6 * sys.cl * nc;
+			d_w2.resize((size_t)6 * Pf); d_s0.resize((size_t)6 * Pf); d_s1.resize((size_t)6 * Pf); d_cw.resize(2 * Ncs); d_cs.resize(2 * Ncs); d_alpha.resize(2);
+			d_cw.zero(stream); d_cs.zero(stream); d_alpha.zero(stream); d_s0.zero(stream); d_s1.zero(stream); d_w2.zero(stream);
+			sys.w2 = d_w2.data(); sys.s0 = d_s0.data(); sys.s1 = d_s1.data(); sys.cw = d_cw.data(); sys.cs = d_cs.data(); sys.alpha = d_alpha.data();
+			sys.cg1 = pcg1_supported(g, st, sys) ? 1 : 0;
+			if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] single-kernel PCG iteration: %s (halo <= %d poses, %d aggregates)\n", sys.cg1 ? "on" : "off", st.hmax, st.jmax);
+		}
 		haveStructure = true;
 	}
 	bool hostPatternValid = false;     // h_rowptr / h_colind describe the current structure (the device-built one downloads them on demand)
@@ -1619,6 +1662,12 @@ struct cuba_hip_solver
 				coarseFresh = refresh;
 			}
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
+			if (sys.cg1)
+			{
+				// single-kernel iterations start from u_0 (just computed), w_0 = A u_0 and their restricted vectors
+				launch_pcg_spmv(g, st, sys, 0, maxIter, tol2, stream);
+				launch_pcg1_init(g, sys, stream);
+			}
 		}
 		// first solve on this structure: the usual chunk lengths at once (0.5 ms), not one by one inside later runs
 		if (useGraph && pcgCheckEvery <= 0 && pcgGraphs.empty())
@@ -1892,7 +1941,12 @@ struct cuba_hip_solver
 		if (sys.agg > 0)
 		{
 			msOut[3] = timeit([&] { launch_pcg2_fused(g, sys, 0, 1, 1 << 30, -1.0, 1, stream); });
-			msOut[5] = 0;   // merged into [3] (update + restrict + two-level preconditioner in one kernel)
+			msOut[5] = 0;   // the single-kernel iteration, where it is in use
+			if (sys.cg1)
+			{
+				launch_pcg1_init(g, sys, stream);
+				msOut[5] = timeit([&] { launch_pcg1(g, st, sys, 0, 1 << 30, -1.0, stream); });
+			}
 			msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream); });
 		}
 		else
@@ -2039,9 +2093,15 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
+		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "coarse_overlap_period") s->coarseOverlapPeriod = (int)value;
+		else if (k == "coarse_cu_mask")
+		{
+			if (s->gjStream) throw StateError{ "coarse_cu_mask must be set before the first solve" };
+			s->coarseCuMask = (int)value;
+		}
 		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }
