@@ -2998,23 +2998,35 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 	const Scalar* cSin = sys.cs + (pk ? 0 : Nc);   Scalar* cSout = sys.cs + (pk ? Nc : 0);     // P^T s_{k-1} in, P^T s_k out
 	const int r0 = I * sys.agg, r1 = min(g.Pf, r0 + sys.agg), nOwn = r1 - r0;
 	const int W20 = 20 * st.ell_m;
+	TRACE_DECL
+	TRACE_MARK();
 
 	// ---- loads: flags, reduction partials, index arrays ------------------------------------------------------------------
 	const int kb_v = vector_load_flag(sys.kbase);
 	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
-	Scalar e_k = 0, e_m = 0, e_0 = 0, e_d = 0;
-	if (t < sys.nc) { e_k = rz_slot(sys, k)[t]; e_m = rz_slot(sys, k - 1)[t]; e_0 = sys.rz[t]; e_d = pq_slot(sys, k)[t]; }
+	// (every wave adds up all nc partials of the four sums itself: no LDS exchange, no barrier before alpha and beta are known)
+	Scalar e_k[2], e_m[2], e_0[2], e_d[2];
+#pragma unroll
+	for (int q = 0; q < 2; q++)
+	{
+		const int u = lane + 64 * q;
+		const bool in = u < sys.nc;
+		e_k[q] = in ? rz_slot(sys, k)[u] : Scalar(0); e_m[q] = in ? rz_slot(sys, k - 1)[u] : Scalar(0);
+		e_0[q] = in ? sys.rz[u] : Scalar(0); e_d[q] = in ? pq_slot(sys, k)[u] : Scalar(0);
+	}
 	int zero; asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 	const Scalar a_prev_v = sys.alpha[1 - pk + zero];
-	const int nH = st.hal_n[I], nJ = st.hal_nj[I];
+	const int nJ = st.hal_nj[I];
 	// halo vectors: thread x = (halo pose, component), two trips cover 170 poses
 	int hp[2]; Scalar hr[2] = { 0, 0 }, hw[2] = { 0, 0 }, hs[2] = { 0, 0 }, hm[2][6]; int hal[2] = { 0, 0 };
 #pragma unroll
 	for (int q = 0; q < 2; q++)
 	{
+		// (the lists are padded with -1 up to hmax / jmax: no load waits for the list lengths)
 		const int x = t + q * PCG1_T;
-		hp[q] = x < 6 * nH ? st.hal_pose[(size_t)I * st.hmax + x / 6] : -1;
-		if (hp[q] >= 0) hal[q] = st.hal_aloc[(size_t)I * st.hmax + x / 6];
+		const bool in = x < 6 * st.hmax;
+		hp[q] = in ? st.hal_pose[(size_t)I * st.hmax + x / 6] : -1;
+		hal[q] = in ? st.hal_aloc[(size_t)I * st.hmax + x / 6] : 0;
 	}
 	// coarse vectors: thread pairs (2 t, 2 t + 1), three trips cover a coarse dimension of 3072
 	Scalar2 vR[3], vW[3], vS[3];
@@ -3054,7 +3066,8 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 	for (int q = 0; q < RB; q++)
 	{
 		const int ri = wv + 8 * q;
-		rowOf[q] = ri < nRows ? CD * st.hagg_id[(size_t)I * st.jmax + ri / CD] + ri % CD : -1;
+		const int J = ri < st.jmax * CD ? st.hagg_id[(size_t)I * st.jmax + ri / CD] : -1;
+		rowOf[q] = J >= 0 ? CD * J + ri % CD : -1;
 	}
 #pragma unroll
 	for (int q = 0; q < RB; q++)
@@ -3063,15 +3076,12 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 #pragma unroll
 		for (int m = 0; m < NQ; m++) ainv[q][m] = rowOf[q] >= 0 ? *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * m, ld - W)) : AV(0);
 	}
+	TRACE_MARK();
 
 	// ---- scalars ---------------------------------------------------------------------------------------------------------------
-	for (int u = t + PCG1_T; u < sys.nc; u += PCG1_T) { e_k += rz_slot(sys, k)[u]; e_m += rz_slot(sys, k - 1)[u]; e_0 += sys.rz[u]; e_d += pq_slot(sys, k)[u]; }
-	e_k = wave_sum(e_k); e_m = wave_sum(e_m); e_0 = wave_sum(e_0); e_d = wave_sum(e_d);
-	if (lane == 0) { red[wv] = e_k; red[8 + wv] = e_m; red[16 + wv] = e_0; red[24 + wv] = e_d; }
-	__syncthreads();
-	Scalar gk = 0, gm = 0, g0 = 0, dk = 0;
-#pragma unroll
-	for (int w = 0; w < PCG1_T / 64; w++) { gk += red[w]; gm += red[8 + w]; g0 += red[16 + w]; dk += red[24 + w]; }
+	Scalar a_k = e_k[0] + e_k[1], a_m = e_m[0] + e_m[1], a_0 = e_0[0] + e_0[1], a_d = e_d[0] + e_d[1];
+	for (int u = lane + 128; u < sys.nc; u += 64) { a_k += rz_slot(sys, k)[u]; a_m += rz_slot(sys, k - 1)[u]; a_0 += sys.rz[u]; a_d += pq_slot(sys, k)[u]; }
+	const Scalar gk = to_uniform(wave_sum(a_k)), gm = to_uniform(wave_sum(a_m)), g0 = to_uniform(wave_sum(a_0)), dk = to_uniform(wave_sum(a_d));
 	const int kabs = k + __builtin_amdgcn_readfirstlane(kb_v);
 	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
 	if (!(kabs < maxIter && failed == 0 && gk > tol2 * g0 && gk == gk))          // uniform over the grid
@@ -3107,6 +3117,7 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 	}
 	if (t < NcP - Nc) sC[Nc + t] = 0;
 	__syncthreads();
+	TRACE_MARK();
 
 	// ---- coarse correction of the halo aggregates: yc = Ac^-1[rows] (P^T r_{k+1}) -----------------------------------------------------
 	for (int b = 0; 8 * RB * b < nRows; b++)
@@ -3117,7 +3128,8 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 			for (int q = 0; q < RB; q++)
 			{
 				const int ri = wv + 8 * (RB * b + q);
-				rowOf[q] = ri < nRows ? CD * st.hagg_id[(size_t)I * st.jmax + ri / CD] + ri % CD : -1;
+				const int J = ri < nRows ? st.hagg_id[(size_t)I * st.jmax + ri / CD] : -1;
+				rowOf[q] = J >= 0 ? CD * J + ri % CD : -1;
 			}
 #pragma unroll
 			for (int q = 0; q < RB; q++)
@@ -3149,6 +3161,24 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 		}
 	}
 
+	TRACE_MARK();
+	// ---- matrix entries of the first SpMV round: requested now, needed after the two halo phases ------------------------------------------
+	const int slot = lane / 3, r2 = lane - 3 * slot;
+	Scalar2 aNext[3][6];
+	int locNext[3] = { -1, -1, -1 };
+	auto loadRound = [&](int row) {
+#pragma unroll
+		for (int m = 0; m < 3; m++)
+		{
+			const bool in = lane < 60 && m < st.ell_m;
+			locNext[m] = in ? st.ell_loc[(size_t)row * W20 + m * 20 + slot] : -1;
+			const Scalar2* A2 = reinterpret_cast<const Scalar2*>(sys.hrow + 36 * ((size_t)row * W20 + (in ? m * 20 + slot : 0)) + 12 * r2);
+#pragma unroll
+			for (int c = 0; c < 6; c++) aNext[m][c] = in ? A2[c] : Scalar2{ 0, 0 };
+		}
+	};
+	if (wv < nOwn) loadRound(r0 + wv);
+
 	// ---- halo: s_k, r_{k+1} ----------------------------------------------------------------------------------------------------------
 #pragma unroll
 	for (int q = 0; q < 2; q++)
@@ -3178,29 +3208,26 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 		}
 	}
 	__syncthreads();
+	TRACE_MARK();
 
 	// ---- w_{k+1} = A u_{k+1} on the own rows: wave = block row, lane = (slot, pair of block rows) --------------------------------------
+	// (the matrix entries of a round -- one row per wave -- were requested a round ahead: padding slots of the row-ordered copy hold
+	// zeros, so the loads need no index and no mask)
 	{
-		const int slot = lane / 3, r2 = lane - 3 * slot;
 		for (int il = wv; il < nOwn; il += PCG1_T / 64)
 		{
 			const int row = r0 + il;
 			Scalar az0 = 0, az1 = 0;
-			int loc[3];
-#pragma unroll
-			for (int m = 0; m < 3; m++) loc[m] = (lane < 60 && m < st.ell_m) ? st.ell_loc[(size_t)row * W20 + m * 20 + slot] : -1;
 			Scalar2 a0v[3][3], a1v[3][3];
+			int loc[3];
 #pragma unroll
 			for (int m = 0; m < 3; m++)
 			{
-				const Scalar2* A2 = reinterpret_cast<const Scalar2*>(sys.hrow + 36 * ((size_t)row * W20 + m * 20 + slot) + 12 * r2);
+				loc[m] = locNext[m];
 #pragma unroll
-				for (int c = 0; c < 3; c++)
-				{
-					a0v[m][c] = loc[m] >= 0 ? A2[c] : Scalar2{ 0, 0 };
-					a1v[m][c] = loc[m] >= 0 ? A2[3 + c] : Scalar2{ 0, 0 };
-				}
+				for (int c = 0; c < 3; c++) { a0v[m][c] = aNext[m][c]; a1v[m][c] = aNext[m][3 + c]; }
 			}
+			if (il + PCG1_T / 64 < nOwn) loadRound(row + PCG1_T / 64);       // next round's entries fly while this round is summed
 #pragma unroll
 			for (int m = 0; m < 3; m++)
 			{
@@ -3232,6 +3259,7 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 		}
 	}
 	__syncthreads();
+	TRACE_MARK();
 
 	// ---- own rows: p_k, x_{k+1}, u_{k+1}; gamma_{k+1}, delta_{k+1}; P^T w_{k+1} ---------------------------------------------------------
 	Scalar dg = 0, dd = 0;
@@ -3267,6 +3295,8 @@ __global__ __launch_bounds__(PCG1_T) void pcg1_kernel(DeviceGraph g, DeviceStruc
 		pq_slot(sys, k + 1)[I] = sd;
 		if (I == 0) { sys.alpha[pk] = alpha; *sys.iters = kabs + 1; }
 	}
+	TRACE_MARK();
+	TRACE_FLUSH(1, blockIdx.x * (PCG1_T / 64) + wv);
 }
 
 // per-solve start of the single-kernel iteration, after pcg_setup (r_0, blockdiag^-1, x = p = 0), the fused kernel with doUpdate = 0

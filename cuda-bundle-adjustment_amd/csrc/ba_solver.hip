@@ -168,7 +168,11 @@ struct cuba_hip_solver
 	// single-kernel PCG iteration: halo lists of the aggregates + its vectors
 	DevBuf<int> d_halN, d_halNJ, d_halPose, d_halAloc, d_haggId, d_ellLoc, d_ownLoc;
 	DevBuf<Scalar> d_w2, d_s0, d_s1, d_cw, d_cs, d_alpha;
-	int pcgSingleKernel = 1;     // option "pcg_single_kernel": 1 = one launch per PCG iteration where the configuration allows it
+	// option "pcg_single_kernel": 1 = one launch per PCG iteration where the configuration allows it.  Built and measured in round 3
+	// (profiles/r03t_trace_pcg1_kitti00.txt): 21 us per iteration at KITTI-00 against 13 + 2 x 1.45 for the two-kernel iteration -- each of
+	// the 84 workgroups pulls 4-6 x the coarse-inverse rows of the fused kernel through its one CU (4.7 us until the loads land) and
+	// redoes residual and preconditioner on a ~50-pose halo -- so it stays OFF by default; iteration counts are identical.
+	int pcgSingleKernel = 0;
 	bool localRanges = false;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -1046,6 +1050,7 @@ struct cuba_hip_solver
 		sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 		d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
+		d_hrow.zero(stream);         // (padding slots are never written: the single-kernel iteration reads them unmasked)
 		sys.spmv_rows = spmvRows;
 		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
@@ -1063,6 +1068,9 @@ struct cuba_hip_solver
 			st.hmax = mx[0]; st.jmax = mx[1];
 			d_halPose.resize((size_t)nc * st.hmax); d_halAloc.resize((size_t)nc * st.hmax); d_haggId.resize((size_t)nc * st.jmax);
 			d_ellLoc.resize((size_t)Pf * ellM * 20); d_ownLoc.resize(Pf);
+			HIP_TRY(hipMemsetAsync(d_halPose.data(), 0xff, sizeof(int) * d_halPose.size(), stream));     // -1 padding: the iteration kernel loads the
+			HIP_TRY(hipMemsetAsync(d_haggId.data(), 0xff, sizeof(int) * d_haggId.size(), stream));       // lists at their full width
+			HIP_TRY(hipMemsetAsync(d_halAloc.data(), 0, sizeof(int) * d_halAloc.size(), stream));
 			topo::launch_halo_fill(d_ell.data(), Pf, ellM, agg, nc, st.hmax, st.jmax, d_halPose.data(), d_halAloc.data(), d_haggId.data(), d_ellLoc.data(), d_ownLoc.data(), stream);
 			st.hal_n = d_halN.data(); st.hal_nj = d_halNJ.data(); st.hal_pose = d_halPose.data(); st.hal_aloc = d_halAloc.data();
 			st.hagg_id = d_haggId.data(); st.ell_loc = d_ellLoc.data(); st.own_loc = d_ownLoc.data();

@@ -102,10 +102,11 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
    the device writes into mapped host memory, not from hipStreamSynchronize), "precond_fp32" (fp64 library only, default 1: the explicit coarse inverse of the two-level
    preconditioner is STORED in fp32 -- symmetrised, applied with fp64 accumulation; it only has to be a fixed SPD operator, so neither parity
-   nor bit-reproducibility change, while the bytes and load instructions of the kernel that applies it halve; 0 = fp64 storage), "pcg_single_kernel" (default 1: one launch per PCG iteration -- Chronopoulos-Gear recurrences, a workgroup
+   nor bit-reproducibility change, while the bytes and load instructions of the kernel that applies it halve; 0 = fp64 storage), "pcg_single_kernel" (default 0; 1 = one launch per PCG iteration -- Chronopoulos-Gear recurrences, a workgroup
    per coarse aggregate that recomputes residual and preconditioned residual on the aggregate's halo -- wherever the two-level preconditioner is on and
    the configuration fits the kernel (block rows within the fixed-width part, halo <= 170 poses, coarse dimension within the instantiated widths);
-   0 = the two-kernel iteration (SpMV, then update + restriction + preconditioner)), "fused_tail" (default 1: optimize() runs back-substitution, update and evaluation of a trial
+   measured slower than the two-kernel iteration (SpMV, then update + restriction + preconditioner) at every BASELINE shape: 21 vs 16 us at KITTI-00,
+   DESIGN.md section 4), "fused_tail" (default 1: optimize() runs back-substitution, update and evaluation of a trial
    as ONE pass over the edges -- two launches between a converged solve and the LM decision instead of four; 0 = the four-launch tail), "speculate_tail" (default 0; 1 = optimize()
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
    was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "schur_atomic"

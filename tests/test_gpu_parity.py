@@ -317,6 +317,32 @@ def test_coarse_inverse_storage_precision(solvers):
         assert np.array_equal(a2.optimize(6)["chi2"], ra), opts
 
 
+def test_single_kernel_pcg_iteration_agrees(solvers):
+    """Option pcg_single_kernel = 1 (round 3, off by default because it measured slower): one launch per PCG iteration --
+    Chronopoulos-Gear recurrences, one workgroup per coarse aggregate that redoes residual and preconditioner on the aggregate's halo.
+    Same preconditioner, same stop quantity: identical iteration counts, solutions equal to the solver tolerance, and the LM
+    trajectory follows the oracle; aggregates of 2 / 5 / 16 poses exercise several halo sizes and coarse-row batch counts."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
+    o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
+    lam = 1e-7 * o.max_diagonal()
+    o.set_lambda(lam); assert o.solve()
+    for agg in (16, 5, 2):
+        a = HipSolver(fp, RK_HUBER, pcg_aggregate=agg, pcg_tol=1e-9, pcg_single_kernel=1)
+        b = HipSolver(fp, RK_HUBER, pcg_aggregate=agg, pcg_tol=1e-9)
+        for h in (a, b):
+            h.set_lambda(lam); assert h.solve()
+            assert rel(h.array("xp"), o.array("xp")) < 1e-6 and rel(h.array("xl"), o.array("xl")) < 1e-6
+        ia, ib = a.pcg_history()[0][-1], b.pcg_history()[0][-1]
+        assert abs(int(ia) - int(ib)) <= 2, (agg, ia, ib)
+        assert rel(a.array("xp"), b.array("xp")) < 1e-7
+    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
+    h = HipSolver(fp, RK_HUBER, pcg_single_kernel=1)
+    got = h.optimize(6)["chi2"]
+    assert rel(got, ref) < CHI2_TOL and h.pcg_history()[1] == 0
+    assert np.array_equal(HipSolver(fp, RK_HUBER, pcg_single_kernel=1).optimize(6)["chi2"], got)
+
+
 def test_coarse_refresh_modes(solvers):
     """The coarse inverse of trial k is built on a second stream for a later trial (default: under every trial for a coarse dimension
     up to 512, under every second up to 1024, every third beyond); coarse_overlap=0 inverts in line and reuses the inverse for up to coarse_max_age solves.
