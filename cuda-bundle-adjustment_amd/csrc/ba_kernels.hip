@@ -741,7 +741,7 @@ __device__ __forceinline__ void load_pose_as(const DeviceGraph& g, int ip, ET q[
 }
 
 // Workgroups beyond nLmGroups (optimize() only) copy the state into its backup: the push() of the LM loop rides in this launch.
-template <int MODE, typename ET>
+template <int MODE, typename ET, bool USEU = false>
 __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
 	unsigned nLmGroups, const Scalar* __restrict__ backupSrc, Scalar* __restrict__ backupDst, size_t backupCount)
 {
@@ -763,6 +763,8 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	const bool valid = e < e1;
 	int il = lm0, seg0 = 0, seg1 = 0;
 	Scalar h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	Scalar hplU[6][3];             // USEU: w' JP^T JL of this lane's edge
+	bool wantU = false;
 	if (valid)
 	{
 		const int pe = g.e_pose[e];
@@ -795,6 +797,14 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 			}
 			seg0 = g.lm_ptr[il] - e0;
 			seg1 = g.lm_ptr[il + 1] - e0;
+			if (USEU && MODE == 1 && ip < g.Pf)
+			{
+				wantU = true;
+#pragma unroll
+				for (int c = 0; c < 6; c++)
+#pragma unroll
+					for (int kk = 0; kk < 3; kk++) hplU[c][kk] = wr * (L.JP[0][c] * L.JL[0][kk] + L.JP[1][c] * L.JL[1][kk] + L.JP[2][c] * L.JL[2][kk]);
+			}
 		}
 	}
 #pragma unroll
@@ -802,6 +812,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	wave_lds_sync();
 	const bool head = valid && il < g.Lf && lane == seg0;
 	Scalar m = 0;
+	Scalar Cf[6] = { 0, 0, 0, 0, 0, 0 };
 	if (head)
 	{
 		Scalar H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -824,6 +835,35 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 			for (int k = 0; k < 6; k++) ls[k] = inv[k];
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
+			if (USEU)
+			{
+				// lower-triangular C with C C^T = inv(Hll + lambda I): c00 c10 c20 c11 c21 c22
+				Cf[0] = sqrt(inv[0]); Cf[1] = inv[1] / Cf[0]; Cf[2] = inv[2] / Cf[0];
+				Cf[3] = sqrt(inv[3] - Cf[1] * Cf[1]); Cf[4] = (inv[4] - Cf[2] * Cf[1]) / Cf[3];
+				Cf[5] = sqrt(inv[5] - Cf[2] * Cf[2] - Cf[4] * Cf[4]);
+			}
+		}
+	}
+	if (USEU && MODE == 1)
+	{
+		wave_lds_sync();                 // every segment sum has been read
+		if (head)
+#pragma unroll
+			for (int k = 0; k < 6; k++) lds[lane * 9 + k] = Cf[k];
+		wave_lds_sync();
+		if (wantU)
+		{
+			Scalar c[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) c[k] = lds[seg0 * 9 + k];
+			ET* u = reinterpret_cast<ET*>(st.e_u) + 18 * (size_t)e;
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+			{
+				u[3 * r + 0] = (ET)(hplU[r][0] * c[0] + hplU[r][1] * c[1] + hplU[r][2] * c[2]);
+				u[3 * r + 1] = (ET)(hplU[r][1] * c[3] + hplU[r][2] * c[4]);
+				u[3 * r + 2] = (ET)(hplU[r][2] * c[5]);
+			}
 		}
 	}
 	if (MODE == 0)
@@ -1074,10 +1114,86 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	}
 }
 
+// option "schur_u": T_ab = sum over the products of U_a U_b^T, two 144-byte (72 in mixed mode) gathers and 108 multiply-adds per
+// product, no pose data at all
+template <typename ET>
+__device__ __forceinline__ void block_pass_u_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
+{
+	typedef ET ET2 __attribute__((ext_vector_type(2)));
+	const int gl = threadIdx.x & (BP_GROUP - 1);
+	const int grp = (bid * 256 + threadIdx.x) / BP_GROUP;
+	const int blk0 = grp < st.nOd ? st.od_blocks[grp] : -1;
+	const bool on = blk0 >= 0;
+	const int blk = on ? blk0 : 0;
+	const int a = st.hsc_blkrow[blk], b = st.hsc_colind[blk];
+	Scalar T[6][6];
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+#pragma unroll
+		for (int c = 0; c < 6; c++) T[r][c] = 0;
+	const ET* ubase = reinterpret_cast<const ET*>(st.e_u);
+	const int p1 = on ? st.prod_end[blk] : 0;
+	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
+	{
+		const ET2* ua2 = reinterpret_cast<const ET2*>(ubase + 18 * (size_t)st.prod_ea[p]);
+		const ET2* ub2 = reinterpret_cast<const ET2*>(ubase + 18 * (size_t)st.prod_eb[p]);
+		ET2 va[9], vb[9];
+#pragma unroll
+		for (int i = 0; i < 9; i++) { va[i] = ua2[i]; vb[i] = ub2[i]; }
+		Scalar Ua[18], Ub[18];
+#pragma unroll
+		for (int i = 0; i < 9; i++) { Ua[2 * i] = (Scalar)va[i].x; Ua[2 * i + 1] = (Scalar)va[i].y; Ub[2 * i] = (Scalar)vb[i].x; Ub[2 * i + 1] = (Scalar)vb[i].y; }
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+#pragma unroll
+			for (int c = 0; c < 6; c++) T[r][c] += Ua[3 * r] * Ub[3 * c] + Ua[3 * r + 1] * Ub[3 * c + 1] + Ua[3 * r + 2] * Ub[3 * c + 2];
+	}
+	Scalar Ts[6][6];
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+		{
+			Scalar v = T[r][c];
+			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+			Ts[r][c] = v;
+		}
+	if (!on) return;
+	Scalar* dst = sys.hsc + 36 * (size_t)blk;
+	if (a != b)
+	{
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
+	}
+	else if (gl == 0)
+	{
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+#pragma unroll
+			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= Ts[r][c] + Ts[c][r];
+	}
+}
+
 template <typename ET>
 __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
 {
 	block_pass_body<ET>(g, st, sys, blockIdx.x);
+}
+
+template <typename ET>
+__global__ __launch_bounds__(256) void block_pass_u_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
+{
+	block_pass_u_body<ET>(g, st, sys, blockIdx.x);
+}
+
+template <typename ET>
+__global__ __launch_bounds__(256) void schur_pass_u_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
+{
+	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
+	else block_pass_u_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
 }
 
 // Pose pass and block pass in one launch: they write disjoint parts of the reduced system (diagonal blocks / bp / bsc vs the
@@ -1094,11 +1210,13 @@ template <typename ET>
 static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
 	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
 {
+	const bool useU = st.e_u && mode == 1 && st.nBig == 0 && st.nDiagProd == 0 && g.Pf > 0 && st.nOd > 0;      // (experiment: graphs without > 64-observation landmarks)
 	if (st.nWaves > 0)
 	{
 		const unsigned grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
 		const unsigned nCopy = backupSrc ? (unsigned)std::min<size_t>(512, (backupCount + LIN_BLOCK - 1) / LIN_BLOCK) : 0;
 		if (mode == 0) hipLaunchKernelGGL((lm_pass_kernel<0, ET>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
+		else if (useU) hipLaunchKernelGGL((lm_pass_kernel<1, ET, true>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
 		else hipLaunchKernelGGL((lm_pass_kernel<1, ET>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
 	}
 	else if (backupSrc && backupCount)
@@ -1109,6 +1227,18 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 	}
 	static const bool separate = std::getenv("CUBA_HIP_SEPARATE_SCHUR_PASSES") != nullptr;     // A/B knob
+	if (useU)
+	{
+		static const bool sepU = std::getenv("CUBA_HIP_SCHUR_U_SEPARATE") != nullptr;     // A/B: the light block pass as its own launch (own register budget)
+		const int np = (g.Pf + 3) / 4;
+		if (!sepU) hipLaunchKernelGGL((schur_pass_u_kernel<ET>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		else
+		{
+			hipLaunchKernelGGL((block_pass_u_kernel<ET>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+			hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3(np), dim3(256), 0, s, g, st, sys);
+		}
+		return;
+	}
 	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0 && !separate)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)
 	{
 		const int np = (g.Pf + 3) / 4;

@@ -82,6 +82,10 @@ struct DeviceStructure
 	int hmax = 0, jmax = 0;
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w', r[3], 2*landmark+stereo (integer bits)}
 	int mixed = 0;                     // fp64 library only: 1 = records and the per-edge arithmetic of the pose / block passes in fp32
+	// option "schur_u" (experiment, round 3): the landmark pass also stores U_e = w' JP^T JL C per edge (6 x 3, C C^T = inv(Hll + lambda I)),
+	// 144 bytes in fp64, and the block pass forms T_ab = sum U_a U_b^T from two 144-byte gathers per product instead of rebuilding
+	// both Jacobians from the 64-byte records (the reference's Hpl * Hll^-1 layout, cuda_block_solver.cu:933-977, without its atomics)
+	Scalar* e_u = nullptr;
 };
 
 int spmv_rows_for(int Pf);      // block rows per SpMV workgroup (two waves each): 2, or 4 for large graphs

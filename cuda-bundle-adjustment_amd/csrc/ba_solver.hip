@@ -174,7 +174,8 @@ struct cuba_hip_solver
 	// redoes residual and preconditioner on a ~50-pose halo -- so it stays OFF by default; iteration counts are identical.
 	int pcgSingleKernel = 0;
 	bool localRanges = false;
-	DevBuf<Scalar> d_erec;
+	DevBuf<Scalar> d_erec, d_eu;
+	bool schurU = false;         // option "schur_u" (experiment): per-edge U blocks for the block pass
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
 	DevBuf<Scalar> d_cbWi, d_cbWj;
 	std::vector<int> h_rowptr, h_colind;
@@ -1034,6 +1035,7 @@ struct cuba_hip_solver
 		st.prod_beg = localRanges ? d_prodBeg.data() : d_prodPtr.data(); st.prod_end = localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1;
 		st.pe_beg = localRanges ? d_peBeg.data() : d_pePtr.data(); st.pe_end = localRanges ? d_peEnd.data() : d_pePtr.data() + 1;
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
+		if (schurU) { d_eu.resize((size_t)18 * E); d_eu.zero(stream); st.e_u = d_eu.data(); }
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
@@ -2101,6 +2103,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
+		else if (k == "schur_u") { s->schurU = value != 0; s->haveStructure = false; }
 		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
