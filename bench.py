@@ -500,11 +500,35 @@ def partition_leg(args, dist, backend, rank, world, device_index, rk):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     c = d.counters()
+    # where a trial's time goes on this rank (one more run with the per-stage synchronising profile of the solver handle): the
+    # replicated reduced solve is the Amdahl term of this mode, what no bucket covers is collectives + host turnaround
+    share = None
+    try:
+        h.set_option("profile", 1.0)
+        p0 = h.profile()
+        h.restore_state()
+        dist.barrier(); torch.cuda.synchronize()
+        tp = time.perf_counter()
+        d.optimize(LM_RUN)
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        prof = {k: v - p0[k] for k, v in h.profile().items()}
+        h.set_option("profile", 0.0)
+        solve_s = prof["6: Numerical Decomposition"]
+        local_s = prof["2: Compute Error"] + prof["3: Build System"] + prof["4: Schur Complement"] + prof["7: Update Solution"]
+        f = solve_s / tp
+        share = {"profiled_run_ms": tp * 1e3, "replicated_reduced_solve": f, "partitioned_edge_and_landmark_work": local_s / tp,
+                 "collectives_and_host": max(0.0, 1.0 - (solve_s + local_s) / tp),
+                 "amdahl_ceiling_at_this_share": 1.0 / f if f > 0 else None,
+                 "note": "shares of one profiled 10-iteration run on rank 0 (every stage synchronises, so the run is slower than the timed ones); "
+                         "the reduced solve is replicated on every rank: speed-up over one GPU <= 1 / its single-GPU share (~0.68 at KITTI-00, ~0.66 at G4M -> <= 1.5x)"}
+    except Exception as e:   # noqa: BLE001
+        share = {"error": repr(e)[:200]}
     res = {"workload": f"ONE ba_{args.shape}-shaped graph, landmark-partitioned over {world} ranks (native driver, "
                        f"{'RCCL' if backend == 'nccl' else backend} all-reduce of [Hsc|bsc|bp] per trial), {LM_RUN}-iteration LM runs",
            "scaling": "strong", "wall_ms_10iter": dt * 1e3 / runs, "value": fp.E * LM_RUN * runs / dt, "unit": "edges/s",
            "final_chi2": float(chi2[-1]), "iterations_done": int(len(chi2)),
-           "allreduce_elements_per_trial": c["large_elements"] // max(c["large_allreduces"], 1)}
+           "allreduce_elements_per_trial": c["large_elements"] // max(c["large_allreduces"], 1), "time_shares": share}
     d.close(); h.close()
     return res
 

@@ -70,6 +70,7 @@ private:
 			std::function<void(int)> job;
 			// parallel regions come in bursts (initialize() + set_graph run five in a row): a worker that has just finished one spins
 			// for a moment before it goes back to sleep, so that the next region of the burst does not pay a futex wake-up per thread
+#ifndef CUBA_HIP_POOL_NO_SPIN
 			if (seen != 0)
 			{
 				const auto t0 = std::chrono::steady_clock::now();
@@ -81,6 +82,7 @@ private:
 #endif
 				}
 			}
+#endif
 			{
 				std::unique_lock<std::mutex> lk(m_);
 				start_.wait(lk, [&] { return stop_ || generation_ != seen; });
