@@ -1025,7 +1025,93 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 	pose_pass_body<MODE, ET>(g, st, sys, blockIdx.x);
 }
 
+// The same block in camera-frame form (default).  With D_e = d(projection)/d(Xc) (3x3, five non-zeros) the Jacobians of an edge are
+// JL_e = D_e R_e and JP_e = D_e G_e, G_e = [-[Xc_e]x | I], so a product is
+//     T_ab = G_a^T [ M_a inv M_b^T ] G_b,    M_e = w_e D_e^T D_e R_e    (K_e = w_e D_e^T D_e is symmetric with K01 = 0)
+// and the two outer factors are cross products with Xc_a / Xc_b: about 200 multiply-adds per product instead of 330, and neither
+// the 3x6 nor the 3x3 Jacobians are ever held in registers (the Jacobian form sits at the 256-register cliff).
 template <typename ET>
+struct ProductOperand { ET X[3]; ET M[3][3]; };
+
+
+// the same in two steps, for the software-pipelined loop: the raw loads of a product (issued one trip ahead) ...
+template <typename ET>
+struct ProductRaw { ET a[4], b[4], ta, tb; Scalar inv[6]; };
+
+template <typename ET>
+__device__ __forceinline__ void product_load(const DeviceStructure& st, const DeviceSystem& sys, int ea, int eb, int lm, ProductRaw<ET>& r)
+{
+	const ET* ra = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)ea;
+	const ET* rb = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)eb;
+	const Scalar* ls = sys.lm_sys + 9 * (size_t)lm;
+#pragma unroll
+	for (int k = 0; k < 4; k++) { r.a[k] = ra[k]; r.b[k] = rb[k]; }
+	r.ta = ra[7]; r.tb = rb[7];
+#pragma unroll
+	for (int k = 0; k < 6; k++) r.inv[k] = ls[k];
+}
+
+// ... and the operand built from them
+template <typename ET>
+__device__ __forceinline__ void product_operand_raw(const ET rec[4], ET tag, const Rot3T<ET>& R, const ET cam[5], ProductOperand<ET>& o)
+{
+	const ET X = rec[0], Y = rec[1], Z = rec[2], w = rec[3];
+	const bool stereo = (tag_decode(tag) & 1) != 0;
+	o.X[0] = X; o.X[1] = Y; o.X[2] = Z;
+	const ET invZ = 1 / Z, invZZ = invZ * invZ;
+	const ET d00 = -cam[0] * invZ, d02 = cam[0] * X * invZZ, d11 = -cam[1] * invZ, d12 = cam[1] * Y * invZZ;
+	const ET d22 = stereo ? d02 - cam[4] * invZZ : ET(0);      // third row of D: (d00, 0, d22) for stereo edges, zero otherwise
+	const ET k00 = w * (stereo ? 2 * d00 * d00 : d00 * d00), k02 = w * (d00 * d02 + (stereo ? d00 * d22 : ET(0)));
+	const ET k11 = w * d11 * d11, k12 = w * d11 * d12, k22 = w * (d02 * d02 + d12 * d12 + d22 * d22);
+#pragma unroll
+	for (int j = 0; j < 3; j++)
+	{
+		o.M[0][j] = k00 * R.m[0][j] + k02 * R.m[2][j];
+		o.M[1][j] = k11 * R.m[1][j] + k12 * R.m[2][j];
+		o.M[2][j] = k02 * R.m[0][j] + k12 * R.m[1][j] + k22 * R.m[2][j];
+	}
+}
+
+template <typename ET>
+__device__ __forceinline__ void product_operand(const Scalar* base, size_t e, const Rot3T<ET>& R, const ET cam[5], ProductOperand<ET>& o)
+{
+	const ET* rec = reinterpret_cast<const ET*>(base) + REC * e;
+	const ET r4[4] = { rec[0], rec[1], rec[2], rec[3] };
+	product_operand_raw<ET>(r4, rec[7], R, cam, o);
+}
+
+template <typename ET>
+__device__ __forceinline__ void product_accumulate(const ProductOperand<ET>& A, const ProductOperand<ET>& B, const ET inv[6], ET (&T)[6][6])
+{
+	// N = M_a inv M_b^T
+	ET P[3][3], W[3][6];
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int k = 0; k < 3; k++)
+			P[i][k] = A.M[i][0] * inv[sym3_idx(0, k)] + A.M[i][1] * inv[sym3_idx(1, k)] + A.M[i][2] * inv[sym3_idx(2, k)];
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+	{
+#pragma unroll
+		for (int j = 0; j < 3; j++) W[i][3 + j] = P[i][0] * B.M[j][0] + P[i][1] * B.M[j][1] + P[i][2] * B.M[j][2];
+		// N_i (-[Xb]x) = Xb x N_i
+		W[i][0] = B.X[1] * W[i][5] - B.X[2] * W[i][4];
+		W[i][1] = B.X[2] * W[i][3] - B.X[0] * W[i][5];
+		W[i][2] = B.X[0] * W[i][4] - B.X[1] * W[i][3];
+	}
+	// T += [ [Xa]x ; I ] W
+#pragma unroll
+	for (int c = 0; c < 6; c++)
+	{
+		T[0][c] += A.X[1] * W[2][c] - A.X[2] * W[1][c];
+		T[1][c] += A.X[2] * W[0][c] - A.X[0] * W[2][c];
+		T[2][c] += A.X[0] * W[1][c] - A.X[1] * W[0][c];
+		T[3][c] += W[0][c]; T[4][c] += W[1][c]; T[5][c] += W[2][c];
+	}
+}
+
+template <typename ET, int FORM = 1>
 __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
 {
 	const int gl = threadIdx.x & (BP_GROUP - 1);
@@ -1049,6 +1135,93 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	// prefetching the next product's index triple, or touching its cache lines one trip ahead, costs 6-14 spilled registers and
 	// 20-50 us: profiles/r03j_block_order.txt, r03k_block_touch.txt.)
 	const int p1 = on ? st.prod_end[blk] : 0;
+	if (FORM == 3)          // TIMING EXPERIMENT: coalesced addresses instead of the gathers (wrong results)
+	{
+		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
+		{
+			const Scalar* ls = sys.lm_sys + 9 * (size_t)(p % g.Lf);
+			ET inv[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
+			ProductOperand<ET> A, B;
+			product_operand<ET>(st.e_rec, (size_t)(p % g.E), Ra, cama, A);
+			product_operand<ET>(st.e_rec, (size_t)((p + 7) % g.E), Rb, camb, B);
+			product_accumulate<ET>(A, B, inv, T);
+		}
+	}
+	else if (FORM == 4)     // TIMING EXPERIMENT: the gathers, no arithmetic (wrong results)
+	{
+		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
+		{
+			const Scalar* ls = sys.lm_sys + 9 * (size_t)st.prod_lm[p];
+			const ET* ra = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_ea[p];
+			const ET* rb = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_eb[p];
+			ET acc = 0;
+#pragma unroll
+			for (int k = 0; k < 6; k++) acc += (ET)ls[k];
+#pragma unroll
+			for (int k = 0; k < 4; k++) acc += ra[k] + rb[k];
+			T[0][0] += acc + ra[7] + rb[7];
+		}
+	}
+	else if (FORM >= 6)     // TIMING EXPERIMENTS: subsets of the gathers, no arithmetic (wrong results)
+	{
+		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
+		{
+			typedef ET ET2 __attribute__((ext_vector_type(2)));
+			const ET2* ra = reinterpret_cast<const ET2*>(reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_ea[p]);
+			ET acc = 0;
+			if (FORM == 6) { const ET2 v = ra[0]; acc = v.x + v.y; }                                     // one 16-byte lane request
+			if (FORM == 7) { const ET2 v = ra[0], w = ra[1]; acc = v.x + v.y + w.x + w.y; }              // two requests, one line
+			if (FORM == 8) { const ET2 v = ra[0], w = ra[1], x = ra[2], y = ra[3]; acc = v.x + v.y + w.x + w.y + x.x + x.y + y.x + y.y; }   // four requests, one line
+			if (FORM == 9)                                                                              // two requests, two lines
+			{
+				const ET2* rb = reinterpret_cast<const ET2*>(reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_eb[p]);
+				const ET2 v = ra[0], w = rb[0]; acc = v.x + v.y + w.x + w.y;
+			}
+			if (FORM == 10) { acc = (ET)(st.prod_ea[p] + st.prod_eb[p] + st.prod_lm[p]); }               // the index loads alone
+			T[0][0] += acc;
+		}
+	}
+	else if (FORM == 1)
+	{
+		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
+		{
+			const Scalar* ls = sys.lm_sys + 9 * (size_t)st.prod_lm[p];
+			ET inv[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
+			ProductOperand<ET> A, B;
+			product_operand<ET>(st.e_rec, (size_t)st.prod_ea[p], Ra, cama, A);
+			product_operand<ET>(st.e_rec, (size_t)st.prod_eb[p], Rb, camb, B);
+			product_accumulate<ET>(A, B, inv, T);
+		}
+	}
+	else if (FORM == 2)
+	{
+		// software pipeline: index triple two trips ahead, raw records one trip ahead
+		int p = (on ? st.prod_beg[blk] : 0) + gl;
+		bool h0 = p < p1, h1 = p + BP_GROUP < p1;
+		ProductRaw<ET> cur, nxt;
+		int ea1 = 0, eb1 = 0, lm1 = 0;
+		if (h0) product_load<ET>(st, sys, st.prod_ea[p], st.prod_eb[p], st.prod_lm[p], cur);
+		if (h1) { ea1 = st.prod_ea[p + BP_GROUP]; eb1 = st.prod_eb[p + BP_GROUP]; lm1 = st.prod_lm[p + BP_GROUP]; }
+		while (h0)
+		{
+			const bool h2 = p + 2 * BP_GROUP < p1;
+			if (h1) product_load<ET>(st, sys, ea1, eb1, lm1, nxt);
+			if (h2) { ea1 = st.prod_ea[p + 2 * BP_GROUP]; eb1 = st.prod_eb[p + 2 * BP_GROUP]; lm1 = st.prod_lm[p + 2 * BP_GROUP]; }
+			ET inv[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) inv[k] = (ET)cur.inv[k];
+			ProductOperand<ET> A, B;
+			product_operand_raw<ET>(cur.a, cur.ta, Ra, cama, A);
+			product_operand_raw<ET>(cur.b, cur.tb, Rb, camb, B);
+			product_accumulate<ET>(A, B, inv, T);
+			cur = nxt; h0 = h1; h1 = h2; p += BP_GROUP;
+		}
+	}
+	else
 	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
 	{
 		EdgeLinT<ET> La, Lb; ET wa, wb, Xa[3], Xb[3]; int il, il2;
@@ -1177,10 +1350,10 @@ __device__ __forceinline__ void block_pass_u_body(const DeviceGraph& g, const De
 	}
 }
 
-template <typename ET>
+template <typename ET, int FORM = 1>
 __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
 {
-	block_pass_body<ET>(g, st, sys, blockIdx.x);
+	block_pass_body<ET, FORM>(g, st, sys, blockIdx.x);
 }
 
 template <typename ET>
@@ -1199,11 +1372,11 @@ __global__ __launch_bounds__(256) void schur_pass_u_kernel(DeviceGraph g, Device
 // Pose pass and block pass in one launch: they write disjoint parts of the reduced system (diagonal blocks / bp / bsc vs the
 // off-diagonal blocks) from the same records.  The pose workgroups come first (a wave walks a pose's ~420 edges in 7 trips:
 // 33 us of latency when launched alone) and run under the ALU-bound block workgroups.
-template <typename ET>
+template <typename ET, int FORM = 1>
 __global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
 {
 	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
-	else block_pass_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
+	else block_pass_body<ET, FORM>(g, st, sys, blockIdx.x - nPoseGroups);
 }
 
 template <typename ET>
@@ -1227,6 +1400,9 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 	}
 	static const bool separate = std::getenv("CUBA_HIP_SEPARATE_SCHUR_PASSES") != nullptr;     // A/B knob
+	static const bool jacForm = std::getenv("CUBA_HIP_BLOCK_PASS_JACOBIANS") != nullptr;        // A/B knob: the block pass of rounds 1-2
+	static const bool pipeForm = std::getenv("CUBA_HIP_BLOCK_PASS_PIPELINED") != nullptr;       // A/B knob: camera-frame form with loads one trip ahead
+	static const int expForm = std::getenv("CUBA_HIP_BLOCK_PASS_EXPERIMENT") ? std::atoi(std::getenv("CUBA_HIP_BLOCK_PASS_EXPERIMENT")) : 0;   // timing experiments (wrong results)
 	if (useU)
 	{
 		static const bool sepU = std::getenv("CUBA_HIP_SCHUR_U_SEPARATE") != nullptr;     // A/B: the light block pass as its own launch (own register budget)
@@ -1242,7 +1418,12 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0 && !separate)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)
 	{
 		const int np = (g.Pf + 3) / 4;
-		hipLaunchKernelGGL((schur_pass_kernel<ET>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		if (jacForm) hipLaunchKernelGGL((schur_pass_kernel<ET, 0>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		else if (pipeForm) hipLaunchKernelGGL((schur_pass_kernel<ET, 2>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		else if (expForm == 3) hipLaunchKernelGGL((schur_pass_kernel<ET, 3>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		else if (expForm == 4) hipLaunchKernelGGL((schur_pass_kernel<ET, 4>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		else if (expForm == 5) hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3(np), dim3(256), 0, s, g, st, sys);
+		else hipLaunchKernelGGL((schur_pass_kernel<ET, 1>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
 		return;
 	}
 	if (g.Pf > 0)
@@ -1251,7 +1432,18 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
 	}
 	if (mode == 1 && st.nOd > 0)
-		hipLaunchKernelGGL((block_pass_kernel<ET>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+	{
+		if (jacForm) hipLaunchKernelGGL((block_pass_kernel<ET, 0>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (pipeForm) hipLaunchKernelGGL((block_pass_kernel<ET, 2>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 3) hipLaunchKernelGGL((block_pass_kernel<ET, 3>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 4) hipLaunchKernelGGL((block_pass_kernel<ET, 4>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 6) hipLaunchKernelGGL((block_pass_kernel<ET, 6>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 7) hipLaunchKernelGGL((block_pass_kernel<ET, 7>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 8) hipLaunchKernelGGL((block_pass_kernel<ET, 8>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 9) hipLaunchKernelGGL((block_pass_kernel<ET, 9>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else if (expForm == 10) hipLaunchKernelGGL((block_pass_kernel<ET, 10>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+		else hipLaunchKernelGGL((block_pass_kernel<ET, 1>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
+	}
 }
 
 void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
