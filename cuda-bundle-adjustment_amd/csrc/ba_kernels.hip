@@ -690,45 +690,43 @@ void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const Dev
 
 // ===================================================================================================
 // Destination-major Schur assembly (default).  No atomics, no per-landmark pair loops:
-//   1. lm_pass_kernel     lane = edge, wave = landmarks: Hll/bl reduced in LDS, (Hll+lambda I)^-1, and a
-//                         64-byte linearisation record per edge {Xc, w', r, landmark/stereo tag};
-//   2. pose_pass_kernel   wave = free pose: every edge of the pose contributes Hpp_e - W_e Hpl_e^T, bp_e,
-//                         bp_e - Hpl_e Hll^-1 bl to registers, one wave reduction, plain stores;
-//   3. block_pass_kernel  16 lanes = one off-diagonal block (a,b): the products of all landmarks seen by
-//                         both poses, T = JP_a^T [w_a w_b JL_a Hll^-1 JL_b^T] JP_b, rebuilt from the two
-//                         records (no Hpl tile is ever stored), reduced over the 16 lanes, one plain store.
+//   1. lm_pass_kernel     lane = edge, wave = landmarks: Hll/bl reduced in LDS, (Hll+lambda I)^-1, and one 128-byte
+//                         linearisation record per edge {Xc, w' (sign = stereo), inv, inv bl, r}, scattered into POSE-major slots;
+//   2. pose_pass_kernel   wave = free pose: streams the pose's records (no gather), every edge contributes Hpp_e - W_e Hpl_e^T,
+//                         bp_e, bp_e - Hpl_e Hll^-1 bl to registers, one wave reduction, plain stores;
+//   3. block_pass_kernel  16 lanes (a whole wave for blocks with more than BP_HEAVY products) = one off-diagonal block (a,b):
+//                         the products of all landmarks seen by both poses, rebuilt from the two records in camera-frame form
+//                         (no Hpl tile is ever stored), reduced over the lanes, one plain store.
 // Every output has exactly one writer and a fixed summation order => results are reproducible bit for bit.
 // ===================================================================================================
-constexpr int REC = 8;   // numbers per edge record
+constexpr int REC = 16;   // numbers per edge record: [0..2] Xc, [3] w' (sign bit = stereo), [4..9] inv(Hll + lambda I), [10..12] inv bl, [13..15] r
 
 // Record element type ET = the arithmetic type of the pose / block passes: Scalar, or float for the mixed-precision mode
 // of the fp64 library (option "mixed_precision": records and per-edge Jacobian arithmetic in fp32, every accumulation that
 // crosses edges and the whole reduced system in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29, applied only
-// where it is safe).  The landmark / stereo tag travels as an integer bit pattern, exact for any landmark count.
-__device__ __forceinline__ double tag_encode(long long tag, double) { return __longlong_as_double(tag); }
-__device__ __forceinline__ float tag_encode(long long tag, float) { return __int_as_float((int)tag); }
-__device__ __forceinline__ long long tag_decode(double v) { return __double_as_longlong(v); }
-__device__ __forceinline__ long long tag_decode(float v) { return (long long)__float_as_int(v); }
+// where it is safe).
+__device__ __forceinline__ bool sign_flag(double v) { return __double_as_longlong(v) < 0; }
+__device__ __forceinline__ bool sign_flag(float v) { return __float_as_int(v) < 0; }
+__device__ __forceinline__ double abs_value(double v) { return __builtin_fabs(v); }
+__device__ __forceinline__ float abs_value(float v) { return __builtin_fabsf(v); }
 
+// first and last part of a record: what the lane's own edge gives
 template <typename ET>
-__device__ __forceinline__ void write_record(Scalar* base, size_t e, const Scalar Xc[3], Scalar wr, const Scalar r[3], int il, bool stereo)
+__device__ __forceinline__ void write_record_edge(Scalar* base, size_t slot, const Scalar Xc[3], Scalar wr, const Scalar r[3], bool stereo)
 {
-	ET* rec = reinterpret_cast<ET*>(base) + REC * e;
-	rec[0] = (ET)Xc[0]; rec[1] = (ET)Xc[1]; rec[2] = (ET)Xc[2]; rec[3] = (ET)wr;
-	rec[4] = (ET)r[0]; rec[5] = (ET)r[1]; rec[6] = (ET)r[2];
-	rec[7] = tag_encode(2 * (long long)il + (stereo ? 1 : 0), ET());
+	ET* rec = reinterpret_cast<ET*>(base) + REC * slot;
+	const ET w = (ET)wr;
+	rec[0] = (ET)Xc[0]; rec[1] = (ET)Xc[1]; rec[2] = (ET)Xc[2]; rec[3] = stereo ? -w : w;       // (-0.0 keeps the flag of a zero weight)
+	rec[13] = (ET)r[0]; rec[14] = (ET)r[1]; rec[15] = (ET)r[2];
 }
 
+// middle part: inv(Hll + lambda I) and inv bl of the edge's landmark (zeros for a fixed landmark)
 template <typename ET>
-__device__ __forceinline__ void rec_jacobians(const Scalar* base, size_t e, const Rot3T<ET>& R, const ET cam[5], EdgeLinT<ET>& L, ET& wr, int& il, ET Xc[3])
+__device__ __forceinline__ void write_record_landmark(Scalar* base, size_t slot, const Scalar v[9])
 {
-	const ET* rec = reinterpret_cast<const ET*>(base) + REC * e;
-	Xc[0] = rec[0]; Xc[1] = rec[1]; Xc[2] = rec[2];
-	wr = rec[3];
-	L.r[0] = rec[4]; L.r[1] = rec[5]; L.r[2] = rec[6];
-	const long long tag = tag_decode(rec[7]);
-	il = (int)(tag >> 1);
-	edge_jacobians(Xc, R, cam, (tag & 1) != 0, L);
+	ET* rec = reinterpret_cast<ET*>(base) + REC * slot;
+#pragma unroll
+	for (int k = 0; k < 9; k++) rec[4 + k] = (ET)v[k];
 }
 
 template <typename ET>
@@ -741,7 +739,7 @@ __device__ __forceinline__ void load_pose_as(const DeviceGraph& g, int ip, ET q[
 }
 
 // Workgroups beyond nLmGroups (optimize() only) copy the state into its backup: the push() of the LM loop rides in this launch.
-template <int MODE, typename ET, bool USEU = false>
+template <int MODE, typename ET>
 __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
 	unsigned nLmGroups, const Scalar* __restrict__ backupSrc, Scalar* __restrict__ backupDst, size_t backupCount)
 {
@@ -761,16 +759,15 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	const int e0 = g.lm_ptr[lm0], e1 = g.lm_ptr[lm1];
 	const int e = e0 + lane;
 	const bool valid = e < e1;
-	int il = lm0, seg0 = 0, seg1 = 0;
+	int il = lm0, seg0 = 0, seg1 = 0, slot = -1;
 	Scalar h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-	Scalar hplU[6][3];             // USEU: w' JP^T JL of this lane's edge
-	bool wantU = false;
 	if (valid)
 	{
 		const int pe = g.e_pose[e];
 		const bool stereo = (pe & STEREO_BIT) != 0;
 		const int ip = pe & ~STEREO_BIT;
 		il = g.e_lm[e];
+		slot = st.e_slot[e];
 		Scalar q[4], t[3], cam[5], Xw[3], meas[3], Xc[3];
 		EdgeLin L;
 		load_pose(g, ip, q, t, cam);
@@ -782,7 +779,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		const int kind = stereo ? g.rk[1].kind : g.rk[0].kind;
 		const Scalar delta = stereo ? g.rk[1].delta : g.rk[0].delta;
 		const Scalar wr = w * robust_weight(kind, delta, w * ss);
-		write_record<ET>(st.e_rec, (size_t)e, Xc, wr, L.r, il, stereo);
+		if (slot >= 0) write_record_edge<ET>(st.e_rec, (size_t)slot, Xc, wr, L.r, stereo);
 		if (il < g.Lf)
 		{
 			const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
@@ -797,14 +794,6 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 			}
 			seg0 = g.lm_ptr[il] - e0;
 			seg1 = g.lm_ptr[il + 1] - e0;
-			if (USEU && MODE == 1 && ip < g.Pf)
-			{
-				wantU = true;
-#pragma unroll
-				for (int c = 0; c < 6; c++)
-#pragma unroll
-					for (int kk = 0; kk < 3; kk++) hplU[c][kk] = wr * (L.JP[0][c] * L.JL[0][kk] + L.JP[1][c] * L.JL[1][kk] + L.JP[2][c] * L.JL[2][kk]);
-			}
 		}
 	}
 #pragma unroll
@@ -812,7 +801,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	wave_lds_sync();
 	const bool head = valid && il < g.Lf && lane == seg0;
 	Scalar m = 0;
-	Scalar Cf[6] = { 0, 0, 0, 0, 0, 0 };
+	Scalar out[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // MODE 1, head lanes: inv and inv bl of the landmark
 	if (head)
 	{
 		Scalar H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -828,42 +817,32 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		}
 		else
 		{
-			Scalar inv[6];
 			H[0] += lambda; H[3] += lambda; H[5] += lambda;
-			sym3_inverse(H, inv);
+			sym3_inverse(H, out);
 #pragma unroll
-			for (int k = 0; k < 6; k++) ls[k] = inv[k];
+			for (int k = 0; k < 6; k++) ls[k] = out[k];
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
-			if (USEU)
-			{
-				// lower-triangular C with C C^T = inv(Hll + lambda I): c00 c10 c20 c11 c21 c22
-				Cf[0] = sqrt(inv[0]); Cf[1] = inv[1] / Cf[0]; Cf[2] = inv[2] / Cf[0];
-				Cf[3] = sqrt(inv[3] - Cf[1] * Cf[1]); Cf[4] = (inv[4] - Cf[2] * Cf[1]) / Cf[3];
-				Cf[5] = sqrt(inv[5] - Cf[2] * Cf[2] - Cf[4] * Cf[4]);
-			}
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+				out[6 + i] = out[sym3_idx(i, 0)] * H[6] + out[sym3_idx(i, 1)] * H[7] + out[sym3_idx(i, 2)] * H[8];
 		}
 	}
-	if (USEU && MODE == 1)
+	if (MODE == 1)
 	{
+		// the landmark's part of the records: from the head lane to the landmark's edges through LDS
 		wave_lds_sync();                 // every segment sum has been read
 		if (head)
 #pragma unroll
-			for (int k = 0; k < 6; k++) lds[lane * 9 + k] = Cf[k];
+			for (int k = 0; k < 9; k++) lds[lane * 9 + k] = out[k];
 		wave_lds_sync();
-		if (wantU)
+		if (slot >= 0)
 		{
-			Scalar c[6];
+			Scalar v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			if (il < g.Lf)
 #pragma unroll
-			for (int k = 0; k < 6; k++) c[k] = lds[seg0 * 9 + k];
-			ET* u = reinterpret_cast<ET*>(st.e_u) + 18 * (size_t)e;
-#pragma unroll
-			for (int r = 0; r < 6; r++)
-			{
-				u[3 * r + 0] = (ET)(hplU[r][0] * c[0] + hplU[r][1] * c[1] + hplU[r][2] * c[2]);
-				u[3 * r + 1] = (ET)(hplU[r][1] * c[3] + hplU[r][2] * c[4]);
-				u[3 * r + 2] = (ET)(hplU[r][2] * c[5]);
-			}
+				for (int k = 0; k < 9; k++) v[k] = lds[seg0 * 9 + k];
+			write_record_landmark<ET>(st.e_rec, (size_t)slot, v);
 		}
 	}
 	if (MODE == 0)
@@ -878,6 +857,7 @@ template <int MODE, typename ET>
 __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
 {
 	__shared__ Scalar red[4][9];
+	__shared__ Scalar outv[9];
 	const int il = st.big_lm[blockIdx.x];
 	const int e0 = g.lm_ptr[il], e1 = g.lm_ptr[il + 1];
 	Scalar acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -892,7 +872,8 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 		for (int i = 0; i < 3; i++) Xw[i] = g.Xw[3 * (size_t)il + i];
 		quat_rotate(q, Xw, Xc);
 		Xc[0] += t[0]; Xc[1] += t[1]; Xc[2] += t[2];
-		write_record<ET>(st.e_rec, (size_t)e, Xc, le.wr, le.lin.r, il, le.stereo);
+		const int slot = st.e_slot[e];
+		if (slot >= 0) write_record_edge<ET>(st.e_rec, (size_t)slot, Xc, le.wr, le.lin.r, le.stereo);
 		if (il < g.Lf)
 		{
 			const EdgeLin& L = le.lin;
@@ -911,6 +892,7 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 	if ((threadIdx.x & 63) == 0)
 #pragma unroll
 		for (int k = 0; k < 9; k++) red[threadIdx.x >> 6][k] = acc[k];
+	if (threadIdx.x < 9) outv[threadIdx.x] = 0;
 	__syncthreads();
 	if (threadIdx.x == 0 && il < g.Lf)
 	{
@@ -930,10 +912,65 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 			H[0] += lambda; H[3] += lambda; H[5] += lambda;
 			sym3_inverse(H, inv);
 #pragma unroll
-			for (int k = 0; k < 6; k++) ls[k] = inv[k];
+			for (int k = 0; k < 6; k++) { ls[k] = inv[k]; outv[k] = inv[k]; }
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+				outv[6 + i] = inv[sym3_idx(i, 0)] * H[6] + inv[sym3_idx(i, 1)] * H[7] + inv[sym3_idx(i, 2)] * H[8];
 		}
+	}
+	if (MODE == 1)
+	{
+		// the landmark's part of its edges' records
+		__syncthreads();
+		Scalar v[9];
+#pragma unroll
+		for (int k = 0; k < 9; k++) v[k] = outv[k];
+		for (int e = e0 + threadIdx.x; e < e1; e += 256)
+		{
+			const int slot = st.e_slot[e];
+			if (slot >= 0) write_record_landmark<ET>(st.e_rec, (size_t)slot, v);
+		}
+	}
+}
+
+// Camera-frame form of an edge.  With D = d(projection)/d(Xc) (3x3, five non-zeros: rows (d00, 0, d02), (0, d11, d12) and, for a
+// stereo edge, (d00, 0, d22)) the Jacobians of computeJacobians (cuda_block_solver.cu:329-415) are JL = D R and JP = D G with
+// G = [-[Xc]x | I].  Everything the Schur passes need is then a 3x3 (or 3-vector) expression in the camera frame, sandwiched between
+// G^T and G, i.e. between cross products with Xc:
+//     K = w' D^T D (symmetric, K01 = 0)      M = K R      v = w' D^T r
+//     Hpp_e = G^T K G      Hpl_e = G^T M      bp_e = G^T v      Hpl_a inv Hpl_b^T = G_a^T [M_a inv M_b^T] G_b
+// About 150 multiply-adds per edge in the pose pass (330 with explicit Jacobians) and 200 per product in the block pass (330), and
+// neither the 3x6 nor the 3x3 Jacobians are ever held in registers.
+template <typename ET>
+struct CameraFrameEdge { ET X[3]; ET k00, k02, k11, k12, k22; ET d00, d02, d11, d12, d22; ET w; bool stereo; };
+
+template <typename ET>
+__device__ __forceinline__ void camera_frame_edge(const ET* rec, const ET cam[5], CameraFrameEdge<ET>& c)
+{
+	const ET X = rec[0], Y = rec[1], Z = rec[2], ws = rec[3];
+	c.stereo = sign_flag(ws);
+	c.w = abs_value(ws);
+	c.X[0] = X; c.X[1] = Y; c.X[2] = Z;
+	const ET invZ = 1 / Z, invZZ = invZ * invZ;
+	c.d00 = -cam[0] * invZ; c.d02 = cam[0] * X * invZZ; c.d11 = -cam[1] * invZ; c.d12 = cam[1] * Y * invZZ;
+	c.d22 = c.stereo ? c.d02 - cam[4] * invZZ : ET(0);
+	c.k00 = c.w * (c.stereo ? 2 * c.d00 * c.d00 : c.d00 * c.d00);
+	c.k02 = c.w * (c.d00 * c.d02 + (c.stereo ? c.d00 * c.d22 : ET(0)));
+	c.k11 = c.w * c.d11 * c.d11; c.k12 = c.w * c.d11 * c.d12;
+	c.k22 = c.w * (c.d02 * c.d02 + c.d12 * c.d12 + c.d22 * c.d22);
+}
+
+template <typename ET>
+__device__ __forceinline__ void camera_frame_m(const CameraFrameEdge<ET>& c, const Rot3T<ET>& R, ET (&M)[3][3])
+{
+#pragma unroll
+	for (int j = 0; j < 3; j++)
+	{
+		M[0][j] = c.k00 * R.m[0][j] + c.k02 * R.m[2][j];
+		M[1][j] = c.k11 * R.m[1][j] + c.k12 * R.m[2][j];
+		M[2][j] = c.k02 * R.m[0][j] + c.k12 * R.m[1][j] + c.k22 * R.m[2][j];
 	}
 }
 
@@ -954,48 +991,65 @@ __device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const Devic
 	const int p1 = st.pe_end[ip];
 	for (int p = st.pe_beg[ip] + lane; p < p1; p += 64)
 	{
-		const int e = st.pe_edge[p];
-		EdgeLinT<ET> L; ET wr, Xc[3]; int il;
-		rec_jacobians<ET>(st.e_rec, (size_t)e, R, cam, L, wr, il, Xc);
-		ET hpl[6][3], W[6][3], ibl[3] = { 0, 0, 0 };
-		const bool lmFree = MODE == 1 && il < g.Lf;
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int k = 0; k < 3; k++)
-				hpl[c][k] = wr * (L.JP[0][c] * L.JL[0][k] + L.JP[1][c] * L.JL[1][k] + L.JP[2][c] * L.JL[2][k]);
-		if (lmFree)
+		// the record slot of an edge is its position in the pose's list: one 128-byte line per lane, consecutive lanes consecutive lines
+		const ET* rec = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)p;
+		CameraFrameEdge<ET> c;
+		camera_frame_edge<ET>(rec, cam, c);
+		const ET r0 = rec[13], r1 = rec[14], r2 = c.stereo ? rec[15] : ET(0);
+		// S = K - M inv M^T (mode 1; the record of an edge to a fixed landmark holds inv = 0, inv bl = 0), v = w' D^T r, v' = v - M inv bl
+		ET S[6] = { c.k00, 0, c.k02, c.k11, c.k12, c.k22 };
+		ET v[3] = { c.w * c.d00 * (r0 + r2), c.w * c.d11 * r1, c.w * (c.d02 * r0 + c.d12 * r1 + c.d22 * r2) };
+		ET vs[3] = { v[0], v[1], v[2] };
+		if (MODE == 1)
 		{
-			const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
-			ET inv[6], bl[3];
+			ET M[3][3], P[3][3], inv[6];
+			camera_frame_m<ET>(c, R, M);
 #pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
-#pragma unroll
-			for (int k = 0; k < 3; k++) bl[k] = (ET)ls[6 + k];
+			for (int k = 0; k < 6; k++) inv[k] = rec[4 + k];
 #pragma unroll
 			for (int i = 0; i < 3; i++)
-				ibl[i] = inv[sym3_idx(i, 0)] * bl[0] + inv[sym3_idx(i, 1)] * bl[1] + inv[sym3_idx(i, 2)] * bl[2];
-#pragma unroll
-			for (int r = 0; r < 6; r++)
 #pragma unroll
 				for (int k = 0; k < 3; k++)
-					W[r][k] = hpl[r][0] * inv[sym3_idx(0, k)] + hpl[r][1] * inv[sym3_idx(1, k)] + hpl[r][2] * inv[sym3_idx(2, k)];
+					P[i][k] = M[i][0] * inv[sym3_idx(0, k)] + M[i][1] * inv[sym3_idx(1, k)] + M[i][2] * inv[sym3_idx(2, k)];
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+#pragma unroll
+				for (int j = i; j < 3; j++)
+					S[sym3_idx(i, j)] -= P[i][0] * M[j][0] + P[i][1] * M[j][1] + P[i][2] * M[j][2];
+			const ET b0 = rec[10], b1 = rec[11], b2 = rec[12];
+#pragma unroll
+			for (int i = 0; i < 3; i++) vs[i] -= M[i][0] * b0 + M[i][1] * b1 + M[i][2] * b2;
 		}
-		else
-		{
+		// G^T S G = [[ U [X]x^T, U ], [ ., S ]] with U = [X]x S; upper triangle, acc[c (c + 1) / 2 + r] for r <= c
+		const ET X = c.X[0], Y = c.X[1], Z = c.X[2];
+		ET U[3][3];
 #pragma unroll
-			for (int r = 0; r < 6; r++) { W[r][0] = 0; W[r][1] = 0; W[r][2] = 0; }
+		for (int j = 0; j < 3; j++)
+		{
+			const ET s0 = S[sym3_idx(0, j)], s1 = S[sym3_idx(1, j)], s2 = S[sym3_idx(2, j)];
+			U[0][j] = Y * s2 - Z * s1;
+			U[1][j] = Z * s0 - X * s2;
+			U[2][j] = X * s1 - Y * s0;
 		}
 #pragma unroll
-		for (int c = 0; c < 6; c++)
+		for (int i = 0; i < 3; i++)
 		{
+			// row i of U [X]x^T = X x U_i
+			const ET t[3] = { Y * U[i][2] - Z * U[i][1], Z * U[i][0] - X * U[i][2], X * U[i][1] - Y * U[i][0] };
 #pragma unroll
-			for (int r = 0; r <= c; r++)
-				acc[c * (c + 1) / 2 + r] += (Scalar)(wr * (L.JP[0][r] * L.JP[0][c] + L.JP[1][r] * L.JP[1][c] + L.JP[2][r] * L.JP[2][c])
-					- (W[r][0] * hpl[c][0] + W[r][1] * hpl[c][1] + W[r][2] * hpl[c][2]));
-			const ET b = wr * (L.JP[0][c] * L.r[0] + L.JP[1][c] * L.r[1] + L.JP[2][c] * L.r[2]);
-			acc[21 + c] += (Scalar)b;
-			acc[27 + c] += (Scalar)(b - (hpl[c][0] * ibl[0] + hpl[c][1] * ibl[1] + hpl[c][2] * ibl[2]));
+			for (int j = i; j < 3; j++) acc[j * (j + 1) / 2 + i] += (Scalar)t[j];
+#pragma unroll
+			for (int j = 0; j < 3; j++) acc[(3 + j) * (4 + j) / 2 + i] += (Scalar)U[i][j];
+#pragma unroll
+			for (int j = i; j < 3; j++) acc[(3 + j) * (4 + j) / 2 + 3 + i] += (Scalar)S[sym3_idx(i, j)];
+		}
+		// G^T v = [X x v ; v]
+		acc[21] += (Scalar)(Y * v[2] - Z * v[1]); acc[22] += (Scalar)(Z * v[0] - X * v[2]); acc[23] += (Scalar)(X * v[1] - Y * v[0]);
+		acc[24] += (Scalar)v[0]; acc[25] += (Scalar)v[1]; acc[26] += (Scalar)v[2];
+		if (MODE == 1)
+		{
+			acc[27] += (Scalar)(Y * vs[2] - Z * vs[1]); acc[28] += (Scalar)(Z * vs[0] - X * vs[2]); acc[29] += (Scalar)(X * vs[1] - Y * vs[0]);
+			acc[30] += (Scalar)vs[0]; acc[31] += (Scalar)vs[1]; acc[32] += (Scalar)vs[2];
 		}
 	}
 #pragma unroll
@@ -1014,9 +1068,10 @@ __device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const Devic
 	}
 }
 
-// 16 lanes = one block (a,b) of Hsc with a != b (or a == b for the rare duplicate-observation products).
-// ET = record / per-product arithmetic type: a lane's own partial sum (its every 16th product) is kept in ET, the sum across
-// the 16 lanes and the stored block are Scalar.
+// GROUP lanes = one block (a,b) of Hsc with a != b (or a == b for the rare duplicate-observation products): 16, or the whole wave for
+// the first st.nHeavy blocks of the list (more than BP_HEAVY products: KITTI-00's longest list, 424 products, is 7 trips instead of 27).
+// ET = record / per-product arithmetic type: a lane's own partial sum is kept in ET, the sum across the lanes and the stored block
+// are Scalar.
 constexpr int BP_GROUP = 16;
 
 template <int MODE, typename ET>
@@ -1025,59 +1080,17 @@ __global__ __launch_bounds__(256) void pose_pass_kernel(DeviceGraph g, DeviceStr
 	pose_pass_body<MODE, ET>(g, st, sys, blockIdx.x);
 }
 
-// The same block in camera-frame form (default).  With D_e = d(projection)/d(Xc) (3x3, five non-zeros) the Jacobians of an edge are
-// JL_e = D_e R_e and JP_e = D_e G_e, G_e = [-[Xc_e]x | I], so a product is
-//     T_ab = G_a^T [ M_a inv M_b^T ] G_b,    M_e = w_e D_e^T D_e R_e    (K_e = w_e D_e^T D_e is symmetric with K01 = 0)
-// and the two outer factors are cross products with Xc_a / Xc_b: about 200 multiply-adds per product instead of 330, and neither
-// the 3x6 nor the 3x3 Jacobians are ever held in registers (the Jacobian form sits at the 256-register cliff).
+// a product of the block pass in camera-frame form: T_ab = G_a^T [ M_a inv M_b^T ] G_b
 template <typename ET>
 struct ProductOperand { ET X[3]; ET M[3][3]; };
 
-
-// the same in two steps, for the software-pipelined loop: the raw loads of a product (issued one trip ahead) ...
 template <typename ET>
-struct ProductRaw { ET a[4], b[4], ta, tb; Scalar inv[6]; };
-
-template <typename ET>
-__device__ __forceinline__ void product_load(const DeviceStructure& st, const DeviceSystem& sys, int ea, int eb, int lm, ProductRaw<ET>& r)
+__device__ __forceinline__ void product_operand(const ET* rec, const Rot3T<ET>& R, const ET cam[5], ProductOperand<ET>& o)
 {
-	const ET* ra = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)ea;
-	const ET* rb = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)eb;
-	const Scalar* ls = sys.lm_sys + 9 * (size_t)lm;
-#pragma unroll
-	for (int k = 0; k < 4; k++) { r.a[k] = ra[k]; r.b[k] = rb[k]; }
-	r.ta = ra[7]; r.tb = rb[7];
-#pragma unroll
-	for (int k = 0; k < 6; k++) r.inv[k] = ls[k];
-}
-
-// ... and the operand built from them
-template <typename ET>
-__device__ __forceinline__ void product_operand_raw(const ET rec[4], ET tag, const Rot3T<ET>& R, const ET cam[5], ProductOperand<ET>& o)
-{
-	const ET X = rec[0], Y = rec[1], Z = rec[2], w = rec[3];
-	const bool stereo = (tag_decode(tag) & 1) != 0;
-	o.X[0] = X; o.X[1] = Y; o.X[2] = Z;
-	const ET invZ = 1 / Z, invZZ = invZ * invZ;
-	const ET d00 = -cam[0] * invZ, d02 = cam[0] * X * invZZ, d11 = -cam[1] * invZ, d12 = cam[1] * Y * invZZ;
-	const ET d22 = stereo ? d02 - cam[4] * invZZ : ET(0);      // third row of D: (d00, 0, d22) for stereo edges, zero otherwise
-	const ET k00 = w * (stereo ? 2 * d00 * d00 : d00 * d00), k02 = w * (d00 * d02 + (stereo ? d00 * d22 : ET(0)));
-	const ET k11 = w * d11 * d11, k12 = w * d11 * d12, k22 = w * (d02 * d02 + d12 * d12 + d22 * d22);
-#pragma unroll
-	for (int j = 0; j < 3; j++)
-	{
-		o.M[0][j] = k00 * R.m[0][j] + k02 * R.m[2][j];
-		o.M[1][j] = k11 * R.m[1][j] + k12 * R.m[2][j];
-		o.M[2][j] = k02 * R.m[0][j] + k12 * R.m[1][j] + k22 * R.m[2][j];
-	}
-}
-
-template <typename ET>
-__device__ __forceinline__ void product_operand(const Scalar* base, size_t e, const Rot3T<ET>& R, const ET cam[5], ProductOperand<ET>& o)
-{
-	const ET* rec = reinterpret_cast<const ET*>(base) + REC * e;
-	const ET r4[4] = { rec[0], rec[1], rec[2], rec[3] };
-	product_operand_raw<ET>(r4, rec[7], R, cam, o);
+	CameraFrameEdge<ET> c;
+	camera_frame_edge<ET>(rec, cam, c);
+	o.X[0] = c.X[0]; o.X[1] = c.X[1]; o.X[2] = c.X[2];
+	camera_frame_m<ET>(c, R, o.M);
 }
 
 template <typename ET>
@@ -1111,12 +1124,11 @@ __device__ __forceinline__ void product_accumulate(const ProductOperand<ET>& A, 
 	}
 }
 
-template <typename ET, int FORM = 1>
-__device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
+// grp = position in st.od_blocks (or -1: idle lanes), gl = lane within the group
+template <typename ET, int GROUP>
+__device__ __forceinline__ void block_pass_group(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int grp, int gl)
 {
-	const int gl = threadIdx.x & (BP_GROUP - 1);
-	const int grp = (bid * 256 + threadIdx.x) / BP_GROUP;
-	const int blk0 = grp < st.nOd ? st.od_blocks[grp] : -1;      // (-1: unused slot of an XCD-aware order)
+	const int blk0 = grp >= 0 ? st.od_blocks[grp] : -1;      // (-1 inside the list: unused slot of an XCD-aware order)
 	const bool on = blk0 >= 0;
 	const int blk = on ? blk0 : 0;
 	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
@@ -1130,133 +1142,21 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	for (int r = 0; r < 6; r++)
 #pragma unroll
 		for (int c = 0; c < 6; c++) T[r][c] = 0;
-	// (Round 3, measured: an XCD-aware block order cuts the HBM-side fetch of this pass from 243 to 87 MB per launch and changes its
-	// time by nothing, so latency at two waves per SIMD bounds it, not bytes; but the loop sits exactly at the 256-register cliff --
-	// prefetching the next product's index triple, or touching its cache lines one trip ahead, costs 6-14 spilled registers and
-	// 20-50 us: profiles/r03j_block_order.txt, r03k_block_touch.txt.)
+	const ET* recs = reinterpret_cast<const ET*>(st.e_rec);
 	const int p1 = on ? st.prod_end[blk] : 0;
-	if (FORM == 3)          // TIMING EXPERIMENT: coalesced addresses instead of the gathers (wrong results)
+	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += GROUP)
 	{
-		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
-		{
-			const Scalar* ls = sys.lm_sys + 9 * (size_t)(p % g.Lf);
-			ET inv[6];
-#pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
-			ProductOperand<ET> A, B;
-			product_operand<ET>(st.e_rec, (size_t)(p % g.E), Ra, cama, A);
-			product_operand<ET>(st.e_rec, (size_t)((p + 7) % g.E), Rb, camb, B);
-			product_accumulate<ET>(A, B, inv, T);
-		}
-	}
-	else if (FORM == 4)     // TIMING EXPERIMENT: the gathers, no arithmetic (wrong results)
-	{
-		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
-		{
-			const Scalar* ls = sys.lm_sys + 9 * (size_t)st.prod_lm[p];
-			const ET* ra = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_ea[p];
-			const ET* rb = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_eb[p];
-			ET acc = 0;
-#pragma unroll
-			for (int k = 0; k < 6; k++) acc += (ET)ls[k];
-#pragma unroll
-			for (int k = 0; k < 4; k++) acc += ra[k] + rb[k];
-			T[0][0] += acc + ra[7] + rb[7];
-		}
-	}
-	else if (FORM >= 6)     // TIMING EXPERIMENTS: subsets of the gathers, no arithmetic (wrong results)
-	{
-		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
-		{
-			typedef ET ET2 __attribute__((ext_vector_type(2)));
-			const ET2* ra = reinterpret_cast<const ET2*>(reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_ea[p]);
-			ET acc = 0;
-			if (FORM == 6) { const ET2 v = ra[0]; acc = v.x + v.y; }                                     // one 16-byte lane request
-			if (FORM == 7) { const ET2 v = ra[0], w = ra[1]; acc = v.x + v.y + w.x + w.y; }              // two requests, one line
-			if (FORM == 8) { const ET2 v = ra[0], w = ra[1], x = ra[2], y = ra[3]; acc = v.x + v.y + w.x + w.y + x.x + x.y + y.x + y.y; }   // four requests, one line
-			if (FORM == 9)                                                                              // two requests, two lines
-			{
-				const ET2* rb = reinterpret_cast<const ET2*>(reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.prod_eb[p]);
-				const ET2 v = ra[0], w = rb[0]; acc = v.x + v.y + w.x + w.y;
-			}
-			if (FORM == 10) { acc = (ET)(st.prod_ea[p] + st.prod_eb[p] + st.prod_lm[p]); }               // the index loads alone
-			T[0][0] += acc;
-		}
-	}
-	else if (FORM == 1)
-	{
-		for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
-		{
-			const Scalar* ls = sys.lm_sys + 9 * (size_t)st.prod_lm[p];
-			ET inv[6];
-#pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
-			ProductOperand<ET> A, B;
-			product_operand<ET>(st.e_rec, (size_t)st.prod_ea[p], Ra, cama, A);
-			product_operand<ET>(st.e_rec, (size_t)st.prod_eb[p], Rb, camb, B);
-			product_accumulate<ET>(A, B, inv, T);
-		}
-	}
-	else if (FORM == 2)
-	{
-		// software pipeline: index triple two trips ahead, raw records one trip ahead
-		int p = (on ? st.prod_beg[blk] : 0) + gl;
-		bool h0 = p < p1, h1 = p + BP_GROUP < p1;
-		ProductRaw<ET> cur, nxt;
-		int ea1 = 0, eb1 = 0, lm1 = 0;
-		if (h0) product_load<ET>(st, sys, st.prod_ea[p], st.prod_eb[p], st.prod_lm[p], cur);
-		if (h1) { ea1 = st.prod_ea[p + BP_GROUP]; eb1 = st.prod_eb[p + BP_GROUP]; lm1 = st.prod_lm[p + BP_GROUP]; }
-		while (h0)
-		{
-			const bool h2 = p + 2 * BP_GROUP < p1;
-			if (h1) product_load<ET>(st, sys, ea1, eb1, lm1, nxt);
-			if (h2) { ea1 = st.prod_ea[p + 2 * BP_GROUP]; eb1 = st.prod_eb[p + 2 * BP_GROUP]; lm1 = st.prod_lm[p + 2 * BP_GROUP]; }
-			ET inv[6];
-#pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = (ET)cur.inv[k];
-			ProductOperand<ET> A, B;
-			product_operand_raw<ET>(cur.a, cur.ta, Ra, cama, A);
-			product_operand_raw<ET>(cur.b, cur.tb, Rb, camb, B);
-			product_accumulate<ET>(A, B, inv, T);
-			cur = nxt; h0 = h1; h1 = h2; p += BP_GROUP;
-		}
-	}
-	else
-	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
-	{
-		EdgeLinT<ET> La, Lb; ET wa, wb, Xa[3], Xb[3]; int il, il2;
-		// the landmark comes from the product list, not from record a: all three gathers of a product are issued together
-		const Scalar* ls = sys.lm_sys + 9 * (size_t)st.prod_lm[p];
+		const ET* ra = recs + REC * (size_t)st.prod_ea[p];
+		const ET* rb = recs + REC * (size_t)st.prod_eb[p];
 		ET inv[6];
 #pragma unroll
-		for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
-		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_ea[p], Ra, cama, La, wa, il, Xa);
-		rec_jacobians<ET>(st.e_rec, (size_t)st.prod_eb[p], Rb, camb, Lb, wb, il2, Xb);
-		// S = wa wb JL_a inv JL_b^T  (measurement x measurement)
-		ET M1[3][3], S[3][3];
-#pragma unroll
-		for (int m = 0; m < 3; m++)
-#pragma unroll
-			for (int k = 0; k < 3; k++)
-				M1[m][k] = La.JL[m][0] * inv[sym3_idx(0, k)] + La.JL[m][1] * inv[sym3_idx(1, k)] + La.JL[m][2] * inv[sym3_idx(2, k)];
-		const ET ww = wa * wb;
-#pragma unroll
-		for (int m = 0; m < 3; m++)
-#pragma unroll
-			for (int n = 0; n < 3; n++)
-				S[m][n] = ww * (M1[m][0] * Lb.JL[n][0] + M1[m][1] * Lb.JL[n][1] + M1[m][2] * Lb.JL[n][2]);
-		// T += JP_a^T (S JP_b)
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-		{
-			const ET u0 = S[0][0] * Lb.JP[0][c] + S[0][1] * Lb.JP[1][c] + S[0][2] * Lb.JP[2][c];
-			const ET u1 = S[1][0] * Lb.JP[0][c] + S[1][1] * Lb.JP[1][c] + S[1][2] * Lb.JP[2][c];
-			const ET u2 = S[2][0] * Lb.JP[0][c] + S[2][1] * Lb.JP[1][c] + S[2][2] * Lb.JP[2][c];
-#pragma unroll
-			for (int r = 0; r < 6; r++) T[r][c] += La.JP[0][r] * u0 + La.JP[1][r] * u1 + La.JP[2][r] * u2;
-		}
+		for (int k = 0; k < 6; k++) inv[k] = ra[4 + k];
+		ProductOperand<ET> A, B;
+		product_operand<ET>(ra, Ra, cama, A);
+		product_operand<ET>(rb, Rb, camb, B);
+		product_accumulate<ET>(A, B, inv, T);
 	}
-	// reduce over the 16 lanes of the group (in Scalar)
+	// reduce over the lanes of the group (in Scalar)
 	Scalar Ts[6][6];
 #pragma unroll
 	for (int r = 0; r < 6; r++)
@@ -1264,7 +1164,8 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 		for (int c = 0; c < 6; c++)
 		{
 			Scalar v = (Scalar)T[r][c];
-			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+			if (GROUP == 64) v = wave_sum(v);
+			else { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); }
 			Ts[r][c] = v;
 		}
 	if (!on) return;
@@ -1275,7 +1176,7 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 		for (int c = 0; c < 6; c++)
 #pragma unroll
 			for (int r = 0; r < 6; r++)
-				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
+				if (GROUP == 64 ? (c * 6 + r) == gl : (c * 6 + r) % GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
 	}
 	else if (gl == 0)
 	{
@@ -1287,109 +1188,51 @@ __device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const Devi
 	}
 }
 
-// option "schur_u": T_ab = sum over the products of U_a U_b^T, two 144-byte (72 in mixed mode) gathers and 108 multiply-adds per
-// product, no pose data at all
+// workgroup bid of the block pass: the heavy blocks first (one per wave), then 16 light blocks per workgroup
+__host__ __device__ __forceinline__ int block_pass_heavy_groups(int nHeavy) { return (nHeavy + 3) / 4; }
+__host__ __device__ __forceinline__ int block_pass_groups(int nOd, int nHeavy) { return block_pass_heavy_groups(nHeavy) + ((nOd - nHeavy) * BP_GROUP + 255) / 256; }
+
 template <typename ET>
-__device__ __forceinline__ void block_pass_u_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
+__device__ __forceinline__ void block_pass_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int bid)
 {
-	typedef ET ET2 __attribute__((ext_vector_type(2)));
-	const int gl = threadIdx.x & (BP_GROUP - 1);
-	const int grp = (bid * 256 + threadIdx.x) / BP_GROUP;
-	const int blk0 = grp < st.nOd ? st.od_blocks[grp] : -1;
-	const bool on = blk0 >= 0;
-	const int blk = on ? blk0 : 0;
-	const int a = st.hsc_blkrow[blk], b = st.hsc_colind[blk];
-	Scalar T[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++) T[r][c] = 0;
-	const ET* ubase = reinterpret_cast<const ET*>(st.e_u);
-	const int p1 = on ? st.prod_end[blk] : 0;
-	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += BP_GROUP)
+	const int nh = block_pass_heavy_groups(st.nHeavy);
+	if (bid < nh)
 	{
-		const ET2* ua2 = reinterpret_cast<const ET2*>(ubase + 18 * (size_t)st.prod_ea[p]);
-		const ET2* ub2 = reinterpret_cast<const ET2*>(ubase + 18 * (size_t)st.prod_eb[p]);
-		ET2 va[9], vb[9];
-#pragma unroll
-		for (int i = 0; i < 9; i++) { va[i] = ua2[i]; vb[i] = ub2[i]; }
-		Scalar Ua[18], Ub[18];
-#pragma unroll
-		for (int i = 0; i < 9; i++) { Ua[2 * i] = (Scalar)va[i].x; Ua[2 * i + 1] = (Scalar)va[i].y; Ub[2 * i] = (Scalar)vb[i].x; Ub[2 * i + 1] = (Scalar)vb[i].y; }
-#pragma unroll
-		for (int r = 0; r < 6; r++)
-#pragma unroll
-			for (int c = 0; c < 6; c++) T[r][c] += Ua[3 * r] * Ub[3 * c] + Ua[3 * r + 1] * Ub[3 * c + 1] + Ua[3 * r + 2] * Ub[3 * c + 2];
+		const int grp = bid * 4 + (threadIdx.x >> 6);
+		block_pass_group<ET, 64>(g, st, sys, grp < st.nHeavy ? grp : -1, threadIdx.x & 63);
 	}
-	Scalar Ts[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-		{
-			Scalar v = T[r][c];
-			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-			Ts[r][c] = v;
-		}
-	if (!on) return;
-	Scalar* dst = sys.hsc + 36 * (size_t)blk;
-	if (a != b)
+	else
 	{
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r < 6; r++)
-				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
-	}
-	else if (gl == 0)
-	{
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= Ts[r][c] + Ts[c][r];
+		const int grp = st.nHeavy + ((bid - nh) * 256 + threadIdx.x) / BP_GROUP;
+		block_pass_group<ET, BP_GROUP>(g, st, sys, grp < st.nOd ? grp : -1, threadIdx.x & (BP_GROUP - 1));
 	}
 }
 
-template <typename ET, int FORM = 1>
+template <typename ET>
 __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
 {
-	block_pass_body<ET, FORM>(g, st, sys, blockIdx.x);
-}
-
-template <typename ET>
-__global__ __launch_bounds__(256) void block_pass_u_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
-{
-	block_pass_u_body<ET>(g, st, sys, blockIdx.x);
-}
-
-template <typename ET>
-__global__ __launch_bounds__(256) void schur_pass_u_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
-{
-	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
-	else block_pass_u_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
+	block_pass_body<ET>(g, st, sys, blockIdx.x);
 }
 
 // Pose pass and block pass in one launch: they write disjoint parts of the reduced system (diagonal blocks / bp / bsc vs the
-// off-diagonal blocks) from the same records.  The pose workgroups come first (a wave walks a pose's ~420 edges in 7 trips:
-// 33 us of latency when launched alone) and run under the ALU-bound block workgroups.
-template <typename ET, int FORM = 1>
+// off-diagonal blocks) from the same records.  The pose workgroups come first (one wave per pose: 7 dependent trips at KITTI-00)
+// and run under the block workgroups.
+template <typename ET>
 __global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
 {
 	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
-	else block_pass_body<ET, FORM>(g, st, sys, blockIdx.x - nPoseGroups);
+	else block_pass_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
 }
 
 template <typename ET>
 static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
 	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
 {
-	const bool useU = st.e_u && mode == 1 && st.nBig == 0 && st.nDiagProd == 0 && g.Pf > 0 && st.nOd > 0;      // (experiment: graphs without > 64-observation landmarks)
 	if (st.nWaves > 0)
 	{
 		const unsigned grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
 		const unsigned nCopy = backupSrc ? (unsigned)std::min<size_t>(512, (backupCount + LIN_BLOCK - 1) / LIN_BLOCK) : 0;
 		if (mode == 0) hipLaunchKernelGGL((lm_pass_kernel<0, ET>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
-		else if (useU) hipLaunchKernelGGL((lm_pass_kernel<1, ET, true>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
 		else hipLaunchKernelGGL((lm_pass_kernel<1, ET>), dim3(grid + nCopy), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, grid, backupSrc, backupDst, backupCount);
 	}
 	else if (backupSrc && backupCount)
@@ -1400,30 +1243,11 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 	}
 	static const bool separate = std::getenv("CUBA_HIP_SEPARATE_SCHUR_PASSES") != nullptr;     // A/B knob
-	static const bool jacForm = std::getenv("CUBA_HIP_BLOCK_PASS_JACOBIANS") != nullptr;        // A/B knob: the block pass of rounds 1-2
-	static const bool pipeForm = std::getenv("CUBA_HIP_BLOCK_PASS_PIPELINED") != nullptr;       // A/B knob: camera-frame form with loads one trip ahead
-	static const int expForm = std::getenv("CUBA_HIP_BLOCK_PASS_EXPERIMENT") ? std::atoi(std::getenv("CUBA_HIP_BLOCK_PASS_EXPERIMENT")) : 0;   // timing experiments (wrong results)
-	if (useU)
-	{
-		static const bool sepU = std::getenv("CUBA_HIP_SCHUR_U_SEPARATE") != nullptr;     // A/B: the light block pass as its own launch (own register budget)
-		const int np = (g.Pf + 3) / 4;
-		if (!sepU) hipLaunchKernelGGL((schur_pass_u_kernel<ET>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
-		else
-		{
-			hipLaunchKernelGGL((block_pass_u_kernel<ET>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-			hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3(np), dim3(256), 0, s, g, st, sys);
-		}
-		return;
-	}
+	const int nbp = block_pass_groups(st.nOd, st.nHeavy);
 	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0 && !separate)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)
 	{
 		const int np = (g.Pf + 3) / 4;
-		if (jacForm) hipLaunchKernelGGL((schur_pass_kernel<ET, 0>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
-		else if (pipeForm) hipLaunchKernelGGL((schur_pass_kernel<ET, 2>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
-		else if (expForm == 3) hipLaunchKernelGGL((schur_pass_kernel<ET, 3>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
-		else if (expForm == 4) hipLaunchKernelGGL((schur_pass_kernel<ET, 4>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
-		else if (expForm == 5) hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3(np), dim3(256), 0, s, g, st, sys);
-		else hipLaunchKernelGGL((schur_pass_kernel<ET, 1>), dim3(np + (st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys, np);
+		hipLaunchKernelGGL((schur_pass_kernel<ET>), dim3(np + nbp), dim3(256), 0, s, g, st, sys, np);
 		return;
 	}
 	if (g.Pf > 0)
@@ -1432,18 +1256,7 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
 	}
 	if (mode == 1 && st.nOd > 0)
-	{
-		if (jacForm) hipLaunchKernelGGL((block_pass_kernel<ET, 0>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (pipeForm) hipLaunchKernelGGL((block_pass_kernel<ET, 2>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 3) hipLaunchKernelGGL((block_pass_kernel<ET, 3>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 4) hipLaunchKernelGGL((block_pass_kernel<ET, 4>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 6) hipLaunchKernelGGL((block_pass_kernel<ET, 6>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 7) hipLaunchKernelGGL((block_pass_kernel<ET, 7>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 8) hipLaunchKernelGGL((block_pass_kernel<ET, 8>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 9) hipLaunchKernelGGL((block_pass_kernel<ET, 9>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else if (expForm == 10) hipLaunchKernelGGL((block_pass_kernel<ET, 10>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-		else hipLaunchKernelGGL((block_pass_kernel<ET, 1>), dim3((st.nOd * BP_GROUP + 255) / 256), dim3(256), 0, s, g, st, sys);
-	}
+		hipLaunchKernelGGL((block_pass_kernel<ET>), dim3(nbp), dim3(256), 0, s, g, st, sys);
 }
 
 void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,

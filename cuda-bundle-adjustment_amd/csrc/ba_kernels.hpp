@@ -37,6 +37,8 @@ struct DeviceGraph
 	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
 };
 
+constexpr int BP_HEAVY = 64;      // blocks of Hsc with more products than this get a whole wave in the block pass
+
 struct DeviceStructure
 {
 	int nWaves = 0;

@@ -163,7 +163,7 @@ struct cuba_hip_solver
 	bool precondFp32 = sizeof(Scalar) == 8;
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
-	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
+	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge, d_eSlot;
 	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
 	// single-kernel PCG iteration: halo lists of the aggregates + its vectors
 	DevBuf<int> d_halN, d_halNJ, d_halPose, d_halAloc, d_haggId, d_ellLoc, d_ownLoc;
@@ -174,8 +174,7 @@ struct cuba_hip_solver
 	// redoes residual and preconditioner on a ~50-pose halo -- so it stays OFF by default; iteration counts are identical.
 	int pcgSingleKernel = 0;
 	bool localRanges = false;
-	DevBuf<Scalar> d_erec, d_eu;
-	bool schurU = false;         // option "schur_u" (experiment): per-edge U blocks for the block pass
+	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
 	DevBuf<Scalar> d_cbWi, d_cbWj;
 	std::vector<int> h_rowptr, h_colind;
@@ -962,6 +961,9 @@ struct cuba_hip_solver
 		sync();
 		lap("structure: coarse lists + sync");
 		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += k >= 0 && blkRow[k] == h_colind[k];
+		heavyBlocks = 0;        // (the list is sorted by length; an XCD-aware experiment order is not: all blocks then take the 16-lane path)
+		if (!std::getenv("CUBA_HIP_BLOCK_ORDER_XCD") && !std::getenv("CUBA_HIP_BLOCK_ORDER_ROW"))
+			for (int k : odBlocks) heavyBlocks += prodPtr[k + 1] - prodPtr[k] > BP_HEAVY;
 		publishStructure(nblk, (int)waveLm.size() / 2, (int)bigLm.size(), (int)odBlocks.size(), (int)cbI.size(), ellM, ellOver, cc);
 		hostPatternValid = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -996,7 +998,6 @@ struct cuba_hip_solver
 	int rzStrideCfg = 1, pqStrideCfg = 1;
 	void allocSystem(int nblk, const CoarseCfg& c)
 	{
-		d_erec.resize((size_t)8 * E);
 		d_red.resize((size_t)36 * nblk + (size_t)12 * Pf);
 		d_lmSys.resize((size_t)9 * Lf); d_xp.resize((size_t)6 * Pf); d_xl.resize((size_t)3 * Lf);
 		d_minv.resize((size_t)36 * Pf);
@@ -1017,6 +1018,7 @@ struct cuba_hip_solver
 
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
 	int diagProdBlocks = 0;      // diagonal blocks with products (duplicate observations), set by the structure builders
+	int heavyBlocks = 0;         // blocks with more than BP_HEAVY products (the first ones of d_odBlocks), set by the structure builders
 	void publishStructure(int nblk, int nWaves, int nBig, int nOd, int nCb, int ellM, int ellOver, const CoarseCfg& c)
 	{
 		const int agg = c.agg, cl = c.cl, nc = c.nc, spmvRows = c.spmvRows;
@@ -1028,14 +1030,20 @@ struct cuba_hip_solver
 		st.pair_blk = d_pairBlk.data(); st.lm_pair_base = d_lmPairBase.data(); st.lm_nfree = d_lmNfree.data();
 		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
 		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
-		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data();
+		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data(); st.nHeavy = std::min(heavyBlocks, nOd);
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
-		if (!localRanges) fillProdLm();          // (a device-built partition needed it earlier)
-		st.prod_lm = d_prodLm.data();
+		st.prod_lm = localRanges ? d_prodLm.data() : nullptr;          // (only the set-up of a device-built partition needs the landmarks of the products)
+		// record slots: the builders leave edge ids in the product lists; the kernels want the position of each edge in the per-pose lists
+		d_eSlot.resize((size_t)E);
+		if (E > 0) (void)hipMemsetAsync(d_eSlot.data(), 0xff, (size_t)E * sizeof(int), stream);
+		topo::launch_slot_scatter(d_peEdge.data(), d_peEdge.size(), d_eSlot.data(), stream);
+		topo::launch_gather_int(d_prodEa.data(), d_eSlot.data(), d_prodEa.size(), d_prodEa.data(), stream);
+		topo::launch_gather_int(d_prodEb.data(), d_eSlot.data(), d_prodEb.size(), d_prodEb.data(), stream);
+		st.e_slot = d_eSlot.data();
+		d_erec.resize((size_t)16 * std::max<size_t>(d_peEdge.size(), 1));
 		st.prod_beg = localRanges ? d_prodBeg.data() : d_prodPtr.data(); st.prod_end = localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1;
 		st.pe_beg = localRanges ? d_peBeg.data() : d_pePtr.data(); st.pe_end = localRanges ? d_peEnd.data() : d_pePtr.data() + 1;
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
-		if (schurU) { d_eu.resize((size_t)18 * E); d_eu.zero(stream); st.e_u = d_eu.data(); }
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
@@ -1373,7 +1381,7 @@ struct cuba_hip_solver
 			topo::launch_segment_subrange(d_prodPtr.data(), nblk, d_prodLm.data(), lo, hi, d_prodBeg.data(), d_prodEnd.data(), stream);
 		}
 		topo::launch_od_keys(localRanges ? d_prodBeg.data() : d_prodPtr.data(), localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1,
-			d_blkrow.data(), d_colind.data(), nblk, farOffset(), d_k32a.data(), d_v32a.data(), cnt, stream);
+			d_blkrow.data(), d_colind.data(), nblk, farOffset(), BP_HEAVY, d_k32a.data(), d_v32a.data(), cnt, stream);
 		if (nblk) HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), nblk, 32, stream));
 		topo::launch_copy_u32_to_int(d_v32b.data(), d_odBlocks.data(), nblk, stream);
 		// 7. symmetric adjacency: the lower part of every row comes from the (column, row)-sorted list of the off-diagonal blocks
@@ -1420,7 +1428,7 @@ struct cuba_hip_solver
 			return;
 		}
 		reorderTried = false;
-		diagProdBlocks = hc[topo::CNT_DIAGPROD];
+		diagProdBlocks = hc[topo::CNT_DIAGPROD]; heavyBlocks = hc[topo::CNT_NHEAVY];
 		publishStructure(nblk, nWaves, nBig, hc[topo::CNT_NOD], cc.nc > 0 ? hc[topo::CNT_NCB] : 0, ellM, ellOver, cc);
 		hostPatternValid = false;
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] structure (device): nblk %d products %lld waves %d big %d od %d coarse blocks %d max row %d\n",
@@ -2103,7 +2111,6 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
-		else if (k == "schur_u") { s->schurU = value != 0; s->haveStructure = false; }
 		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }

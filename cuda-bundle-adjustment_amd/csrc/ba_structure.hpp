@@ -30,7 +30,7 @@ hipError_t exclusive_scan_i64(void* temp, size_t tempBytes, const long long* in,
 hipError_t inclusive_scan_i32(void* temp, size_t tempBytes, const int* in, int* out, size_t n, hipStream_t s);
 
 // counters the kernels fill (one device int each), read back by the host at its synchronisation points
-enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_MAXH, CNT_MAXJ, CNT_COUNT = 16 };
+enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_MAXH, CNT_MAXJ, CNT_NHEAVY, CNT_COUNT = 16 };
 
 // ---- A. edges ------------------------------------------------------------------------------------------------------
 // keys[e] = landmark << 32 | pose, vals[e] = e; counters[CNT_BAD] = 1 / 2 / 3 for an index out of range / a bad dimension /
@@ -69,8 +69,11 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 // blocks with products, longest list first (stable): sort keys + values; counters[CNT_NOD] = their number
 // counters[CNT_FARBLOCKS] = number of blocks more than farOffset block columns off the diagonal (pose order check)
 // counters[CNT_DIAGPROD] = number of DIAGONAL blocks with products (a landmark observed twice by one pose)
+// counters[CNT_NHEAVY] = number of blocks with more than `heavy` products (the first ones of the sorted list)
 // (prod_beg[k] .. prod_end[k] = the product range of block k this handle evaluates: prod_ptr / prod_ptr + 1 for the whole graph)
-void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
+void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, int heavy, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
+// e_slot[pe_edge[k]] = k (e_slot pre-filled with -1): the record slot of an edge is its position in the per-pose edge lists
+void launch_slot_scatter(const int* pe_edge, size_t n, int* e_slot, hipStream_t s);
 // beg[s] .. end[s] = the items of segment s (ptr[s] .. ptr[s + 1], values ascending) whose value lies in [vlo, vhi)
 void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s);
 // pose indices of the caller-order edge array through a map of the free poses (fixed poses keep their index)

@@ -1,16 +1,11 @@
 #!/bin/bash
-# A/B of the Schur block pass: camera-frame form (default), the same with loads one trip ahead, and the Jacobian form of rounds 1-2.
-#   gpurun -- bash scripts/experiments/r03_block_pass_form.sh
-out=gpurun_out/r03x_block_pass_form.txt
+# Kernel times of the four bench shapes (A/B of builds: run it on each).
+#   gpurun -- bash scripts/experiments/r03_block_pass_form.sh <tag>
+out=gpurun_out/${1:-r03y}_kernel_times.txt
 mkdir -p gpurun_out; : > $out
-for shape in kitti00 kitti07 s2m; do
-  for v in "" CUBA_HIP_BLOCK_PASS_PIPELINED=1 CUBA_HIP_BLOCK_PASS_JACOBIANS=1; do
-    echo "== $shape ${v:-camera-frame form}" >> $out
-    env $v timeout 300 python scripts/kernel_times.py $shape >> $out 2>&1
-  done
+for shape in kitti00 kitti07 s2m g4m; do
+  timeout 300 python scripts/kernel_times.py $shape 2>&1 | grep -v amdgpu.ids >> $out
 done
-echo "== mixed precision, kitti00" >> $out
-for v in "" CUBA_HIP_BLOCK_PASS_PIPELINED=1 CUBA_HIP_BLOCK_PASS_JACOBIANS=1; do
-  env $v timeout 300 python scripts/kernel_times.py kitti00 mixed_precision=1 >> $out 2>&1
-done
+timeout 300 python scripts/kernel_times.py kitti00 mixed_precision=1 2>&1 | grep -v amdgpu.ids >> $out
+CUBA_HIP_SEPARATE_SCHUR_PASSES=1 timeout 300 python scripts/kernel_times.py kitti00 2>&1 | grep -v amdgpu.ids | sed 's/^/separate passes: /' >> $out
 cat $out

@@ -281,21 +281,6 @@ def test_schur_paths_agree_and_default_is_reproducible(solvers, small_graph):
     assert all(np.array_equal(a, b) for a, b in zip(h1.state(), h2.state()))
 
 
-def test_schur_u_experiment_agrees(solvers, small_graph):
-    """Option schur_u = 1 (round-3 experiment, measured SLOWER: 166 vs 116 us at KITTI-00, profiles/r03v_schur_u_experiment.txt): the
-    landmark pass stores U_e = w' JP^T JL C per edge (C C^T = inv(Hll + lambda I)) and the block pass forms sum U_a U_b^T.  Same
-    reduced system to rounding, same LM trajectory."""
-    HipSolver, OracleSolver = solvers
-    fp = flatten(small_graph)
-    a, b = HipSolver(fp, RK_HUBER, schur_u=1), HipSolver(fp, RK_HUBER)
-    lam = 1e-5 * a.max_diagonal()
-    for h in (a, b):
-        h.set_lambda(lam); h.schur()
-    (_, _, va), (_, _, vb) = a.hsc(), b.hsc()
-    assert rel(va, vb) < 1e-12 and rel(a.array("bsc"), b.array("bsc")) < 1e-12
-    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
-    assert rel(HipSolver(fp, RK_HUBER, schur_u=1).optimize(6)["chi2"], ref) < CHI2_TOL
-
 
 def test_preconditioner_modes_agree(solvers, small_fp):
     """Block-Jacobi PCG and the two-level (aggregate coarse correction) PCG solve the same system."""
