@@ -690,43 +690,38 @@ void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const Dev
 
 // ===================================================================================================
 // Destination-major Schur assembly (default).  No atomics, no per-landmark pair loops:
-//   1. lm_pass_kernel     lane = edge, wave = landmarks: Hll/bl reduced in LDS, (Hll+lambda I)^-1, and one 128-byte
-//                         linearisation record per edge {Xc, w' (sign = stereo), inv, inv bl, r}, scattered into POSE-major slots;
-//   2. pose_pass_kernel   wave = free pose: streams the pose's records (no gather), every edge contributes Hpp_e - W_e Hpl_e^T,
-//                         bp_e, bp_e - Hpl_e Hll^-1 bl to registers, one wave reduction, plain stores;
+//   1. lm_pass_kernel     lane = edge, wave = landmarks: Hll/bl reduced in LDS, (Hll+lambda I)^-1, and a
+//                         64-byte linearisation record per edge {Xc, w' (sign = stereo), r, landmark};
+//   2. pose_pass_kernel   wave = free pose: every edge of the pose contributes Hpp_e - W_e Hpl_e^T, bp_e,
+//                         bp_e - Hpl_e Hll^-1 bl to registers, one wave reduction, plain stores;
 //   3. block_pass_kernel  16 lanes (a whole wave for blocks with more than BP_HEAVY products) = one off-diagonal block (a,b):
 //                         the products of all landmarks seen by both poses, rebuilt from the two records in camera-frame form
 //                         (no Hpl tile is ever stored), reduced over the lanes, one plain store.
 // Every output has exactly one writer and a fixed summation order => results are reproducible bit for bit.
 // ===================================================================================================
-constexpr int REC = 16;   // numbers per edge record: [0..2] Xc, [3] w' (sign bit = stereo), [4..9] inv(Hll + lambda I), [10..12] inv bl, [13..15] r
+constexpr int REC = 8;   // numbers per edge record: [0..2] Xc, [3] w' (sign bit = stereo), [4..6] r, [7] landmark (integer bits)
 
 // Record element type ET = the arithmetic type of the pose / block passes: Scalar, or float for the mixed-precision mode
 // of the fp64 library (option "mixed_precision": records and per-edge Jacobian arithmetic in fp32, every accumulation that
 // crosses edges and the whole reduced system in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29, applied only
-// where it is safe).
+// where it is safe).  The landmark travels as an integer bit pattern, exact for any landmark count.
+__device__ __forceinline__ double tag_encode(int tag, double) { return __longlong_as_double((long long)tag); }
+__device__ __forceinline__ float tag_encode(int tag, float) { return __int_as_float(tag); }
+__device__ __forceinline__ int tag_decode(double v) { return (int)__double_as_longlong(v); }
+__device__ __forceinline__ int tag_decode(float v) { return __float_as_int(v); }
 __device__ __forceinline__ bool sign_flag(double v) { return __double_as_longlong(v) < 0; }
 __device__ __forceinline__ bool sign_flag(float v) { return __float_as_int(v) < 0; }
 __device__ __forceinline__ double abs_value(double v) { return __builtin_fabs(v); }
 __device__ __forceinline__ float abs_value(float v) { return __builtin_fabsf(v); }
 
-// first and last part of a record: what the lane's own edge gives
 template <typename ET>
-__device__ __forceinline__ void write_record_edge(Scalar* base, size_t slot, const Scalar Xc[3], Scalar wr, const Scalar r[3], bool stereo)
+__device__ __forceinline__ void write_record(Scalar* base, size_t e, const Scalar Xc[3], Scalar wr, const Scalar r[3], int il, bool stereo)
 {
-	ET* rec = reinterpret_cast<ET*>(base) + REC * slot;
+	ET* rec = reinterpret_cast<ET*>(base) + REC * e;
 	const ET w = (ET)wr;
 	rec[0] = (ET)Xc[0]; rec[1] = (ET)Xc[1]; rec[2] = (ET)Xc[2]; rec[3] = stereo ? -w : w;       // (-0.0 keeps the flag of a zero weight)
-	rec[13] = (ET)r[0]; rec[14] = (ET)r[1]; rec[15] = (ET)r[2];
-}
-
-// middle part: inv(Hll + lambda I) and inv bl of the edge's landmark (zeros for a fixed landmark)
-template <typename ET>
-__device__ __forceinline__ void write_record_landmark(Scalar* base, size_t slot, const Scalar v[9])
-{
-	ET* rec = reinterpret_cast<ET*>(base) + REC * slot;
-#pragma unroll
-	for (int k = 0; k < 9; k++) rec[4 + k] = (ET)v[k];
+	rec[4] = (ET)r[0]; rec[5] = (ET)r[1]; rec[6] = (ET)r[2];
+	rec[7] = tag_encode(il, ET());
 }
 
 template <typename ET>
@@ -759,7 +754,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	const int e0 = g.lm_ptr[lm0], e1 = g.lm_ptr[lm1];
 	const int e = e0 + lane;
 	const bool valid = e < e1;
-	int il = lm0, seg0 = 0, seg1 = 0, slot = -1;
+	int il = lm0, seg0 = 0, seg1 = 0;
 	Scalar h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (valid)
 	{
@@ -767,7 +762,6 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		const bool stereo = (pe & STEREO_BIT) != 0;
 		const int ip = pe & ~STEREO_BIT;
 		il = g.e_lm[e];
-		slot = st.e_slot[e];
 		Scalar q[4], t[3], cam[5], Xw[3], meas[3], Xc[3];
 		EdgeLin L;
 		load_pose(g, ip, q, t, cam);
@@ -779,7 +773,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		const int kind = stereo ? g.rk[1].kind : g.rk[0].kind;
 		const Scalar delta = stereo ? g.rk[1].delta : g.rk[0].delta;
 		const Scalar wr = w * robust_weight(kind, delta, w * ss);
-		if (slot >= 0) write_record_edge<ET>(st.e_rec, (size_t)slot, Xc, wr, L.r, stereo);
+		write_record<ET>(st.e_rec, (size_t)e, Xc, wr, L.r, il, stereo);
 		if (il < g.Lf)
 		{
 			const Rot3 R = quat_to_rot(q[0], q[1], q[2], q[3]);
@@ -801,7 +795,6 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 	wave_lds_sync();
 	const bool head = valid && il < g.Lf && lane == seg0;
 	Scalar m = 0;
-	Scalar out[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // MODE 1, head lanes: inv and inv bl of the landmark
 	if (head)
 	{
 		Scalar H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -817,32 +810,15 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		}
 		else
 		{
+			Scalar inv[6];
 			H[0] += lambda; H[3] += lambda; H[5] += lambda;
-			sym3_inverse(H, out);
+			sym3_inverse(H, inv);
+			Scalar* li = sys.lm_inv + 8 * (size_t)il;       // the block pass reads this copy: 64-byte rows, one sector per gather
 #pragma unroll
-			for (int k = 0; k < 6; k++) ls[k] = out[k];
+			for (int k = 0; k < 6; k++) { ls[k] = inv[k]; li[k] = inv[k]; }
+			li[6] = 0; li[7] = 0;                            // (whole sectors: no read-modify-write at the memory side)
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-				out[6 + i] = out[sym3_idx(i, 0)] * H[6] + out[sym3_idx(i, 1)] * H[7] + out[sym3_idx(i, 2)] * H[8];
-		}
-	}
-	if (MODE == 1)
-	{
-		// the landmark's part of the records: from the head lane to the landmark's edges through LDS
-		wave_lds_sync();                 // every segment sum has been read
-		if (head)
-#pragma unroll
-			for (int k = 0; k < 9; k++) lds[lane * 9 + k] = out[k];
-		wave_lds_sync();
-		if (slot >= 0)
-		{
-			Scalar v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-			if (il < g.Lf)
-#pragma unroll
-				for (int k = 0; k < 9; k++) v[k] = lds[seg0 * 9 + k];
-			write_record_landmark<ET>(st.e_rec, (size_t)slot, v);
 		}
 	}
 	if (MODE == 0)
@@ -857,7 +833,6 @@ template <int MODE, typename ET>
 __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
 {
 	__shared__ Scalar red[4][9];
-	__shared__ Scalar outv[9];
 	const int il = st.big_lm[blockIdx.x];
 	const int e0 = g.lm_ptr[il], e1 = g.lm_ptr[il + 1];
 	Scalar acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -872,8 +847,7 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 		for (int i = 0; i < 3; i++) Xw[i] = g.Xw[3 * (size_t)il + i];
 		quat_rotate(q, Xw, Xc);
 		Xc[0] += t[0]; Xc[1] += t[1]; Xc[2] += t[2];
-		const int slot = st.e_slot[e];
-		if (slot >= 0) write_record_edge<ET>(st.e_rec, (size_t)slot, Xc, le.wr, le.lin.r, le.stereo);
+		write_record<ET>(st.e_rec, (size_t)e, Xc, le.wr, le.lin.r, il, le.stereo);
 		if (il < g.Lf)
 		{
 			const EdgeLin& L = le.lin;
@@ -892,7 +866,6 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 	if ((threadIdx.x & 63) == 0)
 #pragma unroll
 		for (int k = 0; k < 9; k++) red[threadIdx.x >> 6][k] = acc[k];
-	if (threadIdx.x < 9) outv[threadIdx.x] = 0;
 	__syncthreads();
 	if (threadIdx.x == 0 && il < g.Lf)
 	{
@@ -911,26 +884,12 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 			Scalar inv[6];
 			H[0] += lambda; H[3] += lambda; H[5] += lambda;
 			sym3_inverse(H, inv);
+			Scalar* li = sys.lm_inv + 8 * (size_t)il;
 #pragma unroll
-			for (int k = 0; k < 6; k++) { ls[k] = inv[k]; outv[k] = inv[k]; }
+			for (int k = 0; k < 6; k++) { ls[k] = inv[k]; li[k] = inv[k]; }
+			li[6] = 0; li[7] = 0;
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-				outv[6 + i] = inv[sym3_idx(i, 0)] * H[6] + inv[sym3_idx(i, 1)] * H[7] + inv[sym3_idx(i, 2)] * H[8];
-		}
-	}
-	if (MODE == 1)
-	{
-		// the landmark's part of its edges' records
-		__syncthreads();
-		Scalar v[9];
-#pragma unroll
-		for (int k = 0; k < 9; k++) v[k] = outv[k];
-		for (int e = e0 + threadIdx.x; e < e1; e += 256)
-		{
-			const int slot = st.e_slot[e];
-			if (slot >= 0) write_record_landmark<ET>(st.e_rec, (size_t)slot, v);
 		}
 	}
 }
@@ -991,21 +950,24 @@ __device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const Devic
 	const int p1 = st.pe_end[ip];
 	for (int p = st.pe_beg[ip] + lane; p < p1; p += 64)
 	{
-		// the record slot of an edge is its position in the pose's list: one 128-byte line per lane, consecutive lanes consecutive lines
-		const ET* rec = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)p;
+		const ET* rec = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.pe_edge[p];
 		CameraFrameEdge<ET> c;
 		camera_frame_edge<ET>(rec, cam, c);
-		const ET r0 = rec[13], r1 = rec[14], r2 = c.stereo ? rec[15] : ET(0);
-		// S = K - M inv M^T (mode 1; the record of an edge to a fixed landmark holds inv = 0, inv bl = 0), v = w' D^T r, v' = v - M inv bl
+		const ET r0 = rec[4], r1 = rec[5], r2 = c.stereo ? rec[6] : ET(0);
+		const int il = tag_decode(rec[7]);
+		// S = K - M inv M^T (mode 1, free landmark), v = w' D^T r, v' = v - M inv bl
 		ET S[6] = { c.k00, 0, c.k02, c.k11, c.k12, c.k22 };
 		ET v[3] = { c.w * c.d00 * (r0 + r2), c.w * c.d11 * r1, c.w * (c.d02 * r0 + c.d12 * r1 + c.d22 * r2) };
 		ET vs[3] = { v[0], v[1], v[2] };
-		if (MODE == 1)
+		if (MODE == 1 && il < g.Lf)
 		{
-			ET M[3][3], P[3][3], inv[6];
-			camera_frame_m<ET>(c, R, M);
+			const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
+			ET M[3][3], P[3][3], inv[6], bl[3];
 #pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = rec[4 + k];
+			for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
+#pragma unroll
+			for (int k = 0; k < 3; k++) bl[k] = (ET)ls[6 + k];
+			camera_frame_m<ET>(c, R, M);
 #pragma unroll
 			for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -1013,12 +975,12 @@ __device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const Devic
 					P[i][k] = M[i][0] * inv[sym3_idx(0, k)] + M[i][1] * inv[sym3_idx(1, k)] + M[i][2] * inv[sym3_idx(2, k)];
 #pragma unroll
 			for (int i = 0; i < 3; i++)
+			{
 #pragma unroll
 				for (int j = i; j < 3; j++)
 					S[sym3_idx(i, j)] -= P[i][0] * M[j][0] + P[i][1] * M[j][1] + P[i][2] * M[j][2];
-			const ET b0 = rec[10], b1 = rec[11], b2 = rec[12];
-#pragma unroll
-			for (int i = 0; i < 3; i++) vs[i] -= M[i][0] * b0 + M[i][1] * b1 + M[i][2] * b2;
+				vs[i] -= P[i][0] * bl[0] + P[i][1] * bl[1] + P[i][2] * bl[2];
+			}
 		}
 		// G^T S G = [[ U [X]x^T, U ], [ ., S ]] with U = [X]x S; upper triangle, acc[c (c + 1) / 2 + r] for r <= c
 		const ET X = c.X[0], Y = c.X[1], Z = c.X[2];
@@ -1146,11 +1108,13 @@ __device__ __forceinline__ void block_pass_group(const DeviceGraph& g, const Dev
 	const int p1 = on ? st.prod_end[blk] : 0;
 	for (int p = (on ? st.prod_beg[blk] : 0) + gl; p < p1; p += GROUP)
 	{
+		// three gathers of one 64-byte sector each, issued together (the landmark comes from the product list, not from a record)
 		const ET* ra = recs + REC * (size_t)st.prod_ea[p];
 		const ET* rb = recs + REC * (size_t)st.prod_eb[p];
+		const Scalar* li = st.inv_rows8 ? sys.lm_inv + 8 * (size_t)st.prod_lm[p] : sys.lm_sys + 9 * (size_t)st.prod_lm[p];
 		ET inv[6];
 #pragma unroll
-		for (int k = 0; k < 6; k++) inv[k] = ra[4 + k];
+		for (int k = 0; k < 6; k++) inv[k] = (ET)li[k];
 		ProductOperand<ET> A, B;
 		product_operand<ET>(ra, Ra, cama, A);
 		product_operand<ET>(rb, Rb, camb, B);

@@ -63,15 +63,16 @@ struct DeviceStructure
 	int nOd = 0;                       // blocks that receive at least one off-diagonal (or duplicate-pose) product
 	int nDiagProd = 0;                 // of these, diagonal blocks (a landmark observed twice by one pose): the block pass then updates what the pose pass stored
 	int* od_blocks = nullptr;          // [nOd] their ids, largest product count first
+	int inv_rows8 = 1;                 // A/B: 0 = the block pass gathers inv(Hll + lambda I) from the 72-byte rows of lm_sys
 	int nHeavy = 0;                    // the first nHeavy of them have more than BP_HEAVY products: a whole wave each in the block pass
 	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
-	int *prod_ea = nullptr, *prod_eb = nullptr;   // record slots (e_slot) of the two edges of each product, in landmark order (ea: row pose, eb: column pose)
+	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)
 	// the ranges of the two lists above that THIS handle walks: prod_ptr / prod_ptr + 1 and pe_ptr / pe_ptr + 1 for a whole graph,
 	// sub-ranges (the lists are in landmark order) for a landmark partition built on the device
 	const int *prod_beg = nullptr, *prod_end = nullptr, *pe_beg = nullptr, *pe_end = nullptr;
-	int* prod_lm = nullptr;            // landmark of each product: set-up only (the sub-ranges of a landmark partition)
-	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids; the position of an edge in pe_edge is its record slot
-	int* e_slot = nullptr;             // [E] record slot of every edge (-1: edge of a fixed pose, no record)
+	int* prod_lm = nullptr;            // landmark of each product (= e_lm[prod_ea]): the block pass then fetches inv(Hll + lambda) beside the
+	                                   // two edge records instead of after them (one memory round trip per product instead of two)
+	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
 	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
@@ -83,13 +84,7 @@ struct DeviceStructure
 	int* ell_loc = nullptr;                        // parallel to ell: local (halo) index of the entry's column
 	int* own_loc = nullptr;                        // [Pf] local index of a pose in its OWN aggregate's halo list
 	int hmax = 0, jmax = 0;
-	// per-edge linearisation records, POSE-major (slot = position in pe_edge), 16 numbers = one 128-byte line in fp64:
-	//   [0..2] Xc   [3] w' (sign bit = stereo)   [4..9] inv(Hll + lambda I) of the edge's landmark   [10..12] inv * bl   [13..15] r
-	// The landmark pass scatters them (one full line per lane); the pose pass streams a pose's records with no gather at all; the block
-	// pass gathers one line for edge a (Xc, w', inv) and 32 bytes for edge b, and the slots of a block's products ascend in both poses'
-	// runs, so neighbouring lanes hit neighbouring lines (round 3: every distinct gathered line per product costs the block pass
-	// ~15 us at KITTI-00, the arithmetic nothing -- profiles/r03x_block_pass_where.txt).
-	Scalar* e_rec = nullptr;           // [16*slots]
+	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w' (sign bit = stereo), r[3], landmark (integer bits)}
 	int mixed = 0;                     // fp64 library only: 1 = records and the per-edge arithmetic of the pose / block passes in fp32
 };
 
@@ -101,6 +96,8 @@ struct DeviceSystem
 	Scalar* bsc = nullptr;     // [6*Pf]     }
 	Scalar* bp = nullptr;      // [6*Pf]     }
 	Scalar* lm_sys = nullptr;  // [9*Lf]  6 unique of Hll or inv(Hll+lambda I), then bl
+	Scalar* lm_inv = nullptr;  // [8*Lf]  copy of inv(Hll+lambda I) in 64-byte rows for the block pass (a 48-byte gather from the 72-byte rows of lm_sys
+	                           // straddles two 64-byte sectors three times out of four, and the pass pays per sector: profiles/r03x_block_pass_where.txt)
 	Scalar* xp = nullptr;      // [6*Pf]
 	Scalar* xl = nullptr;      // [3*Lf]
 	Scalar* parts = nullptr;   // per-workgroup partial sums (first stage of the deterministic global reductions)

@@ -148,7 +148,7 @@ struct cuba_hip_solver
 	DevBuf<long long> d_bigOfs, d_lmPairBase;
 	DevBuf<Scalar> d_bigHpl;
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
-	DevBuf<Scalar> d_parts, d_lmSys, d_xp, d_xl, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
+	DevBuf<Scalar> d_parts, d_lmSys, d_lmInv, d_xp, d_xl, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
@@ -163,7 +163,7 @@ struct cuba_hip_solver
 	bool precondFp32 = sizeof(Scalar) == 8;
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
-	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge, d_eSlot;
+	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
 	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
 	// single-kernel PCG iteration: halo lists of the aggregates + its vectors
 	DevBuf<int> d_halN, d_halNJ, d_halPose, d_halAloc, d_haggId, d_ellLoc, d_ownLoc;
@@ -963,7 +963,7 @@ struct cuba_hip_solver
 		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += k >= 0 && blkRow[k] == h_colind[k];
 		heavyBlocks = 0;        // (the list is sorted by length; an XCD-aware experiment order is not: all blocks then take the 16-lane path)
 		if (!std::getenv("CUBA_HIP_BLOCK_ORDER_XCD") && !std::getenv("CUBA_HIP_BLOCK_ORDER_ROW"))
-			for (int k : odBlocks) heavyBlocks += prodPtr[k + 1] - prodPtr[k] > BP_HEAVY;
+			for (int k : odBlocks) heavyBlocks += prodPtr[k + 1] - prodPtr[k] > heavyThreshold();
 		publishStructure(nblk, (int)waveLm.size() / 2, (int)bigLm.size(), (int)odBlocks.size(), (int)cbI.size(), ellM, ellOver, cc);
 		hostPatternValid = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -999,10 +999,10 @@ struct cuba_hip_solver
 	void allocSystem(int nblk, const CoarseCfg& c)
 	{
 		d_red.resize((size_t)36 * nblk + (size_t)12 * Pf);
-		d_lmSys.resize((size_t)9 * Lf); d_xp.resize((size_t)6 * Pf); d_xl.resize((size_t)3 * Lf);
+		d_lmSys.resize((size_t)9 * Lf); d_lmInv.resize((size_t)8 * std::max(Lf, 1)); d_erec.resize((size_t)8 * E); d_xp.resize((size_t)6 * Pf); d_xl.resize((size_t)3 * Lf);
 		d_minv.resize((size_t)36 * Pf);
 		d_r.resize((size_t)6 * Pf); d_z.resize((size_t)6 * Pf); d_p0.resize((size_t)6 * Pf); d_p1.resize((size_t)6 * Pf); d_ap.resize((size_t)6 * Pf);
-		d_red.zero(stream); d_lmSys.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
+		d_red.zero(stream); d_lmSys.zero(stream); d_lmInv.zero(stream); d_xp.zero(stream); d_xl.zero(stream);
 		reducedZeroed = true;
 		for (auto& b : d_coarse) b.resize((size_t)36 * c.cl * c.cl * c.nc * c.nc);
 		{
@@ -1019,6 +1019,7 @@ struct cuba_hip_solver
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
 	int diagProdBlocks = 0;      // diagonal blocks with products (duplicate observations), set by the structure builders
 	int heavyBlocks = 0;         // blocks with more than BP_HEAVY products (the first ones of d_odBlocks), set by the structure builders
+	static int heavyThreshold() { static const int v = std::getenv("CUBA_HIP_BP_HEAVY") ? std::atoi(std::getenv("CUBA_HIP_BP_HEAVY")) : BP_HEAVY; return v; }   // (A/B knob)
 	void publishStructure(int nblk, int nWaves, int nBig, int nOd, int nCb, int ellM, int ellOver, const CoarseCfg& c)
 	{
 		const int agg = c.agg, cl = c.cl, nc = c.nc, spmvRows = c.spmvRows;
@@ -1031,23 +1032,20 @@ struct cuba_hip_solver
 		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
 		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data(); st.nHeavy = std::min(heavyBlocks, nOd);
+		// (whole-wave blocks shorten the longest dependent chain of the block pass: 51 -> 37 us at KITTI-07; on graphs whose pass is bound by its
+		// gathers they only add waves: 114 -> 122 us at KITTI-00, 405 -> 411 us at S2M -- profiles/r03z_block_pass_ab.txt)
+		if (d_prodEa.size() > ((size_t)1 << 19) && !std::getenv("CUBA_HIP_BP_HEAVY")) st.nHeavy = 0;
+		st.inv_rows8 = std::getenv("CUBA_HIP_BLOCK_PASS_INV_FROM_LM_SYS") ? 0 : 1;
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
-		st.prod_lm = localRanges ? d_prodLm.data() : nullptr;          // (only the set-up of a device-built partition needs the landmarks of the products)
-		// record slots: the builders leave edge ids in the product lists; the kernels want the position of each edge in the per-pose lists
-		d_eSlot.resize((size_t)E);
-		if (E > 0) (void)hipMemsetAsync(d_eSlot.data(), 0xff, (size_t)E * sizeof(int), stream);
-		topo::launch_slot_scatter(d_peEdge.data(), d_peEdge.size(), d_eSlot.data(), stream);
-		topo::launch_gather_int(d_prodEa.data(), d_eSlot.data(), d_prodEa.size(), d_prodEa.data(), stream);
-		topo::launch_gather_int(d_prodEb.data(), d_eSlot.data(), d_prodEb.size(), d_prodEb.data(), stream);
-		st.e_slot = d_eSlot.data();
-		d_erec.resize((size_t)16 * std::max<size_t>(d_peEdge.size(), 1));
+		if (!localRanges) fillProdLm();          // (a device-built partition needed it earlier)
+		st.prod_lm = d_prodLm.data();
 		st.prod_beg = localRanges ? d_prodBeg.data() : d_prodPtr.data(); st.prod_end = localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1;
 		st.pe_beg = localRanges ? d_peBeg.data() : d_pePtr.data(); st.pe_end = localRanges ? d_peEnd.data() : d_pePtr.data() + 1;
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
-		sys.lm_sys = d_lmSys.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = slotsDev; sys.host_flags = flagsDev; sys.parts = d_parts.data();
+		sys.lm_sys = d_lmSys.data(); sys.lm_inv = d_lmInv.data(); sys.xp = d_xp.data(); sys.xl = d_xl.data(); sys.slots = slotsDev; sys.host_flags = flagsDev; sys.parts = d_parts.data();
 		sys.maxdiag = d_maxdiag.data(); sys.fail = d_fail.data();
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
 		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data(); sys.ticket = d_ticket.data();
@@ -1381,7 +1379,7 @@ struct cuba_hip_solver
 			topo::launch_segment_subrange(d_prodPtr.data(), nblk, d_prodLm.data(), lo, hi, d_prodBeg.data(), d_prodEnd.data(), stream);
 		}
 		topo::launch_od_keys(localRanges ? d_prodBeg.data() : d_prodPtr.data(), localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1,
-			d_blkrow.data(), d_colind.data(), nblk, farOffset(), BP_HEAVY, d_k32a.data(), d_v32a.data(), cnt, stream);
+			d_blkrow.data(), d_colind.data(), nblk, farOffset(), heavyThreshold(), d_k32a.data(), d_v32a.data(), cnt, stream);
 		if (nblk) HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), nblk, 32, stream));
 		topo::launch_copy_u32_to_int(d_v32b.data(), d_odBlocks.data(), nblk, stream);
 		// 7. symmetric adjacency: the lower part of every row comes from the (column, row)-sorted list of the off-diagonal blocks

@@ -220,13 +220,6 @@ __global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_beg, const i
 	if ((threadIdx.x & 63) == 0 && nh) atomicAdd(&counters[CNT_NHEAVY], nh);
 }
 
-// record slots: the position of an edge in the per-pose edge lists
-__global__ __launch_bounds__(T) void slot_scatter_kernel(const int* __restrict__ pe_edge, size_t n, int* __restrict__ e_slot)
-{
-	const size_t k = (size_t)blockIdx.x * T + threadIdx.x;
-	if (k < n) e_slot[pe_edge[k]] = (int)k;
-}
-
 __global__ __launch_bounds__(T) void remap_poses_kernel(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut)
 {
 	const int e = blockIdx.x * T + threadIdx.x;
@@ -548,11 +541,6 @@ void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo,
 void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, int heavy, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)
 {
 	if (nblk > 0) hipLaunchKernelGGL(od_keys_kernel, grid_for(nblk), dim3(T), 0, s, prod_beg, prod_end, blkrow, colind, nblk, farOffset, heavy, keys, vals, counters);
-}
-
-void launch_slot_scatter(const int* pe_edge, size_t n, int* e_slot, hipStream_t s)
-{
-	if (n > 0) hipLaunchKernelGGL(slot_scatter_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, s, pe_edge, n, e_slot);
 }
 
 void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s)

@@ -72,8 +72,6 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 // counters[CNT_NHEAVY] = number of blocks with more than `heavy` products (the first ones of the sorted list)
 // (prod_beg[k] .. prod_end[k] = the product range of block k this handle evaluates: prod_ptr / prod_ptr + 1 for the whole graph)
 void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, int heavy, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
-// e_slot[pe_edge[k]] = k (e_slot pre-filled with -1): the record slot of an edge is its position in the per-pose edge lists
-void launch_slot_scatter(const int* pe_edge, size_t n, int* e_slot, hipStream_t s);
 // beg[s] .. end[s] = the items of segment s (ptr[s] .. ptr[s + 1], values ascending) whose value lies in [vlo, vhi)
 void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s);
 // pose indices of the caller-order edge array through a map of the free poses (fixed poses keep their index)
