@@ -110,9 +110,7 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    as ONE pass over the edges -- two launches between a converged solve and the LM decision instead of four; 0 = the four-launch tail), "speculate_tail" (default 0; 1 = optimize()
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
    was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "schur_atomic"
-   (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "schur_u" (default 0; 1 = round-3 experiment: the landmark pass also stores
-   U_e = w' JP^T JL C per edge (C C^T = inv(Hll + lambda I), 144 bytes) and the block pass sums U_a U_b^T -- the reference's Hpl Hll^-1 layout
-   without its atomics; a third of the flops, but 1.6 x the bytes through the fabric: measured 166 vs 116 us at KITTI-00), "mixed_precision" (fp64 library
+   (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "mixed_precision" (fp64 library
    only, default 0; 1 = the per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in
    fp32, every sum over edges, the reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29,
    applied where it is second-order for the objective), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history), "pose_reorder" (default 1: when most blocks of the reduced matrix lie far off its diagonal in
