@@ -933,44 +933,6 @@ __device__ __forceinline__ void camera_frame_m(const CameraFrameEdge<ET>& c, con
 	}
 }
 
-// the sums of the pose pass from the camera-frame terms of one edge: G^T S G (upper triangle, acc[c (c + 1) / 2 + r] for r <= c),
-// G^T v -> acc[21..26], G^T v' -> acc[27..32]
-template <int MODE, typename ET>
-__device__ __forceinline__ void pose_sums_accumulate(const CameraFrameEdge<ET>& c, const ET (&S)[6], const ET (&v)[3], const ET (&vs)[3], Scalar (&acc)[33])
-{
-	// G^T S G = [[ U [X]x^T, U ], [ ., S ]] with U = [X]x S
-	const ET X = c.X[0], Y = c.X[1], Z = c.X[2];
-	ET U[3][3];
-#pragma unroll
-	for (int j = 0; j < 3; j++)
-	{
-		const ET s0 = S[sym3_idx(0, j)], s1 = S[sym3_idx(1, j)], s2 = S[sym3_idx(2, j)];
-		U[0][j] = Y * s2 - Z * s1;
-		U[1][j] = Z * s0 - X * s2;
-		U[2][j] = X * s1 - Y * s0;
-	}
-#pragma unroll
-	for (int i = 0; i < 3; i++)
-	{
-		// row i of U [X]x^T = X x U_i
-		const ET t[3] = { Y * U[i][2] - Z * U[i][1], Z * U[i][0] - X * U[i][2], X * U[i][1] - Y * U[i][0] };
-#pragma unroll
-		for (int j = i; j < 3; j++) acc[j * (j + 1) / 2 + i] += (Scalar)t[j];
-#pragma unroll
-		for (int j = 0; j < 3; j++) acc[(3 + j) * (4 + j) / 2 + i] += (Scalar)U[i][j];
-#pragma unroll
-		for (int j = i; j < 3; j++) acc[(3 + j) * (4 + j) / 2 + 3 + i] += (Scalar)S[sym3_idx(i, j)];
-	}
-	// G^T v = [X x v ; v]
-	acc[21] += (Scalar)(Y * v[2] - Z * v[1]); acc[22] += (Scalar)(Z * v[0] - X * v[2]); acc[23] += (Scalar)(X * v[1] - Y * v[0]);
-	acc[24] += (Scalar)v[0]; acc[25] += (Scalar)v[1]; acc[26] += (Scalar)v[2];
-	if (MODE == 1)
-	{
-		acc[27] += (Scalar)(Y * vs[2] - Z * vs[1]); acc[28] += (Scalar)(Z * vs[0] - X * vs[2]); acc[29] += (Scalar)(X * vs[1] - Y * vs[0]);
-		acc[30] += (Scalar)vs[0]; acc[31] += (Scalar)vs[1]; acc[32] += (Scalar)vs[2];
-	}
-}
-
 // wave = free pose: diagonal block (upper triangle), bp, bsc.  ET = record / per-edge arithmetic type; sums over edges are
 // always accumulated in Scalar.
 template <int MODE, typename ET>
@@ -1020,7 +982,37 @@ __device__ __forceinline__ void pose_pass_body(const DeviceGraph& g, const Devic
 				vs[i] -= P[i][0] * bl[0] + P[i][1] * bl[1] + P[i][2] * bl[2];
 			}
 		}
-		pose_sums_accumulate<MODE, ET>(c, S, v, vs, acc);
+		// G^T S G = [[ U [X]x^T, U ], [ ., S ]] with U = [X]x S; upper triangle, acc[c (c + 1) / 2 + r] for r <= c
+		const ET X = c.X[0], Y = c.X[1], Z = c.X[2];
+		ET U[3][3];
+#pragma unroll
+		for (int j = 0; j < 3; j++)
+		{
+			const ET s0 = S[sym3_idx(0, j)], s1 = S[sym3_idx(1, j)], s2 = S[sym3_idx(2, j)];
+			U[0][j] = Y * s2 - Z * s1;
+			U[1][j] = Z * s0 - X * s2;
+			U[2][j] = X * s1 - Y * s0;
+		}
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+		{
+			// row i of U [X]x^T = X x U_i
+			const ET t[3] = { Y * U[i][2] - Z * U[i][1], Z * U[i][0] - X * U[i][2], X * U[i][1] - Y * U[i][0] };
+#pragma unroll
+			for (int j = i; j < 3; j++) acc[j * (j + 1) / 2 + i] += (Scalar)t[j];
+#pragma unroll
+			for (int j = 0; j < 3; j++) acc[(3 + j) * (4 + j) / 2 + i] += (Scalar)U[i][j];
+#pragma unroll
+			for (int j = i; j < 3; j++) acc[(3 + j) * (4 + j) / 2 + 3 + i] += (Scalar)S[sym3_idx(i, j)];
+		}
+		// G^T v = [X x v ; v]
+		acc[21] += (Scalar)(Y * v[2] - Z * v[1]); acc[22] += (Scalar)(Z * v[0] - X * v[2]); acc[23] += (Scalar)(X * v[1] - Y * v[0]);
+		acc[24] += (Scalar)v[0]; acc[25] += (Scalar)v[1]; acc[26] += (Scalar)v[2];
+		if (MODE == 1)
+		{
+			acc[27] += (Scalar)(Y * vs[2] - Z * vs[1]); acc[28] += (Scalar)(Z * vs[0] - X * vs[2]); acc[29] += (Scalar)(X * vs[1] - Y * vs[0]);
+			acc[30] += (Scalar)vs[0]; acc[31] += (Scalar)vs[1]; acc[32] += (Scalar)vs[2];
+		}
 	}
 #pragma unroll
 	for (int k = 0; k < 33; k++) acc[k] = wave_sum(acc[k]);
@@ -1063,11 +1055,16 @@ __device__ __forceinline__ void product_operand(const ET* rec, const Rot3T<ET>& 
 	camera_frame_m<ET>(c, R, o.M);
 }
 
-// T += G_a^T [P M_b^T] G_b with P = M_a inv (3x3), Xa / Xb the camera-frame points of the two edges
 template <typename ET>
-__device__ __forceinline__ void product_accumulate_p(const ET Xa[3], const ET (&P)[3][3], const ProductOperand<ET>& B, ET (&T)[6][6])
+__device__ __forceinline__ void product_accumulate(const ProductOperand<ET>& A, const ProductOperand<ET>& B, const ET inv[6], ET (&T)[6][6])
 {
-	ET W[3][6];
+	// N = M_a inv M_b^T
+	ET P[3][3], W[3][6];
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int k = 0; k < 3; k++)
+			P[i][k] = A.M[i][0] * inv[sym3_idx(0, k)] + A.M[i][1] * inv[sym3_idx(1, k)] + A.M[i][2] * inv[sym3_idx(2, k)];
 #pragma unroll
 	for (int i = 0; i < 3; i++)
 	{
@@ -1082,23 +1079,11 @@ __device__ __forceinline__ void product_accumulate_p(const ET Xa[3], const ET (&
 #pragma unroll
 	for (int c = 0; c < 6; c++)
 	{
-		T[0][c] += Xa[1] * W[2][c] - Xa[2] * W[1][c];
-		T[1][c] += Xa[2] * W[0][c] - Xa[0] * W[2][c];
-		T[2][c] += Xa[0] * W[1][c] - Xa[1] * W[0][c];
+		T[0][c] += A.X[1] * W[2][c] - A.X[2] * W[1][c];
+		T[1][c] += A.X[2] * W[0][c] - A.X[0] * W[2][c];
+		T[2][c] += A.X[0] * W[1][c] - A.X[1] * W[0][c];
 		T[3][c] += W[0][c]; T[4][c] += W[1][c]; T[5][c] += W[2][c];
 	}
-}
-
-template <typename ET>
-__device__ __forceinline__ void product_accumulate(const ProductOperand<ET>& A, const ProductOperand<ET>& B, const ET inv[6], ET (&T)[6][6])
-{
-	ET P[3][3];
-#pragma unroll
-	for (int i = 0; i < 3; i++)
-#pragma unroll
-		for (int k = 0; k < 3; k++)
-			P[i][k] = A.M[i][0] * inv[sym3_idx(0, k)] + A.M[i][1] * inv[sym3_idx(1, k)] + A.M[i][2] * inv[sym3_idx(2, k)];
-	product_accumulate_p<ET>(A.X, P, B, T);
 }
 
 // grp = position in st.od_blocks (or -1: idle lanes), gl = lane within the group
@@ -1203,174 +1188,6 @@ __global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceSt
 	else block_pass_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Row pass (default when it applies): pose pass and block pass of ONE free pose a in one workgroup.
-//   phase 1  the 256 threads walk a's edges once (record + landmark system gathered, as the pose pass does): the pose sums
-//            (diagonal block, bp, bsc) AND, per edge, {Xc_a, P_a = M_a inv(Hll + lambda I)} into LDS;
-//   phase 2  the products of the row's blocks (a, b > a) take their a-side from LDS -- one LDS row instead of two gathered lines
-//            (record a, landmark inverse) and 27 multiply-adds less per product -- and gather only record b.
-// The block pass alone is bound by its divergent gathers (~15 us per distinct gathered line per product at KITTI-00,
-// profiles/r03x_block_pass_where.txt): this takes two of the three lines away and gives the pose pass four waves per pose.
-// st.prod_apos[p] = position of the product's edge a in a's edge list; whole waves take the row's blocks with more than
-// BP_HEAVY products, 16-lane groups the others.
-// ---------------------------------------------------------------------------------------------------
-constexpr int ROW_REC = 12;     // LDS numbers per edge of the row pose: Xc[3], P[3][3]
-
-__host__ __device__ inline size_t row_pass_lds_bytes(int maxEdges, size_t elemSize) { return (size_t)maxEdges * ROW_REC * elemSize; }
-
-template <typename ET, int GROUP>
-__device__ __forceinline__ void row_block(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const ET* __restrict__ rowdat, int blk, int gl)
-{
-	const int b = st.hsc_colind[blk];
-	ET qb[4], camb[5];
-	load_pose_as<ET>(g, b, qb, camb);
-	const Rot3T<ET> Rb = quat_to_rot(qb[0], qb[1], qb[2], qb[3]);
-	ET T[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++) T[r][c] = 0;
-	const ET* recs = reinterpret_cast<const ET*>(st.e_rec);
-	const int p1 = st.prod_end[blk];
-	for (int p = st.prod_beg[blk] + gl; p < p1; p += GROUP)
-	{
-		const ET* rb = recs + REC * (size_t)st.prod_eb[p];
-		const ET* ra = rowdat + ROW_REC * st.prod_apos[p];
-		ProductOperand<ET> B;
-		product_operand<ET>(rb, Rb, camb, B);
-		const ET Xa[3] = { ra[0], ra[1], ra[2] };
-		ET P[3][3];
-#pragma unroll
-		for (int i = 0; i < 3; i++)
-#pragma unroll
-			for (int k = 0; k < 3; k++) P[i][k] = ra[3 + 3 * i + k];
-		product_accumulate_p<ET>(Xa, P, B, T);
-	}
-	Scalar* dst = sys.hsc + 36 * (size_t)blk;
-#pragma unroll
-	for (int c = 0; c < 6; c++)
-#pragma unroll
-		for (int r = 0; r < 6; r++)
-		{
-			Scalar v = (Scalar)T[r][c];
-			if (GROUP == 64) v = wave_sum(v);
-			else { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); }
-			if (GROUP == 64 ? (c * 6 + r) == gl : (c * 6 + r) % GROUP == gl) dst[c * 6 + r] = -v;
-		}
-}
-
-template <typename ET>
-__global__ __launch_bounds__(256) void row_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
-{
-	extern __shared__ __align__(16) unsigned char row_lds_raw[];
-	__shared__ Scalar red[4][33];
-	__shared__ int row_lists[2][256];
-	__shared__ int row_counts[2];
-	ET* rowdat = reinterpret_cast<ET*>(row_lds_raw);
-	const int ip = blockIdx.x;
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	// ---- phase 1: the edges of pose ip
-	{
-		ET q[4], cam[5];
-		load_pose_as<ET>(g, ip, q, cam);
-		const Rot3T<ET> R = quat_to_rot(q[0], q[1], q[2], q[3]);
-		Scalar acc[33];
-#pragma unroll
-		for (int k = 0; k < 33; k++) acc[k] = 0;
-		const int p0 = st.pe_beg[ip], p1 = st.pe_end[ip];
-		for (int p = p0 + (int)threadIdx.x; p < p1; p += 256)
-		{
-			const ET* rec = reinterpret_cast<const ET*>(st.e_rec) + REC * (size_t)st.pe_edge[p];
-			CameraFrameEdge<ET> c;
-			camera_frame_edge<ET>(rec, cam, c);
-			const ET r0 = rec[4], r1 = rec[5], r2 = c.stereo ? rec[6] : ET(0);
-			const int il = tag_decode(rec[7]);
-			ET S[6] = { c.k00, 0, c.k02, c.k11, c.k12, c.k22 };
-			ET v[3] = { c.w * c.d00 * (r0 + r2), c.w * c.d11 * r1, c.w * (c.d02 * r0 + c.d12 * r1 + c.d22 * r2) };
-			ET vs[3] = { v[0], v[1], v[2] };
-			ET P[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
-			if (il < g.Lf)
-			{
-				const Scalar* ls = sys.lm_sys + 9 * (size_t)il;
-				ET M[3][3], inv[6], bl[3];
-#pragma unroll
-				for (int k = 0; k < 6; k++) inv[k] = (ET)ls[k];
-#pragma unroll
-				for (int k = 0; k < 3; k++) bl[k] = (ET)ls[6 + k];
-				camera_frame_m<ET>(c, R, M);
-#pragma unroll
-				for (int i = 0; i < 3; i++)
-#pragma unroll
-					for (int k = 0; k < 3; k++)
-						P[i][k] = M[i][0] * inv[sym3_idx(0, k)] + M[i][1] * inv[sym3_idx(1, k)] + M[i][2] * inv[sym3_idx(2, k)];
-#pragma unroll
-				for (int i = 0; i < 3; i++)
-				{
-#pragma unroll
-					for (int j = i; j < 3; j++)
-						S[sym3_idx(i, j)] -= P[i][0] * M[j][0] + P[i][1] * M[j][1] + P[i][2] * M[j][2];
-					vs[i] -= P[i][0] * bl[0] + P[i][1] * bl[1] + P[i][2] * bl[2];
-				}
-			}
-			ET* rd = rowdat + ROW_REC * (p - p0);
-			rd[0] = c.X[0]; rd[1] = c.X[1]; rd[2] = c.X[2];
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-#pragma unroll
-				for (int k = 0; k < 3; k++) rd[3 + 3 * i + k] = P[i][k];
-			pose_sums_accumulate<1, ET>(c, S, v, vs, acc);
-		}
-#pragma unroll
-		for (int k = 0; k < 33; k++) acc[k] = wave_sum(acc[k]);
-		if (lane == 0)
-#pragma unroll
-			for (int k = 0; k < 33; k++) red[wv][k] = acc[k];
-	}
-	__syncthreads();
-	if (threadIdx.x < 33)
-	{
-		const int k = threadIdx.x;
-		const Scalar v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-		if (k < 21)
-		{
-			// k = c (c + 1) / 2 + r, r <= c
-			int c = 0;
-			while ((c + 1) * (c + 2) / 2 <= k) c++;
-			const int r = k - c * (c + 1) / 2;
-			sys.hsc[36 * (size_t)st.hsc_rowptr[ip] + c * 6 + r] = v;
-		}
-		else if (k < 27) sys.bp[6 * (size_t)ip + (k - 21)] = v;
-		else sys.bsc[6 * (size_t)ip + (k - 27)] = v;
-	}
-	// ---- phase 2: the blocks (ip, b > ip) of the row (the diagonal block comes first in the row), in windows of 256 blocks:
-	// wave 0 sorts a window's blocks into a heavy and a light list, then whole waves take the heavy and 16-lane groups the light ones
-	const int k0 = st.hsc_rowptr[ip] + 1, k1 = st.hsc_rowptr[ip + 1];
-	const int grp16 = threadIdx.x >> 4;
-	for (int w0 = k0; w0 < k1; w0 += 256)
-	{
-		__syncthreads();                 // (first window: phase 1 is complete; later ones: the lists are free again)
-		if (wv == 0)
-		{
-			int nh = 0, nl = 0;
-			for (int base = w0; base < min(k1, w0 + 256); base += 64)
-			{
-				const int blk = base + lane;
-				const int cnt = blk < k1 ? st.prod_end[blk] - st.prod_beg[blk] : 0;
-				const bool heavy = cnt > BP_HEAVY, light = cnt > 0 && !heavy;
-				const unsigned long long mh = __ballot(heavy), ml = __ballot(light), below = (1ull << lane) - 1;
-				if (heavy) row_lists[0][nh + __popcll(mh & below)] = blk;
-				if (light) row_lists[1][nl + __popcll(ml & below)] = blk;
-				nh += __popcll(mh); nl += __popcll(ml);
-			}
-			if (lane == 0) { row_counts[0] = nh; row_counts[1] = nl; }
-		}
-		__syncthreads();
-		const int nh = row_counts[0], nl = row_counts[1];
-		for (int j = wv; j < nh; j += 4) row_block<ET, 64>(g, st, sys, rowdat, row_lists[0][j], lane);
-		for (int j = grp16; j < nl; j += 16) row_block<ET, BP_GROUP>(g, st, sys, rowdat, row_lists[1][j], threadIdx.x & (BP_GROUP - 1));
-	}
-}
-
 template <typename ET>
 static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
 	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
@@ -1390,12 +1207,6 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 	}
 	static const bool separate = std::getenv("CUBA_HIP_SEPARATE_SCHUR_PASSES") != nullptr;     // A/B knob
-	const size_t rowLds = row_pass_lds_bytes(st.row_edges_max, sizeof(ET));
-	if (mode == 1 && g.Pf > 0 && st.prod_apos && st.nDiagProd == 0 && !separate && rowLds <= 60 * 1024)
-	{
-		hipLaunchKernelGGL((row_pass_kernel<ET>), dim3(g.Pf), dim3(256), rowLds, s, g, st, sys);
-		return;
-	}
 	const int nbp = block_pass_groups(st.nOd, st.nHeavy);
 	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0 && !separate)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)
 	{

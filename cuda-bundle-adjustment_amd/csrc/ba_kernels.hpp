@@ -73,10 +73,6 @@ struct DeviceStructure
 	int* prod_lm = nullptr;            // landmark of each product (= e_lm[prod_ea]): the block pass then fetches inv(Hll + lambda) beside the
 	                                   // two edge records instead of after them (one memory round trip per product instead of two)
 	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
-	// row pass (pose pass + block pass of one pose in one workgroup): position of every product's edge a in a's edge list
-	// (relative to pe_beg), and the longest edge list; prod_apos == nullptr: the two-kernel path
-	int* prod_apos = nullptr;
-	int row_edges_max = 0;
 	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)

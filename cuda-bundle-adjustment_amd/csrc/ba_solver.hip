@@ -163,7 +163,7 @@ struct cuba_hip_solver
 	bool precondFp32 = sizeof(Scalar) == 8;
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
-	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge, d_eSlot, d_prodApos, d_rowMax;
+	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
 	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
 	// single-kernel PCG iteration: halo lists of the aggregates + its vectors
 	DevBuf<int> d_halN, d_halNJ, d_halPose, d_halAloc, d_haggId, d_ellLoc, d_ownLoc;
@@ -340,7 +340,6 @@ struct cuba_hip_solver
 	bool failDirty = true;       // the device-side failure flag of the PCG may be non-zero
 	int expectedTicket = 0;
 	bool spinWait = true;
-	bool rowPass = true;         // option "row_pass": pose pass + block pass of one pose in one workgroup (a-side of every product from LDS)
 	bool fusedTail = true;       // optimize(): back-substitution, update and evaluation of a trial in one pass over the edges (option "fused_tail")
 	bool speculateTail = false;  // optimize(): enqueue back-substitution/update/evaluation behind the first PCG batch. Measured with
 	                             // spin_wait on: 12.01 vs 11.95 ms (the saved host look is cheap now, a misprediction is not) -> off
@@ -1043,19 +1042,6 @@ struct cuba_hip_solver
 		st.prod_beg = localRanges ? d_prodBeg.data() : d_prodPtr.data(); st.prod_end = localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1;
 		st.pe_beg = localRanges ? d_peBeg.data() : d_pePtr.data(); st.pe_end = localRanges ? d_peEnd.data() : d_pePtr.data() + 1;
 		st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
-		// row pass: where each product's edge a sits in a's edge list, and the longest list (one read-back; structure builds only)
-		st.prod_apos = nullptr; st.row_edges_max = 0;
-		if (rowPass && !schurAtomic && Pf > 0 && diagProdBlocks == 0)
-		{
-			d_eSlot.resize((size_t)std::max(E, 1)); d_prodApos.resize(std::max<size_t>(d_prodEa.size(), 1)); d_rowMax.resize(1);
-			topo::launch_row_pass_lists(d_peEdge.data(), d_peEdge.size(), d_eSlot.data(), (size_t)E, st.prod_beg, st.prod_end, d_blkrow.data(), nblk,
-				d_prodEa.data(), st.pe_beg, st.pe_end, Pf, d_prodApos.data(), d_rowMax.data(), stream);
-			int mx = 0;
-			HIP_TRY(hipMemcpyAsync(&mx, d_rowMax.data(), sizeof(int), hipMemcpyDeviceToHost, stream));
-			sync();
-			d_eSlot.resize(0);
-			st.prod_apos = d_prodApos.data(); st.row_edges_max = mx;
-		}
 		st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 		sys = DeviceSystem();
 		sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
@@ -2123,7 +2109,6 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
-		else if (k == "row_pass") { s->rowPass = value != 0; s->haveStructure = false; }
 		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }

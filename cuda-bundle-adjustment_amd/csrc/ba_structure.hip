@@ -220,32 +220,6 @@ __global__ __launch_bounds__(T) void od_keys_kernel(const int* prod_beg, const i
 	if ((threadIdx.x & 63) == 0 && nh) atomicAdd(&counters[CNT_NHEAVY], nh);
 }
 
-// row pass: e_slot[pe_edge[k]] = k (the position of an edge in the per-pose lists), then for every product the position of its
-// edge a inside a's list as the kernels walk it (pe_beg), and the longest list
-__global__ __launch_bounds__(T) void slot_scatter_kernel(const int* __restrict__ pe_edge, size_t n, int* __restrict__ e_slot)
-{
-	const size_t k = (size_t)blockIdx.x * T + threadIdx.x;
-	if (k < n) e_slot[pe_edge[k]] = (int)k;
-}
-
-__global__ __launch_bounds__(T) void prod_apos_kernel(const int* __restrict__ prod_beg, const int* __restrict__ prod_end, const int* __restrict__ blkrow, int nblk,
-	const int* __restrict__ prod_ea, const int* __restrict__ e_slot, const int* __restrict__ pe_beg, int* __restrict__ prod_apos)
-{
-	const int blk = (blockIdx.x * T + threadIdx.x) / 16, gl = threadIdx.x & 15;
-	if (blk >= nblk) return;
-	const int base = pe_beg[blkrow[blk]];
-	for (int p = prod_beg[blk] + gl; p < prod_end[blk]; p += 16) prod_apos[p] = e_slot[prod_ea[p]] - base;
-}
-
-__global__ __launch_bounds__(T) void max_segment_kernel(const int* __restrict__ beg, const int* __restrict__ end, int n, int* __restrict__ out)
-{
-	const int i = blockIdx.x * T + threadIdx.x;
-	int len = i < n ? end[i] - beg[i] : 0;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
-	if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
-}
-
 __global__ __launch_bounds__(T) void remap_poses_kernel(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut)
 {
 	const int e = blockIdx.x * T + threadIdx.x;
@@ -567,16 +541,6 @@ void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo,
 void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, int heavy, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s)
 {
 	if (nblk > 0) hipLaunchKernelGGL(od_keys_kernel, grid_for(nblk), dim3(T), 0, s, prod_beg, prod_end, blkrow, colind, nblk, farOffset, heavy, keys, vals, counters);
-}
-
-void launch_row_pass_lists(const int* pe_edge, size_t nPe, int* e_slot, size_t E, const int* prod_beg, const int* prod_end, const int* blkrow, int nblk,
-	const int* prod_ea, const int* pe_beg, const int* pe_end, int Pf, int* prod_apos, int* maxEdges, hipStream_t s)
-{
-	if (E > 0) (void)hipMemsetAsync(e_slot, 0xff, E * sizeof(int), s);
-	(void)hipMemsetAsync(maxEdges, 0, sizeof(int), s);
-	if (nPe > 0) hipLaunchKernelGGL(slot_scatter_kernel, grid_for(nPe), dim3(T), 0, s, pe_edge, nPe, e_slot);
-	if (nblk > 0) hipLaunchKernelGGL(prod_apos_kernel, grid_for((size_t)nblk * 16), dim3(T), 0, s, prod_beg, prod_end, blkrow, nblk, prod_ea, e_slot, pe_beg, prod_apos);
-	if (Pf > 0) hipLaunchKernelGGL(max_segment_kernel, grid_for(Pf), dim3(T), 0, s, pe_beg, pe_end, Pf, maxEdges);
 }
 
 void launch_remap_poses(const int* epIn, const int* newOfOld, int E, int Pf, int* epOut, hipStream_t s)

@@ -71,10 +71,6 @@ void launch_blocks_from_entries(const uint64_t* keys, const uint64_t* vals, cons
 // counters[CNT_DIAGPROD] = number of DIAGONAL blocks with products (a landmark observed twice by one pose)
 // counters[CNT_NHEAVY] = number of blocks with more than `heavy` products (the first ones of the sorted list)
 // (prod_beg[k] .. prod_end[k] = the product range of block k this handle evaluates: prod_ptr / prod_ptr + 1 for the whole graph)
-// row pass lists: e_slot[pe_edge[k]] = k (scratch, E ints), prod_apos[p] = e_slot[prod_ea[p]] - pe_beg[row of the product's block], *maxEdges = longest
-// pe_end - pe_beg
-void launch_row_pass_lists(const int* pe_edge, size_t nPe, int* e_slot, size_t E, const int* prod_beg, const int* prod_end, const int* blkrow, int nblk,
-	const int* prod_ea, const int* pe_beg, const int* pe_end, int Pf, int* prod_apos, int* maxEdges, hipStream_t s);
 void launch_od_keys(const int* prod_beg, const int* prod_end, const int* blkrow, const int* colind, int nblk, int farOffset, int heavy, uint32_t* keys, uint32_t* vals, int* counters, hipStream_t s);
 // beg[s] .. end[s] = the items of segment s (ptr[s] .. ptr[s + 1], values ascending) whose value lies in [vlo, vhi)
 void launch_segment_subrange(const int* ptr, int nseg, const int* vals, int vlo, int vhi, int* beg, int* end, hipStream_t s);

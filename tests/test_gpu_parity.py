@@ -318,25 +318,6 @@ def test_coarse_inverse_storage_precision(solvers):
         assert np.array_equal(a2.optimize(6)["chi2"], ra), opts
 
 
-@pytest.mark.parametrize("opts", [{}, {"mixed_precision": 1}], ids=["fp64", "mixed"])
-def test_row_pass_agrees_with_the_two_kernel_schur_path(solvers, small_fp, opts):
-    """Default: pose pass and block pass of a pose run in one workgroup (row pass: a-side of every product from LDS).  Option
-    row_pass = 0 keeps the two-kernel path (records gathered per product); both build the same reduced system -- compared block by
-    block after one Schur step, then over an LM run; a graph with > 64-observation landmarks goes through the same check."""
-    HipSolver, _ = solvers
-    for fp in (small_fp, flatten(graph_with_big_landmarks())):
-        a, b = HipSolver(fp, RK_HUBER, row_pass=0, **opts), HipSolver(fp, RK_HUBER, **opts)
-        for h in (a, b):
-            h.compute_errors(); h.build_system(); h.set_lambda(1e-5 * h.max_diagonal()); h.schur()
-        (rpa, cia, va), (rpb, cib, vb) = a.hsc(), b.hsc()
-        assert np.array_equal(rpa, rpb) and np.array_equal(cia, cib)
-        tol = 1e-12 if not opts else 1e-5
-        assert rel(vb, va) < tol
-        assert rel(b.array("bsc"), a.array("bsc")) < tol and rel(b.array("bp"), a.array("bp")) < tol
-        ra, rb = HipSolver(fp, RK_HUBER, row_pass=0, **opts).optimize(6)["chi2"], HipSolver(fp, RK_HUBER, **opts).optimize(6)["chi2"]
-        assert rel(rb, ra) < (1e-11 if not opts else 1e-6)
-
-
 def test_single_kernel_pcg_iteration_agrees(solvers):
     """Option pcg_single_kernel = 1 (round 3, off by default because it measured slower): one launch per PCG iteration --
     Chronopoulos-Gear recurrences, one workgroup per coarse aggregate that redoes residual and preconditioner on the aggregate's halo.
