@@ -347,6 +347,10 @@ def test_bench_independent_graphs_two_ranks_share_one_gpu_over_gloo():
     part = rec["partitioned"]
     assert "error" not in part, part
     assert part["scaling"] == "strong" and part["iterations_done"] == 10 and part["value"] > 0
+    # ... with where its time goes: the replicated reduced solve bounds the speed-up of this mode (Amdahl)
+    ts = part["time_shares"]
+    assert "error" not in ts, ts
+    assert 0 < ts["replicated_reduced_solve"] < 1 and ts["amdahl_ceiling_speedup"] > 0 and part["speedup_over_one_gpu"] > 0
 
 
 @pytest.mark.gpu
