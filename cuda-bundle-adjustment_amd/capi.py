@@ -85,6 +85,7 @@ def load_library(precision="f64"):
         "cuba_hip_compute_scale": [H, C.c_double, _dp],
         "cuba_hip_push": [H],
         "cuba_hip_pop": [H],
+        "cuba_hip_hint_unchanged": [H, C.c_int, C.c_int],
         "cuba_hip_snapshot_state": [H],
         "cuba_hip_restore_state": [H],
         "cuba_hip_optimize": [H, C.c_int, _dp, C.POINTER(C.c_int)],
@@ -189,6 +190,10 @@ class HipSolver:
 
     def set_robust_kernel(self, edge_type, kind, delta):
         self._ck(self.lib.cuba_hip_set_robust_kernel(self.h, int(edge_type), int(kind), float(delta)))
+
+    def hint_unchanged(self, same_edges=True, same_values=False):
+        """promise about the NEXT set_graph call only (cuba_hip_hint_unchanged)"""
+        self._ck(self.lib.cuba_hip_hint_unchanged(self.h, int(bool(same_edges)), int(bool(same_values))))
 
     def set_graph(self, fp):
         self.fp = fp

@@ -340,6 +340,7 @@ struct cuba_hip_solver
 	bool failDirty = true;       // the device-side failure flag of the PCG may be non-zero
 	int expectedTicket = 0;
 	bool spinWait = true;
+	bool hintSameEdges = false, hintSameValues = false;   // cuba_hip_hint_unchanged: promises about the next set_graph call
 	bool fusedTail = true;       // optimize(): back-substitution, update and evaluation of a trial in one pass over the edges (option "fused_tail")
 	bool speculateTail = false;  // optimize(): enqueue back-substitution/update/evaluation behind the first PCG batch. Measured with
 	                             // spin_wait on: 12.01 vs 11.95 ms (the saved host look is cheap now, a misprediction is not) -> off
@@ -460,7 +461,9 @@ struct cuba_hip_solver
 		// the very same index arrays as in the previous call (re-initialisation of an unchanged graph): the sort, the
 		// permutation and the sorted index arrays on the host and on the device are all still valid
 		bool sameInput = !noCache && haveGraph && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_ && (int)h_inEp.size() == E_;
-		if (sameInput)
+		const bool promisedEdges = sameInput && hintSameEdges, promisedValues = promisedEdges && hintSameValues;
+		hintSameEdges = hintSameValues = false;          // (a promise covers one call)
+		if (sameInput && !promisedEdges)
 		{
 			std::atomic<int> diff{ 0 };
 			parallelFor(E_, [&](int e) { if (h_inEp[e] != ep[e] || h_inEl[e] != el[e] || h_inDim[e] != edim[e]) diff.store(1, std::memory_order_relaxed); });
@@ -512,10 +515,11 @@ struct cuba_hip_solver
 				d_rawEp.resize(E);
 				HIP_TRY(hipMemcpyAsync(d_rawEp.data(), d_rawEpCaller.data(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, stream));
 			}
-			d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream);
+			const bool keepValues = promisedValues && reuseSort && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
+			if (!keepValues) { d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream); }
 			lap("set_graph: raw uploads enqueued");
 			if (!reuseSort) runDeviceEdgeSort();
-			else
+			else if (!keepValues)
 			{
 				d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
 				topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
@@ -2132,6 +2136,12 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
 	});
+}
+
+
+int cuba_hip_hint_unchanged(cuba_hip_solver* s, int same_edges, int same_values)
+{
+	return guarded(s, [&] { s->hintSameEdges = same_edges != 0; s->hintSameValues = same_edges != 0 && same_values != 0; });
 }
 
 int cuba_hip_set_graph(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf, const double* q, const double* t, const double* cam,

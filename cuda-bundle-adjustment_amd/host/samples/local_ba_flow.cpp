@@ -91,5 +91,16 @@ int main(int argc, char** argv)
 	ba->initialize();
 	ba->optimize(3);
 	for (const auto& s : ba->batchStatistics()) std::printf("stage3 iter: %2d, chi2: %.6f\n", s.iteration + 1, s.chi2);
+
+	// stage 4: initialize() again with NOTHING changed but the estimates stage 3 left -- the library is told that edges and edge values
+	// are those it already holds (cuba_hip_hint_unchanged) and uploads the estimates only; then one measurement changes, which the
+	// next initialize() must notice
+	ba->initialize();
+	ba->optimize(2);
+	for (const auto& s : ba->batchStatistics()) std::printf("stage4 iter: %2d, chi2: %.6f\n", s.iteration + 1, s.chi2);
+	if (!mono.empty()) mono.front()->measurement[0] += 40.0; else stereo.front()->measurement[0] += 40.0;
+	ba->initialize();
+	ba->optimize(1);
+	for (const auto& s : ba->batchStatistics()) std::printf("stage5 iter: %2d, chi2: %.6f\n", s.iteration + 1, s.chi2);
 	return 0;
 }

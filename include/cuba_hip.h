@@ -136,6 +136,16 @@ int cuba_hip_set_graph(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
 	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
 	const double* meas, const double* omega);
 
+/* A promise about the NEXT cuba_hip_set_graph call only (it is consumed by that call, successful or not):
+   same_edges  != 0: edge_pose / edge_landmark / edge_dim and all five counts are identical to those of the previous successful call
+                     (the library then skips its own comparison of the index arrays);
+   same_values != 0: in addition meas and omega are bit-identical to the previous call's, so their 32 bytes per edge need not cross
+                     PCIe again (the estimates q / t / cam / Xw are uploaded in any case).
+   A host layer that re-walks its own graph anyway (the reference re-reads every edge in initialize(), src/cuda_bundle_adjustment.cpp:
+   204-243) learns both facts for free while it copies; a caller that cannot vouch for them simply does not call this.  A wrong
+   promise is not detected: the solver then works on the previous call's edges / values. */
+int cuba_hip_hint_unchanged(cuba_hip_solver* s, int same_edges, int same_values);
+
 /* Replaces: CudaBundleAdjustment::setRobustKernels (src/cuda_bundle_adjustment.cpp:781-784). */
 int cuba_hip_set_robust_kernel(cuba_hip_solver* s, int edge_type, int kind, double delta);
 

@@ -318,6 +318,28 @@ def test_coarse_inverse_storage_precision(solvers):
         assert np.array_equal(a2.optimize(6)["chi2"], ra), opts
 
 
+def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small_fp):
+    """cuba_hip_hint_unchanged: the next set_graph may skip comparing the index arrays and uploading measurements / information.
+    Same results as a plain set_graph when the promise is true; the promise is consumed by one call; without it changed values
+    are picked up."""
+    import copy
+    HipSolver, _ = solvers
+    fp = small_fp
+    h = HipSolver(fp, RK_HUBER)
+    base = h.optimize(4)["chi2"]
+    h.hint_unchanged(True, True); h.set_graph(fp)
+    assert rel(h.optimize(4)["chi2"], base) < 1e-9
+    fp2 = copy.copy(fp); fp2.meas = fp.meas.copy(); fp2.meas[:, 0] += 0.5
+    moved = HipSolver(fp2, RK_HUBER).optimize(4)["chi2"]
+    assert rel(moved, base) > 1e-6                                   # (the modification is visible in the objective)
+    h.set_graph(fp2)                                                 # no promise: the new values go up
+    assert rel(h.optimize(4)["chi2"], moved) < 1e-9
+    h.hint_unchanged(True, False); h.set_graph(fp)                   # edges promised, values not: the old values go up again
+    assert rel(h.optimize(4)["chi2"], base) < 1e-9
+    h.set_graph(fp2)                                                 # the promise above covered one call only
+    assert rel(h.optimize(4)["chi2"], moved) < 1e-9
+
+
 def test_single_kernel_pcg_iteration_agrees(solvers):
     """Option pcg_single_kernel = 1 (round 3, off by default because it measured slower): one launch per PCG iteration --
     Chronopoulos-Gear recurrences, one workgroup per coarse aggregate that redoes residual and preconditioner on the aggregate's halo.

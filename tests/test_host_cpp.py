@@ -90,8 +90,19 @@ def _local_ba_flow(g, make_solver, fix_every=3, iters1=5, iters2=10):
     write_back(g, fp2, *s2.state())
     g.mono_meas = g.mono_meas + np.array([0.25, -0.25]); g.mono_info = g.mono_info * 0.5
     g.stereo_meas = g.stereo_meas + np.array([0.25, -0.25, 0.25]); g.stereo_info = g.stereo_info * 0.5
-    chi_c = make_solver(flatten(g), RK_NONE).optimize(3)["chi2"]
-    return chi_a, removed, chi_b, chi_c
+    fp3 = flatten(g)
+    s3 = make_solver(fp3, RK_NONE)
+    chi_c = s3.optimize(3)["chi2"]
+    # stage 4: nothing changed but the estimates; stage 5: one measurement of the first (surviving) edge moves by 40 pixels
+    write_back(g, fp3, *s3.state())
+    fp4 = flatten(g)
+    s4 = make_solver(fp4, RK_NONE)
+    chi_d = s4.optimize(2)["chi2"]
+    write_back(g, fp4, *s4.state())
+    if len(g.mono_meas): g.mono_meas = g.mono_meas.copy(); g.mono_meas[0, 0] += 40.0
+    else: g.stereo_meas = g.stereo_meas.copy(); g.stereo_meas[0, 0] += 40.0
+    chi_e = make_solver(flatten(g), RK_NONE).optimize(1)["chi2"]
+    return chi_a, removed, chi_b, chi_c, chi_d, chi_e
 
 
 @pytest.mark.gpu
@@ -110,8 +121,10 @@ def test_local_ba_flow_cpp_api_vs_c_abi_vs_oracle(tmp_path):
     got_b = np.array([float(m) for m in re.findall(r"stage2 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
     got_removed = int(re.search(r"removed (\d+) of", out.stdout).group(1))
     got_c = np.array([float(m) for m in re.findall(r"stage3 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
-    hip_a, hip_removed, hip_b, hip_c = _local_ba_flow(g, lambda fp, rk: HipSolver(fp, rk))
-    ora_a, ora_removed, ora_b, ora_c = _local_ba_flow(g, lambda fp, rk: OracleSolver(fp, rk))
+    got_d = np.array([float(m) for m in re.findall(r"stage4 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
+    got_e = np.array([float(m) for m in re.findall(r"stage5 iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
+    hip_a, hip_removed, hip_b, hip_c, hip_d, hip_e = _local_ba_flow(g, lambda fp, rk: HipSolver(fp, rk))
+    ora_a, ora_removed, ora_b, ora_c, ora_d, ora_e = _local_ba_flow(g, lambda fp, rk: OracleSolver(fp, rk))
     assert got_removed == hip_removed == ora_removed and got_removed > 100
     assert len(got_a) == len(hip_a) and np.all(np.abs(got_a - hip_a) <= 1e-9 * hip_a)      # C++ API == C ABI path (bitwise in practice)
     assert len(got_b) == len(hip_b) and np.all(np.abs(got_b - hip_b) <= 1e-9 * hip_b)
@@ -122,6 +135,11 @@ def test_local_ba_flow_cpp_api_vs_c_abi_vs_oracle(tmp_path):
     # Python flow with a fresh handle -- same results to solver tolerance)
     assert len(got_c) == 3 and np.all(np.abs(got_c - hip_c) <= 1e-8 * hip_c) and np.all(np.abs(hip_c - ora_c) <= 1e-6 * ora_c)
     assert got_b[-1] < 0.5 * got_a[-1]                  # the outliers carried most of the robust objective
+    # stage 4: the host layer promises the library unchanged edges and edge values (cuba_hip_hint_unchanged: only the estimates are
+    # uploaded); stage 5: it must notice the one measurement that moved (its chi2 term alone is ~ 40^2 x information)
+    assert len(got_d) == 2 and np.all(np.abs(got_d - hip_d) <= 1e-8 * hip_d) and np.all(np.abs(hip_d - ora_d) <= 1e-6 * ora_d)
+    assert len(got_e) == 1 and np.all(np.abs(got_e - hip_e) <= 1e-8 * hip_e) and np.all(np.abs(hip_e - ora_e) <= 1e-6 * ora_e)
+    assert got_e[0] > got_d[-1] + 100.0
 
 
 @pytest.mark.gpu
