@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -50,7 +51,9 @@ private:
 	HostPool()
 	{
 		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-		const int n = (int)std::min(32u, hw) - 1;       // (the loops are pointer chases: they scale with the number of outstanding misses, not with flops)
+		unsigned cap = 32;                               // (the loops are pointer chases: they scale with the number of outstanding misses, not with flops)
+		if (const char* e = std::getenv("CUBA_HIP_HOST_THREADS")) cap = (unsigned)std::max(1, std::atoi(e));       // A/B knob
+		const int n = (int)std::min(cap, hw) - 1;
 		for (int w = 0; w < n; w++) workers_.emplace_back([this, w] { loop(w); });
 	}
 	~HostPool()

@@ -406,7 +406,8 @@ private:
 	static constexpr size_t kPrefetch = 12;      // objects ahead of the one being read in the pointer-chasing loops
 	static unsigned hostThreads(size_t items)
 	{
-		return (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)cubahip::HostPool::instance().maxThreads(), items / 20000 + 1));
+		static const size_t grain = std::getenv("CUBA_HIP_HOST_GRAIN") ? (size_t)std::max(1, std::atoi(std::getenv("CUBA_HIP_HOST_GRAIN"))) : 20000;   // A/B knob: items per thread
+		return (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)cubahip::HostPool::instance().maxThreads(), items / grain + 1));
 	}
 
 	template <class Fn>
