@@ -86,6 +86,8 @@ def load_library(precision="f64"):
         "cuba_hip_push": [H],
         "cuba_hip_pop": [H],
         "cuba_hip_hint_unchanged": [H, C.c_int, C.c_int],
+        "cuba_hip_chi_squares_begin": [H, _dp],
+        "cuba_hip_chi_squares_end": [H],
         "cuba_hip_snapshot_state": [H],
         "cuba_hip_restore_state": [H],
         "cuba_hip_optimize": [H, C.c_int, _dp, C.POINTER(C.c_int)],
@@ -269,6 +271,13 @@ class HipSolver:
     def chi_squares(self):
         out = np.zeros(self.fp.E)
         self._ck(self.lib.cuba_hip_chi_squares(self.h, _d(out)))
+        return out
+
+    def chi_squares_two_step(self):
+        """cuba_hip_chi_squares_begin / _end (the C++ layer does its write-back between the two)"""
+        out = np.zeros(self.fp.E)
+        self._ck(self.lib.cuba_hip_chi_squares_begin(self.h, _d(out)))
+        self._ck(self.lib.cuba_hip_chi_squares_end(self.h))
         return out
 
     def profile(self):

@@ -1979,7 +1979,7 @@ struct cuba_hip_solver
 		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	}
 
-	void chiSquares(double* out)
+	void chiSquares(double* out, bool wait = true)
 	{
 		need();
 		launch_residual_chi2(g, d_parts.data(), slotsDev + 2 * NSLOT, d_perEdge.data(), stream);
@@ -1989,7 +1989,7 @@ struct cuba_hip_solver
 			d_chiCaller.resize(E);
 			topo::launch_unsort(d_perm.data(), d_perEdge.data(), E, d_chiCaller.data(), stream);
 			if (E) HIP_TRY(hipMemcpyAsync(out, d_chiCaller.data(), sizeof(double) * E, hipMemcpyDeviceToHost, stream));
-			sync();
+			if (wait) sync();
 			return;
 		}
 		std::vector<double>& sorted = h_chiSorted; sorted.resize(E);
@@ -2257,6 +2257,16 @@ int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, 
 int cuba_hip_chi_squares(cuba_hip_solver* s, double* out)
 {
 	return guarded(s, [&] { if (!out && s->E) throw ArgError{ "null output" }; s->chiSquares(out); });
+}
+
+int cuba_hip_chi_squares_begin(cuba_hip_solver* s, double* out)
+{
+	return guarded(s, [&] { if (!out && s->E) throw ArgError{ "null output" }; s->chiSquares(out, false); });     // (the host set-up path has finished when this returns)
+}
+
+int cuba_hip_chi_squares_end(cuba_hip_solver* s)
+{
+	return guarded(s, [&] { s->sync(); });
 }
 
 int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITEMS])

@@ -349,6 +349,9 @@ public:
 		// finalize (ref :512-526): estimates back into the caller's vertices
 		check(cuba_hip_get_solution(solver_, q_.data(), t_.data(), Xw_.data()), "cuba_hip_get_solution");
 		lap("get_solution");
+		// per-edge chi2 (ref getChiSqs :528-543): evaluated and copied by the device while the host writes the estimates back
+		perEdgeChi_.resize(activeEdges_.size());
+		check(cuba_hip_chi_squares_begin(solver_, perEdgeChi_.data()), "cuba_hip_chi_squares_begin");
 		for (size_t i = 0; i < activePoses_.size(); i++)
 		{
 			double* qc = activePoses_[i]->q.coeffs().data();
@@ -369,10 +372,8 @@ public:
 		}
 
 		lap("write-back into vertices");
-		// per-edge chi2 (ref getChiSqs :528-543)
-		perEdgeChi_.resize(activeEdges_.size());
-		check(cuba_hip_chi_squares(solver_, perEdgeChi_.data()), "cuba_hip_chi_squares");
-		lap("chi_squares");
+		check(cuba_hip_chi_squares_end(solver_), "cuba_hip_chi_squares_end");
+		lap("chi_squares (rest)");
 		chiSqs_.clear();
 		chiEdges_.clear();
 		chiIndexBuilt_ = false;          // the edge -> value index is built on the first chiSquared() query

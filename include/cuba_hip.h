@@ -219,6 +219,11 @@ int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, 
 /* Replaces: CudaBlockSolver::getChiSqs -> gpu::computeChiSquares x2 (:528-543).
    Non-robust omega*|r|^2 per edge, in the caller's edge order. */
 int cuba_hip_chi_squares(cuba_hip_solver* s, double* chi2_per_edge);
+/* The same in two steps, for a caller that has host work of its own to do meanwhile (the C++ layer copies the estimates back into the
+   caller's vertices): _begin enqueues the evaluation and the copy into chi2_per_edge (page-locked memory from cuba_hip_host_alloc, or the
+   copy is not asynchronous) and returns; cuba_hip_chi_squares_end waits for it.  No other call on the handle in between. */
+int cuba_hip_chi_squares_begin(cuba_hip_solver* s, double* chi2_per_edge);
+int cuba_hip_chi_squares_end(cuba_hip_solver* s);
 
 /* Replaces: CudaBlockSolver::getTimeProfile (:545-562). Seconds per bucket. */
 int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITEMS]);

@@ -318,6 +318,15 @@ def test_coarse_inverse_storage_precision(solvers):
         assert np.array_equal(a2.optimize(6)["chi2"], ra), opts
 
 
+@pytest.mark.parametrize("device_setup", [1, 0])
+def test_two_step_chi_squares_equals_the_one_call_form(solvers, small_fp, device_setup):
+    HipSolver, _ = solvers
+    h = HipSolver(small_fp, RK_HUBER, device_setup=device_setup)
+    h.optimize(3)
+    one = h.chi_squares()
+    assert np.array_equal(h.chi_squares_two_step(), one) and one.sum() > 0
+
+
 def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small_fp):
     """cuba_hip_hint_unchanged: the next set_graph may skip comparing the index arrays and uploading measurements / information.
     Same results as a plain set_graph when the promise is true; the promise is consumed by one call; without it changed values
