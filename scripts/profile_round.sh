@@ -17,4 +17,7 @@ cd $root
 python scripts/pmc_traffic.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE > $out/${tag}_kitti00_pmc_traffic.json
 cp $out/${tag}_kitti00_pmc_traffic.json profiles/        # the bench line cites the traffic measured in this very run
 python bench.py --steps 50 --warmup 10 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+# the same command under the tracer (main leg only): its per-kernel averages must agree with the line's HIP-event times
+(cd /tmp && run rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_bench_stats -- python $root/bench.py --steps 50 --warmup 10 --no-shapes --no-end-to-end > $out/${tag}_bench_stats.log 2>&1)
+f=$(find $out/${tag}_bench_stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_bench_py_kernel_stats.csv
 tail -c 600 $out/${tag}_bench.json
