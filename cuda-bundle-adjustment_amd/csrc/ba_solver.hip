@@ -209,7 +209,10 @@ struct cuba_hip_solver
 	{
 		for (auto& kv : pcgGraphs) (void)hipGraphExecDestroy(kv.second);
 		pcgGraphs.clear();
+		batchRequests.clear();
 	}
+	std::map<int, int> batchRequests;      // how often a batch of this length was asked for since the graphs were dropped
+	bool exactBatchGraphs = true;          // option "pcg_exact_batch_graphs"
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
 	{
@@ -1724,6 +1727,13 @@ struct cuba_hip_solver
 			{
 				int c = fixedChunk;
 				if (!c) for (c = 256; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
+				// a batch length that comes back (repeated runs on one structure) gets a graph of exactly that length: one hand-over per
+				// batch instead of one per power of two.  Not on the first request -- the reference's timing protocol meets most lengths for
+				// the first time inside its timed part, and an instantiation costs ~2 us per node.
+				if (!fixedChunk && useGraph && exactBatchGraphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
+				{
+					if (pcgGraphs.count(std::make_pair(todo, (const Scalar*)sys.acinv)) || ++batchRequests[todo] >= 2) c = todo;
+				}
 				if (useGraph) { HIP_TRY(hipGraphLaunch(pcgGraph(c, maxIter, tol2), stream)); noteReport(); }     // (every graph reports; the host waits for the last)
 				else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				k0 += c; todo -= c;
@@ -2113,6 +2123,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "spin_wait") s->spinWait = value != 0;
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
+		else if (k == "pcg_exact_batch_graphs") s->exactBatchGraphs = value != 0;
 		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
