@@ -213,6 +213,7 @@ struct cuba_hip_solver
 	}
 	std::map<int, int> batchRequests;      // how often a batch of this length was asked for since the graphs were dropped
 	bool exactBatchGraphs = true;          // option "pcg_exact_batch_graphs"
+	bool repeatPrediction = true;          // option "pcg_repeat_prediction"
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
 	{
@@ -317,6 +318,8 @@ struct cuba_hip_solver
 	std::vector<int> h_spose[2], h_slm[2];   // sorted edge->pose (with the stereo bit) / edge->landmark of this and the previous set_graph
 	int topoSlot = 0;
 	std::vector<int> runIters;   // PCG iterations of the solves of the current LM run (sizes the next batch of launches)
+	std::vector<int> prevRunIters;   // ... and of the previous run on this structure: a run that repeats it solve for solve is sized from it
+	void startRunHistory() { if (!runIters.empty()) prevRunIters.swap(runIters); runIters.clear(); }
 	int firstSolveIters = 0;     // ... and of the first solve of the previous run
 
 	double lambda = 0;
@@ -641,7 +644,7 @@ struct cuba_hip_solver
 			if (std::memcmp(&a, &b, sizeof(DeviceGraph)) != 0) dropPcgGraph();
 			haveStructure = true;
 		}
-		coarseValid = false; runIters.clear();
+		coarseValid = false; startRunHistory();
 		haveGraph = true;
 		lambda = 0;
 		for (double& v : prof) v = 0;
@@ -1057,7 +1060,7 @@ struct cuba_hip_solver
 		sys.minv = d_minv.data(); sys.r = d_r.data(); sys.z = d_z.data(); sys.p0 = d_p0.data(); sys.p1 = d_p1.data(); sys.ap = d_ap.data();
 		sys.rz = d_rz.data(); sys.pq = d_pq.data(); sys.iters = d_iters.data(); sys.kbase = d_kbase.data(); sys.ticket = d_ticket.data();
 		dropPcgGraph();
-		firstInvValid = false; firstInvPending = false;
+		firstInvValid = false; firstInvPending = false; prevRunIters.clear();
 		sys.rzStride = rzStrideCfg; sys.pqStride = pqStrideCfg; sys.npq = gridSpmv;
 		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
@@ -1717,6 +1720,12 @@ struct cuba_hip_solver
 		}
 		else if (runIters.size() == 1) predicted = (int)(1.35 * runIters[0]) + 2;
 		else if (firstSolveIters > 0) predicted = firstSolveIters + 1;
+		// a run that has repeated the previous run on this structure solve for solve so far (re-optimisation from the same estimate, a
+		// sliding window that barely moved) most likely does so again: exactly that many iterations, no margin
+		{
+			const size_t k = runIters.size();
+			if (repeatPrediction && k < prevRunIters.size() && std::equal(runIters.begin(), runIters.end(), prevRunIters.begin())) predicted = prevRunIters[k];
+		}
 		// (the last node of every iteration graph runs the stop test on the residual its chunk left: a batch of exactly the needed
 		// length is recognised as converged)
 		int target = fixedChunk ? fixedChunk : (predicted + 3) / 4 * 4;
@@ -1816,7 +1825,7 @@ struct cuba_hip_solver
 	{
 		need();
 		coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
-		runIters.clear();
+		startRunHistory();
 		const int maxq = 10;
 		const double tau = 1e-5;
 		double nu = 2, lam = 0, F = 0;
@@ -2124,6 +2133,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
 		else if (k == "pcg_exact_batch_graphs") s->exactBatchGraphs = value != 0;
+		else if (k == "pcg_repeat_prediction") s->repeatPrediction = value != 0;
 		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
@@ -2452,7 +2462,7 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 
 int cuba_hip_begin_run(cuba_hip_solver* s)
 {
-	return guarded(s, [&] { s->need(); s->coarseValid = false; s->runIters.clear(); });
+	return guarded(s, [&] { s->need(); s->coarseValid = false; s->startRunHistory(); });
 }
 
 int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream)

@@ -109,7 +109,7 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    DESIGN.md section 4), "fused_tail" (default 1: optimize() runs back-substitution, update and evaluation of a trial
    as ONE pass over the edges -- two launches between a converged solve and the LM decision instead of four; 0 = the four-launch tail), "speculate_tail" (default 0; 1 = optimize()
    enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
-   was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "pcg_exact_batch_graphs" (default 1: a batch length that is asked for a second time on one structure gets a graph of exactly that length -- one hand-over per batch instead of one per power of two; 0 = powers of two only), "schur_atomic"
+   was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "pcg_exact_batch_graphs" (default 1: a batch length that is asked for a second time on one structure gets a graph of exactly that length -- one hand-over per batch instead of one per power of two; 0 = powers of two only), "pcg_repeat_prediction" (default 1: a run that has repeated the previous run on the same structure solve for solve so far sizes its next batch of iterations from that run instead of extrapolating), "schur_atomic"
    (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "mixed_precision" (fp64 library
    only, default 0; 1 = the per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in
    fp32, every sum over edges, the reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29,
