@@ -813,10 +813,15 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 			Scalar inv[6];
 			H[0] += lambda; H[3] += lambda; H[5] += lambda;
 			sym3_inverse(H, inv);
-			Scalar* li = sys.lm_inv + 8 * (size_t)il;       // the block pass reads this copy: 64-byte rows, one sector per gather
 #pragma unroll
-			for (int k = 0; k < 6; k++) { ls[k] = inv[k]; li[k] = inv[k]; }
-			li[6] = 0; li[7] = 0;                            // (whole sectors: no read-modify-write at the memory side)
+			for (int k = 0; k < 6; k++) ls[k] = inv[k];
+			if (st.inv_rows8)                               // the block pass reads this copy: 64-byte rows, one sector per gather
+			{
+				Scalar* li = sys.lm_inv + 8 * (size_t)il;
+#pragma unroll
+				for (int k = 0; k < 6; k++) li[k] = inv[k];
+				li[6] = 0; li[7] = 0;                        // (whole sectors: no read-modify-write at the memory side)
+			}
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
 		}
@@ -884,10 +889,15 @@ __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceS
 			Scalar inv[6];
 			H[0] += lambda; H[3] += lambda; H[5] += lambda;
 			sym3_inverse(H, inv);
-			Scalar* li = sys.lm_inv + 8 * (size_t)il;
 #pragma unroll
-			for (int k = 0; k < 6; k++) { ls[k] = inv[k]; li[k] = inv[k]; }
-			li[6] = 0; li[7] = 0;
+			for (int k = 0; k < 6; k++) ls[k] = inv[k];
+			if (st.inv_rows8)
+			{
+				Scalar* li = sys.lm_inv + 8 * (size_t)il;
+#pragma unroll
+				for (int k = 0; k < 6; k++) li[k] = inv[k];
+				li[6] = 0; li[7] = 0;
+			}
 #pragma unroll
 			for (int k = 0; k < 3; k++) ls[6 + k] = H[6 + k];
 		}

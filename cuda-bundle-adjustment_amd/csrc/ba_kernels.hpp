@@ -63,7 +63,8 @@ struct DeviceStructure
 	int nOd = 0;                       // blocks that receive at least one off-diagonal (or duplicate-pose) product
 	int nDiagProd = 0;                 // of these, diagonal blocks (a landmark observed twice by one pose): the block pass then updates what the pose pass stored
 	int* od_blocks = nullptr;          // [nOd] their ids, largest product count first
-	int inv_rows8 = 1;                 // A/B: 0 = the block pass gathers inv(Hll + lambda I) from the 72-byte rows of lm_sys
+	int inv_rows8 = 1;                 // 1 = the landmark pass also writes inv(Hll + lambda I) as 64-byte rows (lm_inv) and the block pass gathers those;
+	                                   // 0 = 48-byte gathers from the 72-byte rows of lm_sys (small graphs: the extra stores cost the landmark pass more than the block pass gains)
 	int nHeavy = 0;                    // the first nHeavy of them have more than BP_HEAVY products: a whole wave each in the block pass
 	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
 	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)

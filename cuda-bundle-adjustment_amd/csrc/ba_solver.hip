@@ -1045,7 +1045,8 @@ struct cuba_hip_solver
 		// (whole-wave blocks shorten the longest dependent chain of the block pass: 51 -> 37 us at KITTI-07; on graphs whose pass is bound by its
 		// gathers they only add waves: 114 -> 122 us at KITTI-00, 405 -> 411 us at S2M -- profiles/r03z_block_pass_ab.txt)
 		if (d_prodEa.size() > ((size_t)1 << 19) && !std::getenv("CUBA_HIP_BP_HEAVY")) st.nHeavy = 0;
-		st.inv_rows8 = std::getenv("CUBA_HIP_BLOCK_PASS_INV_FROM_LM_SYS") ? 0 : 1;
+		// (64-byte rows of the landmark inverses: block pass -3 us / landmark pass +5 us at KITTI-00, -16 / +3 us at S2M)
+		st.inv_rows8 = std::getenv("CUBA_HIP_BLOCK_PASS_INV_FROM_LM_SYS") ? 0 : std::getenv("CUBA_HIP_BLOCK_PASS_INV_ROWS8") ? 1 : Lf >= 250000;
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 		if (!localRanges) fillProdLm();          // (a device-built partition needed it earlier)
 		st.prod_lm = d_prodLm.data();
