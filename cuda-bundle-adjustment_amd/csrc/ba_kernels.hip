@@ -2054,109 +2054,6 @@ __device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar
 	}
 }
 
-// ---- coarse rows: (P^T A) p instead of row sums of A p --------------------------------------------------------------------------
-// P^T A of one aggregate I over its halo poses: G[(a,c)][(j,d)] = sum over the rows i of I of w_a(i) A_ij[c][d] = sum w_a(i) A_ji[d][c],
-// so thread (j, d) walks ROW j of the expanded matrix and picks the entries whose column lies in I: no atomics, fixed order.
-template <int CL>
-__global__ __launch_bounds__(256) void pta_assemble_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
-{
-	constexpr int CD = 6 * CL;
-	const int I = blockIdx.x, r0 = I * sys.agg, r1 = min(g.Pf, r0 + sys.agg);
-	const int h6 = 6 * st.hal_n[I];
-	const int W = 20 * st.ell_m;
-	for (int idx = threadIdx.x; idx < h6; idx += 256)
-	{
-		const int r = idx / 6, d = idx - 6 * r;
-		const int j = st.hal_pose[(size_t)I * st.hmax + r];
-		Scalar acc[CD];
-#pragma unroll
-		for (int k = 0; k < CD; k++) acc[k] = 0;
-		for (int m = 0; m < st.ell_m; m++)
-		{
-			int col[20];
-#pragma unroll
-			for (int e = 0; e < 20; e++) col[e] = st.ell[(size_t)j * W + 20 * m + e].y;
-#pragma unroll
-			for (int e = 0; e < 20; e++)
-			{
-				if (col[e] < r0 || col[e] >= r1) continue;
-				const Scalar2* B2 = reinterpret_cast<const Scalar2*>(sys.hrow + 36 * ((size_t)j * W + 20 * m + e) + 6 * d);
-				const Scalar2 b0 = B2[0], b1 = B2[1], b2 = B2[2];
-				const Scalar v[6] = { b0.x, b0.y, b1.x, b1.y, b2.x, b2.y };
-				const Scalar w = CL == 2 ? agg_weight(col[e], sys.agg, g.Pf) : Scalar(0);
-#pragma unroll
-				for (int c = 0; c < 6; c++) { acc[c] += v[c]; if (CL == 2) acc[6 + c] += w * v[c]; }
-			}
-		}
-		Scalar* G = sys.pta + (size_t)I * CD * sys.pta_ld + idx;
-#pragma unroll
-		for (int k = 0; k < CD; k++) G[(size_t)k * sys.pta_ld] = acc[k];
-	}
-}
-
-void launch_pta_assemble(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s)
-{
-	if (!sys.pta || sys.nc <= 0) return;
-	if (sys.cl == 2) hipLaunchKernelGGL((pta_assemble_kernel<2>), dim3(sys.nc), dim3(256), 0, s, g, st, sys);
-	else hipLaunchKernelGGL((pta_assemble_kernel<1>), dim3(sys.nc), dim3(256), 0, s, g, st, sys);
-}
-
-// The extra workgroups of an SpMV launch (blockIdx.x >= number of row workgroups), one per aggregate: cq_I = G_I (z + beta p_{k-1}) over
-// the halo poses of I -- what the two-level kernel needs of A p_k, from 12 dense rows instead of agg / spmv_rows sets of row sums.
-// Up to three halo columns per thread (6 hmax <= 3 blockDim, checked by the host); the same stop test as the row workgroups.
-template <int CL>
-__device__ __forceinline__ void spmv_coarse_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int I, int k, int maxIter, Scalar tol2,
-	const Scalar* pold)
-{
-	constexpr int CD = 6 * CL;
-	__shared__ Scalar csum[16][CD];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-	const int kb_v = vector_load_flag(sys.kbase);
-	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
-	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
-	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
-	const Scalar s_m = load_parts(rz_slot(sys, k - 1), sys.nrz, lane);
-	const Scalar* G = sys.pta + (size_t)I * CD * sys.pta_ld;
-	Scalar gz[CD], gp[CD];
-#pragma unroll
-	for (int q = 0; q < CD; q++) { gz[q] = 0; gp[q] = 0; }
-	int pose[3];
-#pragma unroll
-	for (int u = 0; u < 3; u++)
-	{
-		const int col = (int)threadIdx.x + u * (int)blockDim.x;
-		pose[u] = col < sys.pta_ld ? st.hal_pose[(size_t)I * st.hmax + col / 6] : -1;       // (the lists are padded with -1 to their full width)
-	}
-#pragma unroll
-	for (int u = 0; u < 3; u++)
-	{
-		const int col = (int)threadIdx.x + u * (int)blockDim.x;
-		if (pose[u] < 0) continue;
-		const int d = col % 6;
-		const Scalar zc = sys.z[6 * (size_t)pose[u] + d], pc = pold[6 * (size_t)pose[u] + d];
-#pragma unroll
-		for (int q = 0; q < CD; q++) { const Scalar gv = G[(size_t)q * sys.pta_ld + col]; gz[q] += gv * zc; gp[q] += gv * pc; }
-	}
-	k += __builtin_amdgcn_readfirstlane(kb_v);
-	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
-	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
-	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk)) return;      // (uniform over the grid; a row workgroup raises the flags)
-	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
-#pragma unroll
-	for (int q = 0; q < CD; q++)
-	{
-		const Scalar v = wave_sum(gz[q] + beta * gp[q]);
-		if (lane == 0) csum[wv][q] = v;
-	}
-	__syncthreads();
-	if ((int)threadIdx.x < CD)
-	{
-		Scalar v = 0;
-		for (int w = 0; w < nw; w++) v += csum[w][threadIdx.x];
-		sys.cq[(size_t)CD * I + threadIdx.x] = v;
-	}
-}
-
 // MIN_WAVES = 4 caps the kernel at 128 VGPRs (a few spills): worth it only when the rows need more than one round of
 // waves at occupancy 3 -- at S2M / G4M size the kernel is bound by waves in flight x latency -- not at KITTI-00 size.
 // ROWS = block rows per workgroup (2 or 4): more rows per workgroup mean fewer row-sum partials for the two-level kernel
@@ -2168,15 +2065,7 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 	const int half = wv & 1, lr = wv >> 1;          // the two waves of a row take 10 of its 20 entry slots each
 	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
 	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
-	const int nCoarse = sys.cq ? sys.nc : 0;        // the first workgroups of the launch: coarse rows (they have the longest way to go)
-	if ((int)blockIdx.x < nCoarse)
-	{
-		if (sys.cl == 2) spmv_coarse_body<2>(g, st, sys, blockIdx.x, k, maxIter, tol2, pold);
-		else spmv_coarse_body<1>(g, st, sys, blockIdx.x, k, maxIter, tol2, pold);
-		return;
-	}
-	const int bid = (int)blockIdx.x - nCoarse;
-	const int row = bid * ROWS + lr;
+	const int row = blockIdx.x * ROWS + lr;
 	TRACE_DECL
 	TRACE_MARK();
 	// scalar loads, consumed at the very end (k is chunk-local here; the absolute number only enters the tests)
@@ -2208,7 +2097,7 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
 	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
 	{
-		if (bid == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
 		return;
 	}
 	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
@@ -2261,12 +2150,12 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 		Scalar s2 = 0;
 #pragma unroll
 		for (int w = 0; w < ROWS; w++)
-			s2 += (a == 0 ? Scalar(1) : agg_weight(bid * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
-		if (sys.qpart && sys.agg > 0 && !sys.cq)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		if (sys.qpart && sys.agg > 0)
 		{
 			// layout [m][coarse unknown], m = position of this workgroup inside its aggregate: the two-level kernel then reads
 			// consecutive addresses across a wave for every m
-			const int per = sys.agg / ROWS, J = bid / per, m = bid - J * per;
+			const int per = sys.agg / ROWS, J = blockIdx.x / per, m = blockIdx.x - J * per;
 			sys.qpart[(size_t)m * (6 * sys.cl * sys.nc) + 6 * sys.cl * J + threadIdx.x] = s2;
 		}
 	}
@@ -2275,10 +2164,10 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 		Scalar s2 = 0;
 #pragma unroll
 		for (int w = 0; w < ROWS; w++) s2 += part[w];
-		pq_slot(sys, k)[bid] = s2;
+		pq_slot(sys, k)[blockIdx.x] = s2;
 	}
 	TRACE_MARK();
-	TRACE_FLUSH(0, bid * 2 * ROWS + wv);
+	TRACE_FLUSH(0, blockIdx.x * 2 * ROWS + wv);
 }
 
 // One wave per block row (large graphs).  With two waves per row S2M / G4M need 10 000 / 20 000 waves of ~5 KB each, i.e.
@@ -2326,15 +2215,7 @@ __global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, 
 	const int lane = threadIdx.x & 63, lr = threadIdx.x >> 6;
 	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
 	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
-	const int nCoarse = sys.cq ? sys.nc : 0;        // the first workgroups of the launch: coarse rows (they have the longest way to go)
-	if ((int)blockIdx.x < nCoarse)
-	{
-		if (sys.cl == 2) spmv_coarse_body<2>(g, st, sys, blockIdx.x, k, maxIter, tol2, pold);
-		else spmv_coarse_body<1>(g, st, sys, blockIdx.x, k, maxIter, tol2, pold);
-		return;
-	}
-	const int bid = (int)blockIdx.x - nCoarse;
-	const int row = bid * ROWS + lr;
+	const int row = blockIdx.x * ROWS + lr;
 	const int kb_v = vector_load_flag(sys.kbase);
 	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
 	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
@@ -2359,7 +2240,7 @@ __global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, 
 	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
 	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
 	{
-		if (bid == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
 		return;
 	}
 	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
@@ -2417,10 +2298,10 @@ __global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, 
 		Scalar s2 = 0;
 #pragma unroll
 		for (int w = 0; w < ROWS; w++)
-			s2 += (a == 0 ? Scalar(1) : agg_weight(bid * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
-		if (sys.qpart && sys.agg > 0 && !sys.cq)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		if (sys.qpart && sys.agg > 0)
 		{
-			const int per = sys.agg / ROWS, J = bid / per, m = bid - J * per;
+			const int per = sys.agg / ROWS, J = blockIdx.x / per, m = blockIdx.x - J * per;
 			sys.qpart[(size_t)m * (6 * sys.cl * sys.nc) + 6 * sys.cl * J + threadIdx.x] = s2;
 		}
 	}
@@ -2429,7 +2310,7 @@ __global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, 
 		Scalar s2 = 0;
 #pragma unroll
 		for (int w = 0; w < ROWS; w++) s2 += part[w];
-		pq_slot(sys, k)[bid] = s2;
+		pq_slot(sys, k)[blockIdx.x] = s2;
 	}
 }
 
@@ -2929,8 +2810,6 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	if (doUpdate && 2 * t < Nc)
 	{
 		sr = *reinterpret_cast<const Scalar2*>(rcin + 2 * t);
-		if (sys.cq) qv[0] = *reinterpret_cast<const Scalar2*>(sys.cq + 2 * t);      // P^T q_k itself, from the coarse workgroups of the SpMV launch
-		else
 #pragma unroll
 		for (int m = 0; m < QV; m++)      // (m < per is uniform over the grid; sets of workgroups that do not exist stay zero)
 			if (m < per) qv[m] = *reinterpret_cast<const Scalar2*>(sys.qpart + (size_t)m * Nc + 2 * t);
@@ -2974,12 +2853,8 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 #pragma unroll
 				for (int m = 0; m < QV; m++) s2 += qv[m];
 			}
-			else
-			{
-				s1 = *reinterpret_cast<const Scalar2*>(rcin + 2 * pj);
-				if (sys.cq) s2 = *reinterpret_cast<const Scalar2*>(sys.cq + 2 * pj);
-			}
-			for (int m0 = pj == t ? QV : 0; m0 < (sys.cq ? 0 : per); m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
+			else s1 = *reinterpret_cast<const Scalar2*>(rcin + 2 * pj);
+			for (int m0 = pj == t ? QV : 0; m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
 			{
 				Scalar2 qx[QV];
 				const Scalar* src = sys.qpart + (size_t)m0 * Nc + 2 * pj;
@@ -3627,7 +3502,7 @@ static dim3 spmv_block_for(const DeviceSystem& sys) { return dim3((spmv_row_per_
 
 void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
 {
-	const dim3 grid((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows + (sys.cq ? sys.nc : 0));       // (+ the coarse-row workgroups)
+	const dim3 grid((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows);
 	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar))spmv_kernel_for(g, sys), grid, spmv_block_for(sys), 0, s, g, st, sys, k, maxIter, tol2);
 }
 
@@ -3715,7 +3590,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		e = add_kernel_node(graph, last, pcg1_kernel_for(sys).fn, dim3(sys.nc), dim3(PCG1_T), (unsigned)pcg1_lds_bytes(st, sys), g, st, sys, k, maxIter, tol2);
 	for (int k = 0; k < chunk && e == hipSuccess && !sys.cg1; k++)
 	{
-		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows + (sys.cq ? sys.nc : 0)), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
+		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{

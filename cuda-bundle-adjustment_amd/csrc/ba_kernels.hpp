@@ -134,12 +134,6 @@ struct DeviceSystem
 	                           // aggregate's owner workgroup writes its 6 entries of P^T r_{k+1})
 	Scalar* hrow = nullptr;    // [36 * 20 * ell_m * Pf] row-ordered copy of Hsc for the SpMV (launch_hsc_expand), entry (row, m, slot)
 	int spmv_rows = 2;         // block rows per SpMV workgroup
-	// coarse rows (option "pcg_coarse_rows"): P^T A as a dense [6*cl][6*h] block per aggregate over its halo poses (pta, row stride pta_ld =
-	// 6*hmax), assembled once per solve; the SpMV launch then carries one extra workgroup per aggregate that writes (P^T A) p_k into cq, and
-	// the two-level kernel reads those 6*cl*nc numbers instead of adding up agg/spmv_rows sets of row sums (qpart).  nullptr: the row-sum path.
-	Scalar* pta = nullptr;
-	Scalar* cq = nullptr;
-	int pta_ld = 0;
 	Scalar* qpart = nullptr;   // [agg/spmv_rows][6*cl*nc] (weighted) sums of q = A p over the block rows of each SpMV workgroup,
 	                           // indexed by the workgroup's position inside its aggregate (P^T q is summed from these:
 	                           // aggregates are whole multiples of spmv_rows rows)
@@ -195,8 +189,6 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 // blocked Gauss-Jordan inversion of a dense SPD n x n matrix (column-major in work0; work1 = scratch of the same size);
 // returns whichever of the two buffers holds the inverse
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
-// P^T A of the current reduced matrix (sys.hrow) into sys.pta (needs the halo lists of the aggregates; sys.pta != nullptr)
-void launch_pta_assemble(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
 // single-kernel PCG iteration: can this configuration run it (kernel instantiation + LDS)?  / the per-solve initialisation that

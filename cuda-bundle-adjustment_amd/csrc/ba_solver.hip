@@ -152,7 +152,6 @@ struct cuba_hip_solver
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
-	DevBuf<Scalar> d_pta, d_cq;       // coarse rows P^T A per aggregate, and (P^T A) p_k of the current iteration
 	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<float> d_coarse32[2];  // option precond_fp32 (fp64 library): the inverse in use in fp32 [0] + the staging copy an overlapped inversion leaves [1]
 	// The inverse the FIRST solve of the previous LM run was given (same damping regime: lambda_0 = tau * max diagonal): it serves the first
@@ -213,7 +212,6 @@ struct cuba_hip_solver
 		batchRequests.clear();
 	}
 	std::map<int, int> batchRequests;      // how often a batch of this length was asked for since the graphs were dropped
-	bool coarseRows = true;                // option "pcg_coarse_rows": (P^T A) p from the SpMV launch instead of row sums (needs the halo lists)
 	bool exactBatchGraphs = true;          // option "pcg_exact_batch_graphs"
 	bool repeatPrediction = true;          // option "pcg_repeat_prediction"
 
@@ -1077,8 +1075,7 @@ struct cuba_hip_solver
 		sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
 		// single-kernel iteration: halo lists of the aggregates (two small launches + one read-back of their maximal lengths)
 		sys.cg1 = 0;
-		sys.pta = nullptr; sys.cq = nullptr; sys.pta_ld = 0;
-		if (agg > 0 && (pcgSingleKernel || coarseRows) && !ellOver && ellM >= 1 && topo::halo_lds_bytes(Pf, nc) <= 48 * 1024)
+		if (agg > 0 && pcgSingleKernel && !ellOver && ellM >= 1 && topo::halo_lds_bytes(Pf, nc) <= 48 * 1024)
 		{
 			d_counters.resize(topo::CNT_COUNT);
 			HIP_TRY(hipMemsetAsync(d_counters.data() + topo::CNT_MAXH, 0, 2 * sizeof(int), stream));
@@ -1096,19 +1093,6 @@ struct cuba_hip_solver
 			topo::launch_halo_fill(d_ell.data(), Pf, ellM, agg, nc, st.hmax, st.jmax, d_halPose.data(), d_halAloc.data(), d_haggId.data(), d_ellLoc.data(), d_ownLoc.data(), stream);
 			st.hal_n = d_halN.data(); st.hal_nj = d_halNJ.data(); st.hal_pose = d_halPose.data(); st.hal_aloc = d_halAloc.data();
 			st.hagg_id = d_haggId.data(); st.ell_loc = d_ellLoc.data(); st.own_loc = d_ownLoc.data();
-			if (!pcgSingleKernel)
-			{
-				// coarse rows: up to three halo columns per thread of the smallest SpMV workgroup (256 threads)
-				if (6 * st.hmax <= 3 * 256)
-				{
-					sys.pta_ld = 6 * st.hmax;
-					d_pta.resize((size_t)nc * 6 * sys.cl * sys.pta_ld); d_cq.resize((size_t)6 * sys.cl * nc);
-					d_pta.zero(stream); d_cq.zero(stream);
-					sys.pta = d_pta.data(); sys.cq = d_cq.data();
-				}
-				haveStructure = true;
-				return;
-			}
 			const size_t Ncs = (size_t)6 * sys.cl * nc;
 			d_w2.resize((size_t)6 * Pf); d_s0.resize((size_t)6 * Pf); d_s1.resize((size_t)6 * Pf); d_cw.resize(2 * Ncs); d_cs.resize(2 * Ncs); d_alpha.resize(2);
 			d_cw.zero(stream); d_cs.zero(stream); d_alpha.zero(stream); d_s0.zero(stream); d_s1.zero(stream); d_w2.zero(stream);
@@ -1625,7 +1609,6 @@ struct cuba_hip_solver
 			launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? reinterpret_cast<const Scalar*>(d_coarse32[1].data()) : nullptr,
 				reinterpret_cast<Scalar*>(d_coarse32[0].data()), inv32Count() / 2);
 		else launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
-		if (sys.pta) launch_pta_assemble(g, st, sys, stream);       // coarse rows P^T A of this trial's matrix (reads the rows the launch above wrote)
 		if (twoLevel)
 		{
 			// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
@@ -2151,7 +2134,6 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
 		else if (k == "pcg_exact_batch_graphs") s->exactBatchGraphs = value != 0;
-		else if (k == "pcg_coarse_rows") { s->coarseRows = value != 0; s->haveStructure = false; }
 		else if (k == "pcg_repeat_prediction") s->repeatPrediction = value != 0;
 		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }

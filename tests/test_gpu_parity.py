@@ -349,22 +349,6 @@ def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small
     assert rel(h.optimize(4)["chi2"], moved) < 1e-9
 
 
-def test_coarse_rows_equal_the_row_sum_path(solvers):
-    """Default: the SpMV launch carries one workgroup per aggregate that computes (P^T A) p_k from dense coarse rows assembled once per
-    solve; option pcg_coarse_rows = 0: the two-level kernel adds up the row sums of A p_k instead.  Same operator, other rounding:
-    iteration counts within one of each other, same trajectory to solver tolerance; both follow the oracle."""
-    HipSolver, OracleSolver = solvers
-    fp = flatten(synth_ba(400, 20000, 90000, seed=5))
-    a, b = HipSolver(fp, RK_HUBER), HipSolver(fp, RK_HUBER, pcg_coarse_rows=0)
-    ra, rb = a.optimize(6)["chi2"], b.optimize(6)["chi2"]
-    assert a.counters()["coarse_dim"] > 0
-    assert rel(ra, rb) < 1e-9
-    ia, ib = a.pcg_history()[0], b.pcg_history()[0]
-    assert len(ia) == len(ib) and np.abs(np.abs(ia) - np.abs(ib)).max() <= 2
-    assert rel(ra, OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]) < CHI2_TOL
-    assert np.array_equal(HipSolver(fp, RK_HUBER).optimize(6)["chi2"], ra)          # reproducible bit for bit
-
-
 def test_single_kernel_pcg_iteration_agrees(solvers):
     """Option pcg_single_kernel = 1 (round 3, off by default because it measured slower): one launch per PCG iteration --
     Chronopoulos-Gear recurrences, one workgroup per coarse aggregate that redoes residual and preconditioner on the aggregate's halo.
