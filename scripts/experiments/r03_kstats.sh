@@ -11,7 +11,7 @@ for shape in "$@"; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Name']
-    if any(k in n for k in ('lm_pass', 'schur_pass', 'pose_pass', 'block_pass', 'trial_tail', 'reduce_report', 'pcg_advance', 'setup_expand')):
+    if any(k in n for k in ('lm_pass', 'schur_pass', 'trial_tail', 'reduce_report', 'setup_expand', 'pta_assemble', 'pcg_spmv', 'pcg2_fused')):
         print("%-60s calls %5s avg %9.1f us" % (n[:60], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
 done
