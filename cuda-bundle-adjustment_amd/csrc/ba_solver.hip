@@ -854,6 +854,7 @@ struct cuba_hip_solver
 			odBlocks.resize(start[maxCnt + 1]);
 			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) odBlocks[start[maxCnt - c]++] = k; }
 			if (std::getenv("CUBA_HIP_BLOCK_ORDER_ROW")) { odBlocks.clear(); for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k); }   // A/B: row order (measured slower: 174 vs 135 us at KITTI-00, the long lists must start first)
+			if (rowGroupedBlocks(nprodLocal)) odBlocks = rowGroupedOrder(blkRow.data(), [&](int k) { return prodPtr[k + 1] - prodPtr[k]; }, nblk);
 			if (const char* xe = std::getenv("CUBA_HIP_BLOCK_ORDER_XCD"))
 			{
 				// A/B (host pipeline only): blocks of the x-th eighth of the rows go to the workgroups that land on XCD x (workgroup w of the
@@ -972,7 +973,7 @@ struct cuba_hip_solver
 		lap("structure: coarse lists + sync");
 		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += k >= 0 && blkRow[k] == h_colind[k];
 		heavyBlocks = 0;        // (the list is sorted by length; an XCD-aware experiment order is not: all blocks then take the 16-lane path)
-		if (!std::getenv("CUBA_HIP_BLOCK_ORDER_XCD") && !std::getenv("CUBA_HIP_BLOCK_ORDER_ROW"))
+		if (!std::getenv("CUBA_HIP_BLOCK_ORDER_XCD") && !std::getenv("CUBA_HIP_BLOCK_ORDER_ROW") && !rowGroupedBlocks(nprodLocal))
 			for (int k : odBlocks) heavyBlocks += prodPtr[k + 1] - prodPtr[k] > heavyThreshold();
 		publishStructure(nblk, (int)waveLm.size() / 2, (int)bigLm.size(), (int)odBlocks.size(), (int)cbI.size(), ellM, ellOver, cc);
 		hostPatternValid = true;
@@ -1027,6 +1028,38 @@ struct cuba_hip_solver
 	}
 
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
+	// Order of the blocks in the Schur block pass for graphs beyond 2^19 products: the 16 blocks of a workgroup come from ONE block row
+	// where possible -- their a-side records then hit the CU's L1 after the first group's miss, and the pass is bound by the L1's
+	// outstanding misses (PMC: 4.6 L1->L2 requests per product, 546 cycles each, the L1 stalled on pending misses for 70 % of the launch:
+	// profiles/r03zw_pmc_schur_and_pcg_kernels.txt) --, rows' leftovers re-chunked in row order (neighbouring rows share records too),
+	// chunks ordered by their longest list, -1 padding.  KITTI-00: linearise + Schur 110.7 -> 102.3 us, S2M 399 -> 358 us.
+	static bool rowGroupedBlocks(long long products)
+	{
+		static const int forced = std::getenv("CUBA_HIP_BLOCK_ORDER_ROWGROUP") ? std::atoi(std::getenv("CUBA_HIP_BLOCK_ORDER_ROWGROUP")) : -1;   // A/B knob: 0 / 1
+		return forced >= 0 ? forced != 0 : products > (1LL << 19);
+	}
+	template <class Cnt>
+	std::vector<int> rowGroupedOrder(const int* blkRow, Cnt&& cntOf, int nblk) const
+	{
+		std::vector<std::vector<int>> rows(Pf);
+		for (int k = 0; k < nblk; k++) if (cntOf(k) > 0) rows[blkRow[k]].push_back(k);
+		std::vector<std::vector<int>> chunks;
+		std::vector<int> rest;
+		for (auto& r : rows)
+		{
+			std::stable_sort(r.begin(), r.end(), [&](int a, int b) { return cntOf(a) > cntOf(b); });
+			size_t i = 0;
+			for (; i + 16 <= r.size(); i += 16) chunks.emplace_back(r.begin() + i, r.begin() + i + 16);
+			rest.insert(rest.end(), r.begin() + i, r.end());
+		}
+		for (size_t i = 0; i < rest.size(); i += 16) chunks.emplace_back(rest.begin() + i, rest.begin() + std::min(rest.size(), i + 16));
+		for (auto& c : chunks) std::stable_sort(c.begin(), c.end(), [&](int a, int b) { return cntOf(a) > cntOf(b); });
+		std::stable_sort(chunks.begin(), chunks.end(), [&](const std::vector<int>& a, const std::vector<int>& b) { return cntOf(a[0]) > cntOf(b[0]); });
+		std::vector<int> od;
+		od.reserve(chunks.size() * 16);
+		for (auto& c : chunks) { od.insert(od.end(), c.begin(), c.end()); while (od.size() % 16) od.push_back(-1); }
+		return od;
+	}
 	int diagProdBlocks = 0;      // diagonal blocks with products (duplicate observations), set by the structure builders
 	int heavyBlocks = 0;         // blocks with more than BP_HEAVY products (the first ones of d_odBlocks), set by the structure builders
 	static int heavyThreshold() { static const int v = std::getenv("CUBA_HIP_BP_HEAVY") ? std::atoi(std::getenv("CUBA_HIP_BP_HEAVY")) : BP_HEAVY; return v; }   // (A/B knob)
@@ -1438,7 +1471,20 @@ struct cuba_hip_solver
 		}
 		reorderTried = false;
 		diagProdBlocks = hc[topo::CNT_DIAGPROD]; heavyBlocks = hc[topo::CNT_NHEAVY];
-		publishStructure(nblk, nWaves, nBig, hc[topo::CNT_NOD], cc.nc > 0 ? hc[topo::CNT_NCB] : 0, ellM, ellOver, cc);
+		int nOdList = hc[topo::CNT_NOD];
+		if (rowGroupedBlocks(npairs) && nblk > 0)
+		{
+			// (the grouping itself is a few sorts of nblk numbers: done on the host from two small downloads)
+			std::vector<int> hRow(nblk), hBeg(nblk), hEnd(nblk);
+			HIP_TRY(hipMemcpyAsync(hRow.data(), d_blkrow.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(hBeg.data(), localRanges ? d_prodBeg.data() : d_prodPtr.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(hEnd.data(), localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1, sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
+			sync();
+			const std::vector<int> od = rowGroupedOrder(hRow.data(), [&](int k) { return hEnd[k] - hBeg[k]; }, nblk);
+			d_odBlocks.upload(od, stream);
+			nOdList = (int)od.size(); heavyBlocks = 0;
+		}
+		publishStructure(nblk, nWaves, nBig, nOdList, cc.nc > 0 ? hc[topo::CNT_NCB] : 0, ellM, ellOver, cc);
 		hostPatternValid = false;
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] structure (device): nblk %d products %lld waves %d big %d od %d coarse blocks %d max row %d\n",
 			nblk, npairs, nWaves, nBig, hc[topo::CNT_NOD], hc[topo::CNT_NCB], maxRow);
