@@ -854,7 +854,7 @@ struct cuba_hip_solver
 			odBlocks.resize(start[maxCnt + 1]);
 			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) odBlocks[start[maxCnt - c]++] = k; }
 			if (std::getenv("CUBA_HIP_BLOCK_ORDER_ROW")) { odBlocks.clear(); for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k); }   // A/B: row order (measured slower: 174 vs 135 us at KITTI-00, the long lists must start first)
-			if (rowGroupedBlocks(nprodLocal)) odBlocks = rowGroupedOrder(blkRow.data(), [&](int k) { return prodPtr[k + 1] - prodPtr[k]; }, nblk);
+			if (rowGroupedBlocks(nprodLocal)) odBlocks = rowGroupedOrder(blkRow.data(), [&](int k) { return prodPtr[k + 1] - prodPtr[k]; }, nblk, h_colind.data());
 			if (const char* xe = std::getenv("CUBA_HIP_BLOCK_ORDER_XCD"))
 			{
 				// A/B (host pipeline only): blocks of the x-th eighth of the rows go to the workgroups that land on XCD x (workgroup w of the
@@ -1028,10 +1028,10 @@ struct cuba_hip_solver
 	}
 
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
-	// Order of the blocks in the Schur block pass for graphs beyond 2^19 products: the 16 blocks of a workgroup come from ONE block row
-	// where possible -- their a-side records then hit the CU's L1 after the first group's miss, and the pass is bound by the L1's
+	// Order of the blocks in the Schur block pass for graphs beyond 2^19 products: the 16 blocks of a workgroup come from ONE tile of the
+	// block matrix where possible -- the records they share then hit the CU's L1 after the first group's miss, and the pass is bound by the L1's
 	// outstanding misses (PMC: 4.6 L1->L2 requests per product, 546 cycles each, the L1 stalled on pending misses for 70 % of the launch:
-	// profiles/r03zw_pmc_schur_and_pcg_kernels.txt) --, rows' leftovers re-chunked in row order (neighbouring rows share records too),
+	// profiles/r03zw_pmc_schur_and_pcg_kernels.txt) --, tiles' leftovers re-chunked in tile order (neighbouring tiles share records too),
 	// chunks ordered by their longest list, -1 padding.  KITTI-00: linearise + Schur 110.7 -> 102.3 us, S2M 399 -> 358 us.
 	static bool rowGroupedBlocks(long long products)
 	{
@@ -1039,10 +1039,27 @@ struct cuba_hip_solver
 		return forced >= 0 ? forced != 0 : products > (1LL << 19);
 	}
 	template <class Cnt>
-	std::vector<int> rowGroupedOrder(const int* blkRow, Cnt&& cntOf, int nblk) const
+	std::vector<int> rowGroupedOrder(const int* blkRow, Cnt&& cntOf, int nblk, const int* blkCol = nullptr) const
 	{
-		std::vector<std::vector<int>> rows(Pf);
-		for (int k = 0; k < nblk; k++) if (cntOf(k) > 0) rows[blkRow[k]].push_back(k);
+		// groups are t x (16 / t) tiles of the block matrix, t = 4 (A/B knob CUBA_HIP_BLOCK_ORDER_TILE = 1, 2, 4, 8): a-side records are shared
+		// by 16 / t blocks of a workgroup, b-side records by t.  KITTI-00 linearise + Schur: pieces of one row (t = 1) 102.9 us, 2 x 8 tiles
+		// 99.3, 4 x 4 tiles 99.6; S2M 356 / 341.6 / 340.9 us
+		static const int tile = std::getenv("CUBA_HIP_BLOCK_ORDER_TILE") ? std::atoi(std::getenv("CUBA_HIP_BLOCK_ORDER_TILE")) : 4;
+		const int tr = blkCol && (tile == 2 || tile == 4 || tile == 8) ? tile : 1, tc = 16 / tr;
+		const int nColTiles = (Pf + tc - 1) / tc;
+		std::vector<std::vector<int>> rows(tr > 1 ? 0 : Pf);
+		if (tr > 1)
+		{
+			std::vector<std::pair<long long, int>> keyed;
+			for (int k = 0; k < nblk; k++) if (cntOf(k) > 0) keyed.emplace_back((long long)(blkRow[k] / tr) * nColTiles + blkCol[k] / tc, k);
+			std::sort(keyed.begin(), keyed.end());
+			for (size_t i = 0; i < keyed.size(); i++)
+			{
+				if (i == 0 || keyed[i].first != keyed[i - 1].first) rows.emplace_back();
+				rows.back().push_back(keyed[i].second);
+			}
+		}
+		else for (int k = 0; k < nblk; k++) if (cntOf(k) > 0) rows[blkRow[k]].push_back(k);
 		std::vector<std::vector<int>> chunks;
 		std::vector<int> rest;
 		for (auto& r : rows)
@@ -1475,12 +1492,13 @@ struct cuba_hip_solver
 		if (rowGroupedBlocks(npairs) && nblk > 0)
 		{
 			// (the grouping itself is a few sorts of nblk numbers: done on the host from two small downloads)
-			std::vector<int> hRow(nblk), hBeg(nblk), hEnd(nblk);
+			std::vector<int> hRow(nblk), hBeg(nblk), hEnd(nblk), hCol;
+			hCol.resize(nblk); HIP_TRY(hipMemcpyAsync(hCol.data(), d_colind.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hRow.data(), d_blkrow.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hBeg.data(), localRanges ? d_prodBeg.data() : d_prodPtr.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hEnd.data(), localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1, sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
 			sync();
-			const std::vector<int> od = rowGroupedOrder(hRow.data(), [&](int k) { return hEnd[k] - hBeg[k]; }, nblk);
+			const std::vector<int> od = rowGroupedOrder(hRow.data(), [&](int k) { return hEnd[k] - hBeg[k]; }, nblk, hCol.empty() ? nullptr : hCol.data());
 			d_odBlocks.upload(od, stream);
 			nOdList = (int)od.size(); heavyBlocks = 0;
 		}
