@@ -90,6 +90,9 @@ def load_library(precision="f64"):
         "cuba_hip_chi_squares_end": [H],
         "cuba_hip_snapshot_state": [H],
         "cuba_hip_restore_state": [H],
+        "cuba_hip_snapshot_state_slot": [H, C.c_int],
+        "cuba_hip_restore_state_slot": [H, C.c_int],
+        "cuba_hip_get_counter": [H, C.c_char_p, C.POINTER(C.c_int64)],
         "cuba_hip_optimize": [H, C.c_int, _dp, C.POINTER(C.c_int)],
         "cuba_hip_get_solution": [H, _dp, _dp, _dp],
         "cuba_hip_set_solution": [H, _dp, _dp, _dp],
@@ -249,8 +252,8 @@ class HipSolver:
 
     def push(self): self._ck(self.lib.cuba_hip_push(self.h))
     def pop(self): self._ck(self.lib.cuba_hip_pop(self.h))
-    def snapshot_state(self): self._ck(self.lib.cuba_hip_snapshot_state(self.h))
-    def restore_state(self): self._ck(self.lib.cuba_hip_restore_state(self.h))
+    def snapshot_state(self, slot=0): self._ck(self.lib.cuba_hip_snapshot_state_slot(self.h, int(slot)))
+    def restore_state(self, slot=0): self._ck(self.lib.cuba_hip_restore_state_slot(self.h, int(slot)))
 
     def optimize(self, niter):
         chi2 = np.zeros(max(niter, 1))
@@ -290,6 +293,12 @@ class HipSolver:
         self._ck(self.lib.cuba_hip_get_counters(self.h, c))
         return dict(pcg_iterations=int(c[0]), lm_trials=int(c[1]), hsc_blocks=int(c[2]), schur_products=int(c[3]),
                     coarse_refreshes=int(c[4]), pcg_host_looks=int(c[5]), pcg_iterations_enqueued=int(c[6]), coarse_dim=int(c[7]))
+
+    def counter(self, name):
+        """one counter by name (cuba_hip_get_counter), e.g. "coarse_inline_inversions", "pcg_graph_instantiations"."""
+        v = C.c_int64()
+        self._ck(self.lib.cuba_hip_get_counter(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def pcg_history(self):
         """(iterations per reduced solve since set_graph [negative = stopped at max_iter], number of unconverged solves)."""

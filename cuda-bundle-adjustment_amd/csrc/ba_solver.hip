@@ -139,8 +139,11 @@ struct cuba_hip_solver
 	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
 
 	// device: state [q | t | Xw] contiguous (push/pop = one copy), edges, structure, system
-	DevBuf<Scalar> d_state, d_backup, d_cam, d_snapshot;
-	bool haveSnapshot = false;
+	DevBuf<Scalar> d_state, d_backup, d_cam;
+	// caller-controlled copies of the estimates (cuba_hip_snapshot_state[_slot]): slot -> [q | t | Xw] in the INTERNAL pose order that
+	// was in force when the copy was made -- dropped whenever that order changes (applyPoseOrder / resetPoseOrder) or a new graph arrives
+	std::map<int, DevBuf<Scalar>> d_snapshots;
+	void dropSnapshots() { d_snapshots.clear(); }
 	DevBuf<int> d_epose, d_elm, d_lmptr;
 	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
 	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_pairBlk, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
@@ -246,6 +249,7 @@ struct cuba_hip_solver
 		}
 		HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
 		(void)hipGraphDestroy(graph);
+		cntGraphBuilds++;
 		graphBuildSeconds += std::chrono::duration<double>(Clock::now() - tg0).count();
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG graph builds so far: %.3f ms\n", 1e3 * graphBuildSeconds);
 		pcgGraphs[key] = exec;
@@ -326,6 +330,9 @@ struct cuba_hip_solver
 	int maxIterAlloc = 0;
 	long long nmul = 0;
 	int64_t cntPcgIters = 0, cntTrials = 0, cntCoarseRefresh = 0, cntPcgLooks = 0, cntPcgEnqueued = 0, cntPcgUnconverged = 0;
+	int64_t cntCoarseInline = 0;      // coarse inversions that ran on the WORK stream (in front of a solve), a subset of cntCoarseRefresh
+	int64_t cntGraphBuilds = 0;       // hipGraph instantiations of PCG iteration batches
+	int64_t cntFp32Fallbacks = 0;     // solves repeated with the fp64 coarse inverse after the fp32-stored one broke the PCG down
 	bool acceptUnconverged = false;   // true: a solve that hits max_iter hands back its best iterate as a success (inexact LM step)
 	std::vector<int> pcgHistory;      // PCG iterations of every reduced solve since set_graph (negative = stopped at max_iter)
 	double prof[CUBA_HIP_PROFILE_ITEMS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -609,7 +616,7 @@ struct cuba_hip_solver
 			d_cam.upload(camv, stream);
 		}
 		d_backup.resize(nState);
-		haveSnapshot = false;
+		dropSnapshots();
 		d_perEdge.resize(E);
 		if (!h_pinned)
 		{
@@ -649,6 +656,7 @@ struct cuba_hip_solver
 		lambda = 0;
 		for (double& v : prof) v = 0;
 		cntPcgIters = cntTrials = cntCoarseRefresh = cntPcgLooks = cntPcgEnqueued = cntPcgUnconverged = 0;
+		cntCoarseInline = cntGraphBuilds = cntFp32Fallbacks = 0;
 		pcgHistory.clear();
 		prof[0] += std::chrono::duration<double>(Clock::now() - t0).count();
 	}
@@ -1163,6 +1171,7 @@ struct cuba_hip_solver
 	int farOffset() const { return std::max(24, Pf / 8); }      // "far from the diagonal", in block columns
 	void resetPoseOrder()
 	{
+		if (reorderActive) dropSnapshots();          // (they hold rows in the order that ends here)
 		reorderActive = false;
 		poseNewOfOld.resize(Pf); poseOldOfNew.resize(Pf);
 		for (int i = 0; i < Pf; i++) poseNewOfOld[i] = poseOldOfNew[i] = i;
@@ -1285,6 +1294,7 @@ struct cuba_hip_solver
 		topo::launch_remap_poses(d_rawEpCaller.data(), d_poseMap.data(), E, Pf, d_rawEp.data(), stream);
 		runDeviceEdgeSort();
 		sync();          // the host vectors above go out of scope
+		dropSnapshots(); // (round-3 advisor: a snapshot taken in the previous order would assign pose rows to the wrong poses)
 		haveStructure = false; hostTopoValid = false; hostPatternValid = false;
 	}
 
@@ -1500,6 +1510,7 @@ struct cuba_hip_solver
 			sync();
 			const std::vector<int> od = rowGroupedOrder(hRow.data(), [&](int k) { return hEnd[k] - hBeg[k]; }, nblk, hCol.empty() ? nullptr : hCol.data());
 			d_odBlocks.upload(od, stream);
+			sync();          // `od` is a local: the copy must have left it (round-3 advisor)
 			nOdList = (int)od.size(); heavyBlocks = 0;
 		}
 		publishStructure(nblk, nWaves, nBig, nOdList, cc.nc > 0 ? hc[topo::CNT_NCB] : 0, ellM, ellOver, cc);
@@ -1642,9 +1653,27 @@ struct cuba_hip_solver
 	// the trial) but is enqueued right behind the FIRST batch of iterations, speculating that the predicted batch size was
 	// enough -- it is for ~9 solves in 10, and then the whole trial costs one host look instead of two.  If the batch was
 	// too short, `undo` restores what the tail changed, the iterations continue, and *tailValid stays false.
+	// A PCG that BREAKS DOWN (p.Ap <= 0 or a NaN -- not a solve that merely runs out of iterations) while the coarse inverse is stored in
+	// fp32 is repeated once with fp64 storage, which the handle then keeps: rounding a symmetrised inverse to fp32 perturbs it by
+	// ~6e-8 ||Ac^-1||, which can cost positive definiteness once lambda_max(block) / lambda_min(Ac) approaches 1e7 (weakly constrained
+	// graphs at very small damping; round-3 advisor).  Counted in "precond_fp32_fallbacks".
+	bool lastSolveBrokeDown = false;
 	bool solveReduced(const std::function<void()>* tail = nullptr, const std::function<void()>* undo = nullptr, bool* tailValid = nullptr)
 	{
+		const bool ok = solveReducedOnce(tail, undo, tailValid);
+		if (ok || !lastSolveBrokeDown || !fp32Inverse() || sys.agg <= 0) return ok;
+		precondFp32 = false; sys.acinv32 = nullptr;
+		dropPcgGraph();
+		coarseValid = false; firstInvValid = false; firstInvPending = false;
+		cntFp32Fallbacks++;
+		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG broke down with the fp32-stored coarse inverse: repeating the solve with fp64 storage\n");
+		return solveReducedOnce(nullptr, nullptr, nullptr);
+	}
+
+	bool solveReducedOnce(const std::function<void()>* tail, const std::function<void()>* undo, bool* tailValid)
+	{
 		if (tailValid) *tailValid = false;
+		lastSolveBrokeDown = false;
 		need();
 		StageTimer tm(this, 6);
 		if (Pf == 0) return true;
@@ -1700,7 +1729,7 @@ struct cuba_hip_solver
 					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
 					else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
-					coarseValid = true; cntCoarseRefresh++; sideAge = 0;
+					coarseValid = true; cntCoarseRefresh++; cntCoarseInline++; sideAge = 0;
 					if (coarseFirstReuse)
 					{
 						// every run keeps ONE schedule of overlapped inversions -- under trial 1, 1 + period, ... --, whether its first solve was
@@ -1747,7 +1776,7 @@ struct cuba_hip_solver
 					drainInversion();
 					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 					if (fp32Inverse()) launch_coarse_to_fp32(sys.acinv, d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
-					coarseValid = true; coarseAge = 0; cntCoarseRefresh++;
+					coarseValid = true; coarseAge = 0; cntCoarseRefresh++; cntCoarseInline++;
 				}
 				else coarseAge++;
 				coarseFresh = refresh;
@@ -1816,7 +1845,7 @@ struct cuba_hip_solver
 			if (speculate) (*tail)();                                             // ends with its own report
 			else if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (the graphs end with this report)
 			waitReport();
-			if (hInts[0] != 0) { cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; lastSolveIters = 0; failDirty = true; return false; }
+			if (hInts[0] != 0) { lastSolveBrokeDown = true; cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; lastSolveIters = 0; failDirty = true; return false; }
 			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 			if (speculate)
 			{
@@ -1826,7 +1855,15 @@ struct cuba_hip_solver
 			target = k0 + (fixedChunk ? fixedChunk : (looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
 			looks++; cntPcgLooks++;
 		}
-		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued, %d host looks (prediction %d)\n", hInts[1], k0, looks, predicted);
+		if (std::getenv("CUBA_HIP_DEBUG"))
+		{
+			// (debug only: r_0.z_0 of this solve from the partial sums the first preconditioner application left in slot 0)
+			std::vector<Scalar> part((size_t)std::max(1, sys.nrz0));
+			HIP_TRY(hipMemcpyAsync(part.data(), sys.rz, sizeof(Scalar) * part.size(), hipMemcpyDeviceToHost, stream));
+			sync();
+			double rz0 = 0; for (Scalar v : part) rz0 += (double)v;
+			std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued, %d host looks (prediction %d), lambda %.3e, r0.z0 %.6e\n", hInts[1], k0, looks, predicted, lambda, rz0);
+		}
 		const int itersDone = hInts[1];
 		cntPcgIters += itersDone; cntPcgEnqueued += k0;
 		if (runIters.empty()) firstSolveIters = itersDone;
@@ -2286,24 +2323,29 @@ int cuba_hip_compute_scale(cuba_hip_solver* s, double lambda, double* scale)
 	});
 }
 
-int cuba_hip_snapshot_state(cuba_hip_solver* s)
+int cuba_hip_snapshot_state_slot(cuba_hip_solver* s, int slot)
 {
 	return guarded(s, [&] {
+		if (slot < 0 || slot >= CUBA_HIP_SNAPSHOT_SLOTS) throw ArgError{ "snapshot slot out of range" };
 		s->need();
-		s->d_snapshot.resize(s->d_state.size());
-		HIP_TRY(hipMemcpyAsync(s->d_snapshot.data(), s->d_state.data(), s->d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, s->stream));
-		s->haveSnapshot = true;
+		DevBuf<Scalar>& b = s->d_snapshots[slot];
+		b.resize(s->d_state.size());
+		HIP_TRY(hipMemcpyAsync(b.data(), s->d_state.data(), s->d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, s->stream));
 	});
 }
 
-int cuba_hip_restore_state(cuba_hip_solver* s)
+int cuba_hip_restore_state_slot(cuba_hip_solver* s, int slot)
 {
 	return guarded(s, [&] {
 		s->need();
-		if (!s->haveSnapshot || s->d_snapshot.size() != s->d_state.size()) throw StateError{ "no snapshot of this graph's estimates (cuba_hip_snapshot_state)" };
-		HIP_TRY(hipMemcpyAsync(s->d_state.data(), s->d_snapshot.data(), s->d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, s->stream));
+		const auto it = s->d_snapshots.find(slot);
+		if (it == s->d_snapshots.end() || it->second.size() != s->d_state.size()) throw StateError{ "no snapshot of this graph's estimates in that slot (cuba_hip_snapshot_state)" };
+		HIP_TRY(hipMemcpyAsync(s->d_state.data(), it->second.data(), s->d_state.size() * sizeof(Scalar), hipMemcpyDeviceToDevice, s->stream));
 	});
 }
+
+int cuba_hip_snapshot_state(cuba_hip_solver* s) { return cuba_hip_snapshot_state_slot(s, 0); }
+int cuba_hip_restore_state(cuba_hip_solver* s) { return cuba_hip_restore_state_slot(s, 0); }
 
 int cuba_hip_push(cuba_hip_solver* s) { return guarded(s, [&] { s->push(); }); }
 int cuba_hip_pop(cuba_hip_solver* s) { return guarded(s, [&] { s->pop(); }); }
@@ -2365,6 +2407,24 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t c[8])
 	return guarded(s, [&] {
 		c[0] = s->cntPcgIters; c[1] = s->cntTrials; c[2] = s->st.nblk; c[3] = s->nmul;
 		c[4] = s->cntCoarseRefresh; c[5] = s->cntPcgLooks; c[6] = s->cntPcgEnqueued; c[7] = 6 * (int64_t)s->sys.cl * s->sys.nc;
+	});
+}
+
+int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
+{
+	return guarded(s, [&] {
+		if (!name || !value) throw ArgError{ "null argument" };
+		const std::string k(name);
+		if (k == "pcg_iterations") *value = s->cntPcgIters;
+		else if (k == "lm_trials") *value = s->cntTrials;
+		else if (k == "coarse_refreshes") *value = s->cntCoarseRefresh;
+		else if (k == "coarse_inline_inversions") *value = s->cntCoarseInline;
+		else if (k == "pcg_host_looks") *value = s->cntPcgLooks;
+		else if (k == "pcg_iterations_enqueued") *value = s->cntPcgEnqueued;
+		else if (k == "pcg_unconverged_solves") *value = s->cntPcgUnconverged;
+		else if (k == "pcg_graph_instantiations") *value = s->cntGraphBuilds;
+		else if (k == "precond_fp32_fallbacks") *value = s->cntFp32Fallbacks;
+		else throw ArgError{ "unknown counter: " + k };
 	});
 }
 

@@ -199,8 +199,15 @@ int cuba_hip_pop(cuba_hip_solver* s);
    every trial of cuba_hip_optimize): snapshot keeps [q | t | Xw] as they are now, restore brings them back with one device-to-device
    copy on the handle's stream -- repeated runs from one starting point (benchmarks, parameter sweeps) need no host round trip.
    No counterpart in the reference, whose callers re-upload through initialize(). */
-int cuba_hip_snapshot_state(cuba_hip_solver* s);
+int cuba_hip_snapshot_state(cuba_hip_solver* s);      /* = slot 0 */
 int cuba_hip_restore_state(cuba_hip_solver* s);
+/* The same with several copies (slot in [0, CUBA_HIP_SNAPSHOT_SLOTS)): a caller that re-optimises from a SET of starting points --
+   a benchmark whose timed runs must not replay one another, a sweep over perturbations -- prepares them once and switches between
+   them with one device-to-device copy each.  Copies are dropped by cuba_hip_set_graph and whenever the library changes its
+   internal pose order ("pose_reorder"): restoring an absent slot is CUBA_HIP_ERR_STATE, never a silent mix-up of pose rows. */
+enum { CUBA_HIP_SNAPSHOT_SLOTS = 64 };
+int cuba_hip_snapshot_state_slot(cuba_hip_solver* s, int slot);
+int cuba_hip_restore_state_slot(cuba_hip_solver* s, int slot);
 
 /* ---- whole Levenberg-Marquardt run -------------------------------------------------------------- */
 
@@ -234,6 +241,12 @@ int cuba_hip_get_profile(cuba_hip_solver* s, double seconds[CUBA_HIP_PROFILE_ITE
    [6] PCG iterations enqueued (>= [0]: launches after convergence return at once), [7] dimension of the coarse
    system of the two-level preconditioner. */
 int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
+/* One counter by name (totals since cuba_hip_set_graph): the eight above as "pcg_iterations", "lm_trials", "coarse_refreshes",
+   "pcg_host_looks", "pcg_iterations_enqueued", plus "coarse_inline_inversions" (coarse inversions that ran on the work stream in front
+   of a solve -- the others ran on the second stream under an earlier trial's PCG), "pcg_unconverged_solves",
+   "pcg_graph_instantiations" (hipGraphs of PCG iteration batches built), "precond_fp32_fallbacks" (solves repeated with the fp64
+   coarse inverse after the fp32-stored one broke the PCG down).  Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
+int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);
 
 /* PCG iteration count of every reduced solve since cuba_hip_set_graph, oldest first (at most `capacity` are written,
    *n_solves receives their number); a NEGATIVE entry is a solve that stopped at pcg_max_iter with the stop test

@@ -20,13 +20,15 @@ def collect(d, counter):
 fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 def source_sha16():
-    """hash of the kernel sources this profile was taken with (bench.py flags a traffic file from other sources as stale)"""
+    """hash of the device-side sources this profile was taken with: every .hip / .hpp under csrc/ (same function as bench.py's;
+    bench.py flags a traffic file from other sources as stale)"""
     import hashlib
     h = hashlib.sha256()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for f in ("ba_kernels.hip", "ba_math.hpp", "ba_kernels.hpp"):
-        with open(os.path.join(root, "cuda-bundle-adjustment_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    csrc = os.path.join(root, "cuda-bundle-adjustment_amd", "csrc")
+    for f in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
     return h.hexdigest()[:16]
 
 

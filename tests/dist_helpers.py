@@ -109,3 +109,33 @@ def gloo_rank_main(rank, world, port, out_path, graph_args, robust, iters):
             json.dump({"chi2": chi2.tolist(), "q": q.tolist(), "t": t.tolist(), "X": X.tolist()}, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def rccl_rank_main(rank, world, port, out_dir, graph_args, robust, iters, precision="f64"):
+    """One rank of a REAL multi-rank RCCL run of the native driver (tests/test_dist.py, needs `world` GPUs): device = rank, the
+    128-byte RCCL unique id travels through a gloo group (CPU), the communicator itself is the library's own
+    (cuba_hip_dist_create_rccl -> ncclCommInitRank) and every collective runs in-stream on the solver's stream."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.dist import NativeDist, rccl_unique_id
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import synth_ba
+    fp = flatten(synth_ba(**graph_args))
+    ids = [rccl_unique_id(precision) if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    h = HipSolver(fp, robust, device=rank, precision=precision)
+    d = NativeDist(h, fp, rank, world, unique_id=ids[0], precision=precision)
+    chi2 = d.optimize(iters)
+    q, t, X = d.complete_solution()
+    c = d.counters()
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"chi2": chi2.tolist(), "q": q.tolist(), "t": t.tolist(), "X": X.tolist(), "counters": {k: int(v) for k, v in c.items()}}, f)
+    d.close(); h.close()
+    dist.barrier()
+    dist.destroy_process_group()

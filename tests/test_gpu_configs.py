@@ -91,6 +91,34 @@ def test_baseline_shape_full_lm_parity(solvers, name):
     assert all(np.array_equal(a, b) for a, b in zip(h.state(), st))
 
 
+CONFIG4_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_seeds_chi2.json")
+
+
+@pytest.mark.parametrize("seed", list(range(100, 108)))
+def test_config4_graphs_follow_the_oracle(solvers, seed):
+    """BASELINE.json configs[3]: the eight independent KITTI-00-sized graphs `bench.py --gpus N` hands to rank 0..7 (seed
+    100 + rank).  Protocol of samples/sample_comparison_with_g2o.cpp:89-110 per graph: the same 10 iterations on both sides,
+    chi2 per iteration (<= 1e-6 relative, the north star's bar) and final-estimate RMSE per quantity at the stated default
+    tolerance, against the live oracle; the committed golden trajectory every bench rank checks itself against
+    (tests/golden/config4_seeds_chi2.json) must be that oracle run (<= 1e-12: same code, same thread count)."""
+    import json
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_named("kitti00", seed=seed))
+    o = OracleSolver(fp, RK_HUBER); r = o.optimize(10)
+    h = HipSolver(fp, RK_HUBER)
+    got = h.optimize(10)["chi2"]
+    res = check_run(got, h.state(), r["chi2"], o.state(), EST_TOL["default"])
+    assert h.pcg_history()[1] == 0
+    gold = json.load(open(CONFIG4_GOLDEN))["seeds"][str(seed)]
+    assert (gold["P"], gold["L"], gold["E"]) == (fp.Pt, fp.Lt, fp.E)
+    gchi = np.array(gold["chi2"])
+    assert len(gchi) == len(r["chi2"]) and np.all(np.abs(gchi - r["chi2"]) <= 1e-12 * r["chi2"])
+    assert gold["trials"] == [int(v) for v in r["trials"]]
+    print(f"\n[config 4, seed {seed}] chi2 rel {res['chi2']:.2e}  RMSE q {res['q']:.2e} t {res['t']:.2e} X {res['X']:.2e}  "
+          f"PCG iterations {int(h.counters()['pcg_iterations'])}")
+    h.close()
+
+
 @pytest.mark.parametrize("name", ["kitti00", "s2m"])
 def test_tight_tolerance_estimates(solvers, name):
     """pcg_tol = 1e-10: the estimates agree with the exact-solve oracle to the nanometre."""

@@ -136,6 +136,83 @@ def test_push_pop_and_set_state(solvers, small_fp):
     assert np.array_equal(h0.optimize(4)["chi2"], a)         # without the reuse every run is a function of its start alone
 
 
+def test_snapshot_slots_and_named_counters(solvers, small_fp):
+    """cuba_hip_snapshot_state_slot / _restore_state_slot: several device-side copies of the estimates (bench.py's non-replay
+    protocol); slot 0 is the slot-less pair; an absent or out-of-range slot is a reported error.  cuba_hip_get_counter: the
+    eight positional counters by name + the in-line coarse inversions and graph instantiations bench.py reports."""
+    from cuba_amd.capi import CubaHipError
+    HipSolver, _ = solvers
+    h = HipSolver(small_fp, RK_HUBER)
+    h.optimize(1)
+    a = h.state(); h.snapshot_state(3)
+    h.optimize(2)
+    b = h.state(); h.snapshot_state(0)
+    h.optimize(1)
+    h.restore_state(3)
+    assert all(np.array_equal(x, y) for x, y in zip(h.state(), a))
+    h.restore_state()                                               # = slot 0
+    assert all(np.array_equal(x, y) for x, y in zip(h.state(), b))
+    for bad in (5, -1, 64):
+        with pytest.raises(CubaHipError):
+            h.restore_state(bad)
+    with pytest.raises(CubaHipError):
+        h.snapshot_state(64)
+    c = h.counters()
+    assert h.counter("pcg_iterations") == c["pcg_iterations"] and h.counter("lm_trials") == c["lm_trials"] == 4
+    assert h.counter("coarse_refreshes") == c["coarse_refreshes"] and h.counter("pcg_iterations_enqueued") == c["pcg_iterations_enqueued"]
+    # the first run on a structure inverts its first coarse matrix on the work stream, later runs start with the carried-over inverse
+    assert h.counter("coarse_inline_inversions") == 1 and h.counter("pcg_graph_instantiations") >= 1
+    assert h.counter("precond_fp32_fallbacks") == 0 and h.counter("pcg_unconverged_solves") == 0
+    with pytest.raises(CubaHipError):
+        h.counter("no_such_counter")
+    h.set_graph(small_fp)                                           # a new upload drops every copy
+    with pytest.raises(CubaHipError):
+        h.restore_state(3)
+
+
+def test_snapshot_is_dropped_when_the_internal_pose_order_changes(solvers):
+    """Round-3 advisor: a snapshot holds pose rows in the internal order in force when it was taken; a structure rebuild that
+    changes that order (here: device_setup = 0 sends a renumbered handle back to the caller's order) must not let a later
+    restore assign rows to the wrong poses -- the copy is dropped and the restore reports it."""
+    from cuba_amd.capi import CubaHipError
+    from test_gpu_configs import shuffled_pose_ids
+    HipSolver, _ = solvers
+    fp = flatten(shuffled_pose_ids(synth_ba(200, 8000, 32000, seed=13), seed=2))
+    h = HipSolver(fp, RK_HUBER)
+    h.optimize(1)
+    want = h.state()
+    h.snapshot_state()
+    h.restore_state()
+    assert all(np.array_equal(x, y) for x, y in zip(h.state(), want))
+    h.set_option("device_setup", 0)                                 # host pipeline: runs in the caller's order
+    h.build_structure()
+    assert all(np.array_equal(x, y) for x, y in zip(h.state(), want))     # the estimates themselves moved with the order
+    with pytest.raises(CubaHipError):
+        h.restore_state()
+
+
+def test_fp32_coarse_inverse_falls_back_when_the_pcg_breaks_down(solvers):
+    """Round-3 advisor: the coarse inverse is STORED in fp32 by default; rounding can cost it positive definiteness when
+    lambda_max(block) / lambda_min(Ac) approaches 1e7.  A gauge-free monocular graph (7 unconstrained directions held by the
+    damping alone) at very small damping is such a system.  Whatever the fp32 operator does there, the solve must come back
+    converged -- repeated with fp64 storage if the PCG broke down (counted) -- and agree with the fp64-storage handle."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(96, 3000, 12000, seed=21, stereo_frac=0.0, fix_first=False))
+    o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
+    md = o.max_diagonal()
+    for scale in (1e-9, 1e-11):
+        h32 = HipSolver(fp, RK_HUBER, pcg_tol=1e-9, pcg_aggregate=8); h32.max_diagonal(); h32.set_lambda(scale * md)
+        h64 = HipSolver(fp, RK_HUBER, pcg_tol=1e-9, pcg_aggregate=8, precond_fp32=0); h64.max_diagonal(); h64.set_lambda(scale * md)
+        ok32, ok64 = h32.solve(), h64.solve()
+        it32, it64 = h32.pcg_history()[0], h64.pcg_history()[0]
+        print(f"\n[lambda = {scale:g} max-diag] fp32 storage: ok {ok32}, iterations {it32.tolist()}, fallbacks {h32.counter('precond_fp32_fallbacks')}; "
+              f"fp64 storage: ok {ok64}, iterations {it64.tolist()}")
+        assert ok64 and ok32                                        # never a failed solve because of the storage precision
+        x32, x64 = h32.array("xp"), h64.array("xp")
+        assert np.abs(x32 - x64).max() <= 1e-5 * np.abs(x64).max()
+        h32.close(); h64.close()
+
+
 @pytest.mark.parametrize("rk", [RK_NONE, RK_HUBER, RK_TUKEY])
 def test_lm_parity_robust_kernels(solvers, small_fp, rk):
     compare_lm(*solvers, small_fp, rk, 8)

@@ -176,3 +176,19 @@ def test_baseline_shape_golden_kitti07():
     assert (fp.Pt, fp.Lt, fp.E) == (e["P"], e["L"], e["E"])
     got = OracleSolver(fp, rk).optimize(gold["iterations"])["chi2"]
     assert len(got) == len(e["chi2"]) and np.allclose(got, e["chi2"], rtol=1e-12)
+
+
+def test_config4_golden_seed100():
+    """tests/golden/config4_seeds_chi2.json (what every rank of `bench.py --gpus N` checks its graph's run against) is the CPU
+    oracle's trajectory: re-derived here for rank 0's graph (seed 100, ~4 s of one core); the GPU suite re-derives all eight."""
+    import json
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import synth_named
+    from oracle.oracle import OracleSolver
+    with open(os.path.join(os.path.dirname(__file__), "golden", "config4_seeds_chi2.json")) as f:
+        gold = json.load(f)
+    rk = tuple((int(k), float(d)) for k, d in gold["robust"])
+    fp = flatten(synth_named(gold["shape"], seed=100))
+    r = OracleSolver(fp, rk).optimize(gold["iterations"])
+    want = np.array(gold["seeds"]["100"]["chi2"])
+    assert len(r["chi2"]) == len(want) and np.all(np.abs(r["chi2"] - want) <= 1e-12 * want)

@@ -20,12 +20,17 @@ ORACLE_TOL = 1e-9     # same algorithm, exact solves on both sides: summation-or
 HIP_TOL = 1e-8        # HIP path at pcg_tol = 1e-11; at the default pcg_tol the bar is the north star's 1e-6
 
 
-def rough_start(g, seed=1, sx=3.0, st=0.6):
+def rough_start(g, seed=1, sx=3.0, st=0.6, sr=0.0):
+    """landmarks + N(0, sx) m, free-pose translations + N(0, st) m, free-pose rotations composed with exp(N(0, sr) rad)"""
     h = copy.deepcopy(g)
     rng = np.random.default_rng(seed)
     h.lm_X = h.lm_X + rng.normal(0, sx, h.lm_X.shape)
     free = ~h.pose_fixed
     h.pose_t = h.pose_t.copy(); h.pose_t[free] += rng.normal(0, st, (int(free.sum()), 3))
+    if sr > 0:
+        from scipy.spatial.transform import Rotation
+        dq = Rotation.from_rotvec(rng.normal(0, sr, (int(free.sum()), 3)))
+        h.pose_q = h.pose_q.copy(); h.pose_q[free] = (dq * Rotation.from_quat(h.pose_q[free])).as_quat()
     return h
 
 
@@ -43,10 +48,26 @@ def cases():
 def full_size_cases():
     """BASELINE configs[0] and configs[1] at full size (round-2 verdict: the reference-run pins stopped at 120 poses).
     KITTI-07 shape: n = 1482, the reference's stand-in linear solver factorises it on the host as before; KITTI-00 shape:
-    n = 7986, the same exact dense Cholesky through rocSOLVER on the device (oracle/ref_build/ref_linear_solver.cpp)."""
+    n = 7986, the same exact dense Cholesky through rocSOLVER on the device (oracle/ref_build/ref_linear_solver.cpp).
+    Round 4: S2M (configs[2]; n = 29 994 -- 7.2 GB dense, ~9 TFLOP per factorisation, 11 of them) and, opt-in
+    (CUBA_TEST_REF_G4M=1), configs[4]'s graph (n = 59 994 -- 28.8 GB dense, ~72 TFLOP per factorisation).
+    name -> (graph factory, robust kernels, iterations): graphs are generated only for the case that runs."""
     from cuba_amd.synth import synth_named
-    yield "kitti07_full", synth_named("kitti07"), RK_HUBER, 10
-    yield "kitti00_full", synth_named("kitti00"), RK_HUBER, 10
+    return {"kitti07_full": (lambda: synth_named("kitti07"), RK_HUBER, 10),
+            "kitti00_full": (lambda: synth_named("kitti00"), RK_HUBER, 10),
+            "s2m_full": (lambda: synth_named("s2m"), RK_HUBER, 10),
+            "g4m_full": (lambda: synth_named("g4m"), RK_HUBER, 10)}
+
+
+def rejected_trial_cases():
+    """Full KITTI-00 shape from starts that make the REFERENCE reject trials (restore + lambda *= nu, nu *= 2:
+    src/cuda_bundle_adjustment.cpp:824-845) inside a well-conditioned stretch of the run.  Found with the oracle: rejections in
+    iterations 10 and 12 / 11 and 13 (three trials each), and the trajectory is stable against summation-order noise (1 vs 16
+    oracle threads: <= 5e-12 / 1e-9 on chi2).  A 30-iteration Huber run that only starts rejecting at lambda ~ 1e-14 x max-diag is
+    chaotic instead -- 40 % apart between 1 and 16 threads -- and cannot pin anything."""
+    from cuba_amd.synth import synth_named
+    return {"k00_rot0.5rad_none": (lambda: rough_start(synth_named("kitti00"), seed=1, sx=0.0, st=0.0, sr=0.5), RK_NONE, 14),
+            "k00_lm10m_tukey": (lambda: rough_start(synth_named("kitti00"), seed=1, sx=10.0, st=0.0, sr=0.0), RK_TUKEY, 14)}
 
 
 def in_graph_order(fp, g, state):
@@ -105,16 +126,20 @@ def test_warm_start_protocol_follows_the_reference():
     assert len(got) == len(ref2["chi2"]) and np.all(np.abs(got - ref2["chi2"]) <= HIP_TOL * ref2["chi2"])
 
 
-@pytest.mark.parametrize("name", ["kitti07_full", "kitti00_full"])
+@pytest.mark.parametrize("name", ["kitti07_full", "kitti00_full", "s2m_full", "g4m_full"])
 def test_full_size_lm_trajectory_follows_the_reference(name):
     """The reference's own optimiser (its LM loop, block solver and all kernels, compiled in place) at the full BASELINE
     shapes, under the samples' protocol (sample_comparison_with_g2o.cpp:303-307): initialize() + optimize(1) warm-up, then
     initialize() + optimize(10) from the written-back estimates.  The CPU oracle must follow it to <= 1e-9 on every
     per-iteration chi2, the HIP path to <= 1e-8 at pcg_tol = 1e-11 and to <= 1e-6 (the north star's bar) at the default
     tolerance; final estimates and per-edge chi2 likewise.  All deviations are printed before anything is asserted."""
+    import os
     from cuba_amd.capi import HipSolver
     from oracle.oracle import OracleSolver
-    g, rk, iters = {c[0]: c[1:] for c in full_size_cases()}[name]
+    if name == "g4m_full" and os.environ.get("CUBA_TEST_REF_G4M") != "1":
+        pytest.skip("28.8 GB dense stand-in factorisation, ~72 TFLOP each: opt-in with CUBA_TEST_REF_G4M=1")
+    make, rk, iters = full_size_cases()[name]
+    g = make()
     # warm-up run of the reference, then the timed-protocol run from its written-back estimates
     warm = ref_lm.run(g, rk, 1)
     g1 = copy.deepcopy(g); g1.pose_q, g1.pose_t, g1.lm_X = warm["q"], warm["t"], warm["Xw"]
@@ -149,3 +174,39 @@ def test_full_size_lm_trajectory_follows_the_reference(name):
         lim = 1e-7 if k.startswith("oracle") else 1e-6 if "tight" in k else (1e-8 if k.endswith(" q") else 1e-6) * 10
         assert v <= lim, (k, v, lim)
     assert dev["hip tight per-edge chi2 (abs / max)"] <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["k00_rot0.5rad_none", "k00_lm10m_tukey"])
+def test_full_size_rejected_trials_follow_the_reference(name):
+    """A run at BASELINE size (KITTI-00 shape) in which the reference's own optimiser REJECTS trials -- the restore / lambda *= nu,
+    nu *= 2 path of src/cuda_bundle_adjustment.cpp:824-845, so far exercised at <= 60 poses only.  The reference (its LM loop, block
+    solver and kernels compiled in place, exact dense Cholesky through rocSOLVER in cuSOLVER's seat) runs 14 iterations from a rough
+    start; the oracle must follow it to <= 1e-9 on every per-iteration chi2 with the same trial counts, the HIP path to <= 1e-8 at
+    pcg_tol = 1e-11 and <= 1e-6 at the default tolerance, with exactly the oracle's number of trials; final estimates likewise."""
+    from cuba_amd.capi import HipSolver
+    from oracle.oracle import OracleSolver
+    make, rk, iters = rejected_trial_cases()[name]
+    g = make()
+    ref = ref_lm.run(g, rk, iters)
+    fp = flatten(g)
+    o = OracleSolver(fp, rk); ro = o.optimize(iters)
+    assert ro["trials"].max() > 1, ro["trials"]                       # the case really rejects trials
+    dev = {"oracle chi2": float(np.abs(ro["chi2"] / ref["chi2"] - 1).max()) if len(ro["chi2"]) == len(ref["chi2"]) else np.inf}
+    est, trials = {}, {}
+    for label, opts in (("hip tight", dict(pcg_tol=1e-11)), ("hip default", dict())):
+        h = HipSolver(fp, rk, **opts); rh = h.optimize(iters)["chi2"]
+        dev[label + " chi2"] = float(np.abs(rh / ref["chi2"] - 1).max()) if len(rh) == len(ref["chi2"]) else np.inf
+        trials[label] = h.counters()["lm_trials"]
+        for nm, a, b in zip("qtX", in_graph_order(fp, g, h.state()), (ref["q"], ref["t"], ref["Xw"])):
+            est[f"{label} {nm}"] = float(np.abs(a - b).max())
+        assert h.pcg_history()[1] == 0
+        h.close()
+    for nm, a, b in zip("qtX", in_graph_order(fp, g, o.state()), (ref["q"], ref["t"], ref["Xw"])):
+        est[f"oracle {nm}"] = float(np.abs(a - b).max())
+    print(f"\n[{name}] trials per iteration {ro['trials'].tolist()} vs the reference's own optimiser: "
+          + ", ".join(f"{k} {v:.2e}" for k, v in {**dev, **est}.items()))
+    assert dev["oracle chi2"] <= 1e-9 and dev["hip tight chi2"] <= 1e-8 and dev["hip default chi2"] <= 1e-6, dev
+    assert trials["hip tight"] == trials["hip default"] == int(ro["trials"].sum()), (trials, ro["trials"])
+    for k, v in est.items():
+        lim = 1e-7 if k.startswith("oracle") else 1e-6 if "tight" in k else 1e-5
+        assert v <= lim, (k, v, lim)
