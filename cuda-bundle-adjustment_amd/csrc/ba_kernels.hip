@@ -3538,6 +3538,26 @@ __global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n
 	}
 }
 
+// Forcing term of the inexact Levenberg-Marquardt step (option "pcg_forcing"): one wave between the first preconditioner application
+// of a solve and its first iteration.  The stop test of every iteration kernel is r_k.z_k <= tol^2 * sum(slot 0 of rz), slot 0 holding
+// the per-workgroup partials of r_0.z_0; this kernel fills ONE extra partial behind them with max(0, eta^2 * ref - r_0.z_0), ref =
+// r_0.z_0 of the first solve of the LM run (stored here when isFirst != 0) -- so the test becomes r_k.z_k <= tol^2 max(r_0.z_0, eta^2 ref)
+// without a single extra load in the iteration kernels.  Fixed summation order: reproducible.
+__global__ __launch_bounds__(64) void pcg_forcing_kernel(DeviceSystem sys, int nReal, Scalar eta2, int isFirst, Scalar* ref)
+{
+	const int lane = threadIdx.x;
+	const Scalar rz0 = wave_sum(load_parts(sys.rz, nReal, lane));
+	if (lane != 0) return;
+	if (isFirst) { *ref = rz0; sys.rz[nReal] = 0; return; }
+	const Scalar want = eta2 * *ref;
+	sys.rz[nReal] = want > rz0 ? want - rz0 : Scalar(0);
+}
+
+void launch_pcg_forcing(const DeviceSystem& sys, Scalar eta2, int isFirst, Scalar* ref, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_forcing_kernel, dim3(1), dim3(64), 0, s, sys, sys.nrz0 - 1, eta2, isFirst, ref);
+}
+
 // {chi2, landmark part of the gain-ratio denominator, pose part} of the evaluation just enqueued -> three device scalars
 // (the multi-GPU driver all-reduces the first two in-stream instead of reading them back rank by rank)
 __global__ void collect_eval_kernel(const Scalar* slots, Scalar* out)

@@ -214,6 +214,10 @@ void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, co
 // out3 = {chi2 total, landmark scale part, pose scale part} gathered from the result slots of the kernels enqueued before
 void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s);
 
+// forcing term of the inexact LM step: fills the extra partial behind the r_0.z_0 partials (sys.nrz0 counts it) with
+// max(0, eta2 * *ref - r_0.z_0); isFirst != 0 stores r_0.z_0 into *ref instead (first solve of an LM run)
+void launch_pcg_forcing(const DeviceSystem& sys, Scalar eta2, int isFirst, Scalar* ref, hipStream_t s);
+
 // copies {fail, iters, done} into sys.host_flags (what the last node of an iteration graph does anyway)
 void launch_pcg_report(const DeviceSystem& sys, hipStream_t s);
 

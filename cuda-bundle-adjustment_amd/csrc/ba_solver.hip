@@ -155,6 +155,12 @@ struct cuba_hip_solver
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
+	// Forcing term of the inexact LM step (option "pcg_forcing" = eta, 0 = off): inside an LM run (cuba_hip_optimize, or a driver's
+	// cuba_hip_begin_run + stage calls) a solve stops at r.z <= pcg_tol^2 max(r_0.z_0, eta^2 ref), ref = r_0.z_0 of the run's first solve --
+	// late solves, whose right-hand side is orders of magnitude below the first one's, are not driven pcg_tol below THEIR start
+	DevBuf<Scalar> d_rzRef;
+	double pcgForcing = 0;
+	bool inRun = false, forcingSlotDirty = false;
 	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<float> d_coarse32[2];  // option precond_fp32 (fp64 library): the inverse in use in fp32 [0] + the staging copy an overlapped inversion leaves [1]
 	// The inverse the FIRST solve of the previous LM run was given (same damping regime: lambda_0 = tau * max diagonal): it serves the first
@@ -651,7 +657,7 @@ struct cuba_hip_solver
 			if (std::memcmp(&a, &b, sizeof(DeviceGraph)) != 0) dropPcgGraph();
 			haveStructure = true;
 		}
-		coarseValid = false; startRunHistory();
+		coarseValid = false; startRunHistory(); inRun = false;
 		haveGraph = true;
 		lambda = 0;
 		for (double& v : prof) v = 0;
@@ -1031,8 +1037,9 @@ struct cuba_hip_solver
 		d_rc.resize((size_t)12 * c.cl * c.nc); d_r2.resize((size_t)6 * Pf);
 		maxIterAlloc = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		const int gridSetup = (Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + c.spmvRows - 1) / c.spmvRows;
-		rzStrideCfg = std::max(1, std::max(std::max(gridSetup, gridUpd), c.nc)); pqStrideCfg = std::max(1, gridSpmv);
+		rzStrideCfg = std::max(1, std::max(std::max(gridSetup, gridUpd), c.nc)) + 1; pqStrideCfg = std::max(1, gridSpmv);   // (+ 1: the forcing term's extra partial of slot 0)
 		d_rz.resize((size_t)5 * rzStrideCfg); d_pq.resize((size_t)4 * pqStrideCfg);
+		d_rz.zero(stream); d_rzRef.resize(1);
 	}
 
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
@@ -1121,7 +1128,8 @@ struct cuba_hip_solver
 		dropPcgGraph();
 		firstInvValid = false; firstInvPending = false; prevRunIters.clear();
 		sys.rzStride = rzStrideCfg; sys.pqStride = pqStrideCfg; sys.npq = gridSpmv;
-		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
+		sys.nrz0 = (agg > 0 ? nc : gridSetup) + 1; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();   // (slot 0: the partials of r_0.z_0 + the forcing term's, zero unless "pcg_forcing" is at work)
+		forcingSlotDirty = false;
 		coarseValid = false;
 		d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); d_gjPivots.resize(2 * 32 * 32); sys.gj_pivots = d_gjPivots.data();
 		sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
@@ -1670,6 +1678,21 @@ struct cuba_hip_solver
 		return solveReducedOnce(nullptr, nullptr, nullptr);
 	}
 
+	// between the first preconditioner application of a solve (which leaves the partials of r_0.z_0) and its first iteration
+	void applyForcing()
+	{
+		if (inRun && pcgForcing > 0)
+		{
+			launch_pcg_forcing(sys, (Scalar)(pcgForcing * pcgForcing), runIters.empty() ? 1 : 0, d_rzRef.data(), stream);
+			forcingSlotDirty = true;
+		}
+		else if (forcingSlotDirty)
+		{
+			HIP_TRY(hipMemsetAsync(sys.rz + (sys.nrz0 - 1), 0, sizeof(Scalar), stream));
+			forcingSlotDirty = false;
+		}
+	}
+
 	bool solveReducedOnce(const std::function<void()>* tail, const std::function<void()>* undo, bool* tailValid)
 	{
 		if (tailValid) *tailValid = false;
@@ -1702,6 +1725,7 @@ struct cuba_hip_solver
 			launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? reinterpret_cast<const Scalar*>(d_coarse32[1].data()) : nullptr,
 				reinterpret_cast<Scalar*>(d_coarse32[0].data()), inv32Count() / 2);
 		else launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
+		if (!twoLevel) applyForcing();
 		if (twoLevel)
 		{
 			// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
@@ -1782,6 +1806,7 @@ struct cuba_hip_solver
 				coarseFresh = refresh;
 			}
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
+			applyForcing();
 			if (sys.cg1)
 			{
 				// single-kernel iterations start from u_0 (just computed), w_0 = A u_0 and their restricted vectors
@@ -1928,6 +1953,8 @@ struct cuba_hip_solver
 		need();
 		coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
 		startRunHistory();
+		inRun = true;
+		struct EndRun { bool& f; ~EndRun() { f = false; } } endRun{ inRun };
 		const int maxq = 10;
 		const double tau = 1e-5;
 		double nu = 2, lam = 0, F = 0;
@@ -2229,6 +2256,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		if (!key) throw ArgError{ "null key" };
 		const std::string k(key);
 		if (k == "pcg_tol") s->pcgTol = value;
+		else if (k == "pcg_forcing") s->pcgForcing = std::max(0.0, value);
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
 		else if (k == "spin_wait") s->spinWait = value != 0;
@@ -2587,7 +2615,7 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 
 int cuba_hip_begin_run(cuba_hip_solver* s)
 {
-	return guarded(s, [&] { s->need(); s->coarseValid = false; s->startRunHistory(); });
+	return guarded(s, [&] { s->need(); s->coarseValid = false; s->startRunHistory(); s->inRun = true; });
 }
 
 int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream)
