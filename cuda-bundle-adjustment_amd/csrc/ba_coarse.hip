@@ -1,0 +1,378 @@
+// ba_coarse.hip -- coarse level of the two-level preconditioner: assembly of P^T A P from the reduced matrix and its explicit
+// inverse by a blocked Gauss-Jordan sweep (tile products on the matrix cores: v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32),
+// plus the fp32 copy the iteration kernels read.  Stands where the reference calls cuSOLVER's csrcholFactor
+// (/root/reference/src/cuda_linear_solver.cpp:147-232); runs on a second stream under the PCG of an earlier trial.
+
+#include "ba_device.hpp"
+
+namespace cubahip
+{
+
+// ---------------------------------------------------------------------------------------------------
+// Two-level preconditioner  M^-1 = blockdiag(A)^-1 + P (P^T A P)^-1 P^T.
+// P is piecewise constant over aggregates of `agg` consecutive free poses (6 coarse dof per aggregate):
+// keyframe chains are stiff along the trajectory, and these are exactly the slowly converging drift
+// modes of block-Jacobi CG (1887 -> 226 iterations on the KITTI-00-shaped system at lambda_9).
+// The coarse matrix is dense and small (6*nc <= ~1500), so its explicit inverse is formed on the device by
+// a blocked Gauss-Jordan sweep (SPD => no pivoting) and applied as a dense mat-vec inside the PCG.
+// ---------------------------------------------------------------------------------------------------
+// one 64-lane wave per non-empty pair of aggregates (I,J): lanes 0..35 own one element of the 6x6 blocks and add the fine
+// blocks of the list in a fixed order (no atomics => the coarse matrix, its inverse and hence the whole CG are
+// reproducible).  With the linear coarse functions (cl = 2) a fine block (i,j) goes into four coarse blocks with the
+// weights 1, w_j, w_i, w_i w_j.
+__global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st, DeviceSystem sys, Scalar* Ac, int Pf)
+{
+	// one workgroup per pair of aggregates: its four waves take every fourth entry of the list, the partial sums are
+	// added in wave order
+	__shared__ Scalar sh[4][4][36];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int cb = blockIdx.x;
+	const int r = lane % 6, c = (lane / 6) % 6;
+	const int CD = 6 * sys.cl, Nc = CD * sys.nc;
+	Scalar acc[2][2] = { { 0, 0 }, { 0, 0 } };
+	const int p1 = st.cb_ptr[cb + 1];
+	for (int p = st.cb_ptr[cb] + wv; p < p1; p += 16)
+	{
+		int b[4]; Scalar v[4], wi[4], wj[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+		{
+			const int q = min(p + 4 * m, p1 - 1);
+			b[m] = st.cb_blk[q];
+			wi[m] = sys.cl == 2 ? st.cb_wi[q] : Scalar(0); wj[m] = sys.cl == 2 ? st.cb_wj[q] : Scalar(0);
+		}
+#pragma unroll
+		for (int m = 0; m < 4; m++) v[m] = p + 4 * m < p1 ? sys.hsc[36 * (size_t)(b[m] & 0x7fffffff) + (b[m] < 0 ? r * 6 + c : c * 6 + r)] : Scalar(0);
+#pragma unroll
+		for (int m = 0; m < 4; m++) { acc[0][0] += v[m]; acc[0][1] += v[m] * wj[m]; acc[1][0] += wi[m] * v[m]; acc[1][1] += wi[m] * v[m] * wj[m]; }
+	}
+	if (lane < 36)
+	{
+		sh[wv][0][lane] = acc[0][0]; sh[wv][1][lane] = acc[0][1]; sh[wv][2][lane] = acc[1][0]; sh[wv][3][lane] = acc[1][1];
+	}
+	__syncthreads();
+	if (threadIdx.x >= 36 * 4) return;
+	const int ab = threadIdx.x / 36, el = threadIdx.x - 36 * ab, a = ab >> 1, bb = ab & 1;
+	if (a >= sys.cl || bb >= sys.cl) return;
+	Scalar v = ((sh[0][ab][el] + sh[1][ab][el]) + sh[2][ab][el]) + sh[3][ab][el];
+	const int rr = el % 6, cc = el / 6;
+	if (ab == 3 && st.cb_I[cb] == st.cb_J[cb] && st.cb_I[cb] == sys.nc - 1 && Pf % sys.agg == 1) v = rr == cc ? Scalar(1) : Scalar(0);
+	Ac[(size_t)(st.cb_J[cb] * CD + 6 * bb + cc) * Nc + st.cb_I[cb] * CD + 6 * a + rr] = v;
+}
+
+constexpr int GJ_B = 32;      // pivot block width of the Gauss-Jordan sweep = output tile edge
+
+// 16 x 16 x 4 matrix-core step in the library's Scalar: v_mfma_f64_16x16x4_f64 (fp64 build) / v_mfma_f32_16x16x4_f32 (fp32 build).
+// Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives 4 results of column l & 15, in rows (l >> 4) + 4 q (f64)
+// or 4 (l >> 4) + q (f32), q = 0..3.
+#ifdef CUBA_HIP_FLOAT32
+typedef float MfmaAcc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MfmaAcc mfma_16x16x4(float a, float b, MfmaAcc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mfma_row(int lane, int q) { return 4 * (lane >> 4) + q; }
+#else
+typedef double MfmaAcc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MfmaAcc mfma_16x16x4(double a, double b, MfmaAcc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mfma_row(int lane, int q) { return (lane >> 4) + 4 * q; }
+#endif
+__device__ __forceinline__ MfmaAcc mfma_zero() { return MfmaAcc{ 0, 0, 0, 0 }; }
+__device__ __forceinline__ Scalar mfma_get(const MfmaAcc& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// Inverse of the 32 x 32 block a 256-thread workgroup holds as Dcur[r][c] in LDS (Dnext: identity outside [0, bk)^2): 2x2 block
+// pivots -- 16 dependent steps instead of 32, one reciprocal (v_rcp_f64 + two Newton steps: the pivots of an SPD matrix are
+// positive and well scaled) per step -- ping-ponging between the two LDS copies so that one barrier per step is enough.
+// Returns the array holding the result (callers synchronise before reading it: the last step ends with a barrier).
+// The chain is instruction issue + latency of one wave per SIMD (every element changes in every step), so the thread -> element
+// map is chosen for the fewest instructions: thread (c, rb) = (tid & 31, tid >> 5) owns rows rb + 8u of column c, hence one
+// (W D[P][c]) pair per thread instead of one per element, and whether a row is a pivot row is uniform over a wave (rows rb + 8u,
+// rb in {2w, 2w + 1}: the pivot rows p, p + 1 are the element u = p / 8 of wave w = (p mod 8) / 2) -- a scalar branch, no selects.
+__device__ __forceinline__ Scalar (*gj_pivot_inverse(Scalar (*Dcur)[GJ_B + 1], Scalar (*Dnext)[GJ_B + 1], int tid, int bk))[GJ_B + 1]
+{
+	const int c = tid & 31, rb = tid >> 5;
+	const int wv2 = 2 * __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int bkPad = (bk + 1) & ~1;
+	Scalar d[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) d[u] = Dcur[rb + 8 * u][c];
+	for (int p = 0; p < bkPad; p += 2)
+	{
+		const Scalar a00 = Dcur[p][p], a01 = Dcur[p][p + 1], a10 = Dcur[p + 1][p], a11 = Dcur[p + 1][p + 1];
+		const Scalar m0 = Dcur[p][c], m1 = Dcur[p + 1][c];
+		Scalar mi0[4], mi1[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { mi0[u] = Dcur[rb + 8 * u][p]; mi1[u] = Dcur[rb + 8 * u][p + 1]; }
+		const Scalar rdet = fast_rcp(a00 * a11 - a01 * a10);
+		const Scalar w00 = a11 * rdet, w01 = -a01 * rdet, w10 = -a10 * rdet, w11 = a00 * rdet;     // W = inverse of the 2x2 pivot block
+		const Scalar t0 = w00 * m0 + w01 * m1, t1 = w10 * m0 + w11 * m1;                           // (W D[P][c])
+		const bool jp = c == p || c == p + 1;
+		const Scalar wA = c == p ? w00 : w01, wB = c == p ? w10 : w11;                              // column c - p of W
+		const bool pivotWave = (p & 7) == wv2;                                                        // (scalar)
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int r = rb + 8 * u;
+			Scalar v;
+			if (pivotWave && u == (p >> 3))          // rows p (rb even) and p + 1 (rb odd)
+			{
+				const Scalar vRow = r == p ? t0 : t1;
+				const Scalar vBoth = r == p ? wA : wB;
+				v = jp ? vBoth : vRow;
+			}
+			else
+			{
+				const Scalar vGen = d[u] - (mi0[u] * t0 + mi1[u] * t1);
+				const Scalar vCol = -(mi0[u] * wA + mi1[u] * wB);
+				v = jp ? vCol : vGen;
+			}
+			if (r < bkPad && c < bkPad) { d[u] = v; Dnext[r][c] = v; }
+		}
+		__syncthreads();
+		Scalar (*tmp)[GJ_B + 1] = Dcur; Dcur = Dnext; Dnext = tmp;
+	}
+	return Dcur;
+}
+
+// Inverse of the first pivot block (rows / columns [0, bk)) of the sweep -> pivOut[c * 32 + r]; every later pivot block is
+// inverted by the step before it (below).
+__global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar* __restrict__ src, int n, int bk, Scalar* __restrict__ pivOut)
+{
+	__shared__ Scalar D[GJ_B][GJ_B + 1];
+	__shared__ Scalar D2[GJ_B][GJ_B + 1];
+	const int tid = threadIdx.x, r = tid & 31, cb = tid >> 5;
+	Scalar dv[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) dv[u] = src[(size_t)min(cb + 8 * u, n - 1) * n + min(r, n - 1)];
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u;
+		dv[u] = (r < bk && c < bk) ? dv[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short block
+		D[r][c] = dv[u];
+		D2[r][c] = r == c ? Scalar(1) : Scalar(0);
+	}
+	__syncthreads();
+	Scalar (*res)[GJ_B + 1] = gj_pivot_inverse(D, D2, tid, bk);
+#pragma unroll
+	for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
+}
+
+// One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B: dst = GJ_step(src). After the
+// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile (or per colsPerGroup tiles of one tile row); thread
+// (r, cb) owns the elements (r, cb + 8u), u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32
+// dependent launches), so:
+//   * every global load of the kernel is issued before the first use (clamped addresses, selected afterwards);
+//   * the inverse of the pivot block comes in ready-made (pivIn): the workgroup that produced the NEXT pivot block in the
+//     previous step -- tile (p0/32 + 1, p0/32 + 1) is final for this purpose once step p0 has updated it -- inverted it right
+//     away (look-ahead).  One workgroup runs the 16-step chain per launch instead of all of them (twice as slow when two
+//     workgroups share a CU), and it has its CU nearly to itself by then: 15.9 -> ~10 us per step;
+//   * the two 32x32x32 products run on the matrix cores.
+__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk, int colsPerGroup,
+	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
+{
+	__shared__ Scalar D[GJ_B][GJ_B + 1];
+	__shared__ Scalar D2[GJ_B][GJ_B + 1];
+	__shared__ Scalar Apj[GJ_B][GJ_B + 1];
+	__shared__ Scalar R[GJ_B][GJ_B + 1];
+	__shared__ Scalar F[GJ_B][GJ_B + 1];
+	const int tid = threadIdx.x;
+	TRACE_DECL
+	TRACE_MARK();
+	const int tiles = (n + GJ_B - 1) / GJ_B;
+	const int jt0 = blockIdx.x * colsPerGroup, jt1 = min(tiles, jt0 + colsPerGroup);
+	const int i0 = blockIdx.y * GJ_B;
+	int j0 = jt0 * GJ_B;
+	const int r = tid & 31, cb = tid >> 5;
+	const bool rowTile = i0 == p0;                          // this workgroup's tiles lie in the pivot rows
+	const int pNext = p0 + GJ_B;                            // look-ahead: the tile (pNext, pNext) is the next pivot block
+	const bool aheadRow = i0 == pNext && pNext < n;
+	Scalar dv[4], av[4], fv[4], sv[4], keep[4] = { 0, 0, 0, 0 };
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u;
+		const size_t pr = (size_t)min(p0 + r, n - 1), pc = (size_t)min(p0 + c, n - 1);
+		const size_t gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + c, n - 1);
+		dv[u] = pivIn[c * GJ_B + r];   // D[r][c]   = inverse of the pivot block A[p0.., p0..]
+		av[u] = src[gj * n + pr];      // Apj[r][c] = A[p0+r, j0+c]
+		fv[u] = src[pc * n + gi];      // F[r][c]   = A[i0+r, p0+c]
+		sv[u] = src[gj * n + gi];      // own tile
+	}
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u;
+		D[r][c] = dv[u];
+		Apj[r][c] = (r < bk && j0 + c < n) ? av[u] : Scalar(0);
+		F[r][c] = (c < bk && i0 + r < n) ? fv[u] : Scalar(0);
+	}
+	__syncthreads();
+	TRACE_MARK();
+	Scalar (*Dcur)[GJ_B + 1] = D;
+	// The two 32 x 32 x 32 tile products on the matrix cores: wave w owns the 16 x 16 output tile (w >> 1, w & 1), eight
+	// v_mfma_f64_16x16x4_f64 k-steps each (operands straight from LDS, one number per lane: A[i = lane & 15][k = lane >> 4],
+	// B[k = lane >> 4][j = lane & 15]).  This is the one GEMM-shaped piece of the whole path.
+	const int wv = tid >> 6, lane = tid & 63;
+	const int ti = wv >> 1, tj = wv & 1;
+	// A workgroup walks over colsPerGroup column tiles (1 up to n = 768: the sweep is latency there and the grid small;
+	// more beyond).
+	for (int jt = jt0; jt < jt1; jt++)
+	{
+		j0 = jt * GJ_B;
+		const bool colTile = j0 == p0;                      // this tile lies in the pivot columns
+		// next column tile of this workgroup: loads in flight under the products of the current one
+		Scalar avN[4], svN[4];
+		if (jt + 1 < jt1)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const size_t pr = (size_t)min(p0 + r, n - 1), gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + GJ_B + cb + 8 * u, n - 1);
+				avN[u] = src[gj * n + pr];
+				svN[u] = src[gj * n + gi];
+			}
+		}
+		// R = Dinv * Apj (not needed by the tiles of the pivot columns)
+		if (!colTile)
+		{
+			MfmaAcc acc = mfma_zero();
+#pragma unroll
+			for (int s4 = 0; s4 < GJ_B; s4 += 4)
+				acc = mfma_16x16x4(Dcur[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const int rr = 16 * ti + mfma_row(lane, q);
+				R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
+			}
+		}
+		__syncthreads();
+		Scalar out[4];
+		if (rowTile && colTile)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++) out[u] = dv[u];
+		}
+		else if (rowTile)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++) out[u] = R[r][cb + 8 * u];
+		}
+		else
+		{
+			Scalar (*B)[GJ_B + 1] = colTile ? Dcur : R;            // pivot columns: -F Dinv; elsewhere: S - F R
+			MfmaAcc acc = mfma_zero();
+#pragma unroll
+			for (int s4 = 0; s4 < GJ_B; s4 += 4)
+				acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+			// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
+			__syncthreads();
+#pragma unroll
+			for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int gi = i0 + r, gj = j0 + cb + 8 * u;
+			if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
+		}
+		if (aheadRow && j0 == pNext)                        // (uniform over the workgroup)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++) keep[u] = out[u];
+		}
+		if (jt + 1 < jt1)
+		{
+			__syncthreads();                                   // every reader of Apj / R of this tile is through
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				sv[u] = svN[u];
+				Apj[r][cb + 8 * u] = (r < bk && j0 + GJ_B + cb + 8 * u < n) ? avN[u] : Scalar(0);
+			}
+			__syncthreads();
+		}
+	}
+	TRACE_MARK();
+	// look-ahead: this workgroup produced the next pivot block -> invert it for the next launch
+	if (aheadRow && jt0 * GJ_B <= pNext && pNext < jt1 * GJ_B)
+	{
+		const int bkN = min(GJ_B, n - pNext);
+		__syncthreads();                                       // D (the current inverse) is no longer an operand
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int c = cb + 8 * u;
+			keep[u] = (r < bkN && c < bkN) ? keep[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short last block
+			D[r][c] = keep[u];
+			D2[r][c] = r == c ? Scalar(1) : Scalar(0);
+		}
+		__syncthreads();
+		Scalar (*res)[GJ_B + 1] = gj_pivot_inverse(D, D2, tid, bkN);
+#pragma unroll
+		for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
+		TRACE_MARK();
+		TRACE_FLUSH(2, 8000 + (threadIdx.x >> 6));          // (kept apart: the last launch of a sweep has no look-ahead workgroup)
+		return;
+	}
+	TRACE_MARK();
+	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+}
+
+// blocked Gauss-Jordan sweep: work0 holds the matrix on entry; returns the buffer (work0 or work1) holding the inverse.
+// pivots: 2 x 32 x 32 numbers of scratch (the inverse of the current / of the next pivot block)
+Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s)
+{
+	Scalar* src = work0; Scalar* dst = work1;
+	const int tiles = (n + GJ_B - 1) / GJ_B;
+	// column tiles per workgroup: enough workgroups to fill 256 CUs once (3 fit a CU by their LDS), no second round
+	int cols = 1;
+	if (const char* e = std::getenv("CUBA_HIP_GJ_COLS")) cols = std::max(1, std::atoi(e));
+	else while (tiles * ((tiles + cols - 1) / cols) > 768) cols++;
+	const int groups = (tiles + cols - 1) / cols;
+	Scalar* pivIn = pivots; Scalar* pivOut = pivots + GJ_B * GJ_B;
+	hipLaunchKernelGGL(dense_gj_first_pivot_kernel, dim3(1), dim3(256), 0, s, src, n, min(GJ_B, n), pivIn);
+	for (int p0 = 0; p0 < n; p0 += GJ_B)
+	{
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols, pivIn, pivOut);
+		Scalar* tmp = src; src = dst; dst = tmp;
+		tmp = pivIn; pivIn = pivOut; pivOut = tmp;
+	}
+	return src;
+}
+
+// Assemble P^T A P from the (already damped) reduced matrix and invert it; returns the buffer (work0 or work1) holding the inverse.
+Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled)
+{
+	const int Nc = 6 * sys.cl * sys.nc;
+	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
+	if (st.nCb) hipLaunchKernelGGL(coarse_assemble_kernel, dim3(st.nCb), dim3(256), 0, s, st, sys, work0, g.Pf);
+	if (assembled) (void)hipEventRecord(assembled, s);      // from here on the sweep no longer reads the reduced matrix
+	return launch_dense_inverse(work0, work1, Nc, sys.gj_pivots, s);
+}
+
+// fp64 coarse inverse (n x n, column-major, symmetric up to rounding) -> fp32, symmetrised exactly, rows padded with zeros to ld
+__global__ __launch_bounds__(256) void coarse_to_fp32_kernel(const Scalar* __restrict__ src, float* __restrict__ dst, int n, int ld)
+{
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= (size_t)n * ld) return;
+	const int row = (int)(t / ld), j = (int)(t - (size_t)row * ld);
+	dst[t] = j < n ? (float)(Scalar(0.5) * (src[(size_t)row * n + j] + src[(size_t)j * n + row])) : 0.0f;
+}
+
+void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s)
+{
+	const int ld = (n + 3) & ~3;
+	const size_t total = (size_t)n * ld;
+	if (total) hipLaunchKernelGGL(coarse_to_fp32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, n, ld);
+}
+
+}  // namespace cubahip
+
+#ifdef CUBA_HIP_TRACE
+extern "C" int cuba_hip_debug_read_trace_coarse(unsigned long long* out)   // this translation unit's 3 x 8192 x 8 timestamps (100 MHz)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cubahip::cuba_trace_buf), sizeof(unsigned long long) * 3 * 8192 * 8);
+}
+#endif

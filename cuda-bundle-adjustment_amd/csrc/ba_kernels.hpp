@@ -1,4 +1,4 @@
-// ba_kernels.hpp -- launch interface of the gfx950 kernels (implemented in ba_kernels.hip).
+// ba_kernels.hpp -- launch interface of the gfx950 kernels (implemented in ba_edge.hip, ba_linearize.hip, ba_pcg.hip, ba_coarse.hip).
 //
 // Device data model (all SoA, fp64 + int32):
 //   poses      q[4*Pt] t[3*Pt] cam[5*Pt]          free poses [0,Pf) first, fixed after
@@ -8,7 +8,7 @@
 //   wave list  wave_lm[2*nWaves]: each 64-lane wavefront owns whole landmarks with <= 64 edges in total,
 //              one lane per edge -> Hll/bl are reduced inside the wave, no atomics on the landmark side
 //   Hsc        upper-triangular BSR (row_ptr/col_ind, 6x6 col-major blocks, diagonal block first in
-//              each row), pair_blk = destination block of every Schur product, adj_* = full symmetric
+//              each row), prod_* = per block the edge pairs of its Schur products, adj_* = full symmetric
 //              adjacency over the same storage for the PCG SpMV
 #pragma once
 
@@ -49,8 +49,6 @@ struct DeviceStructure
 	Scalar* big_hpl = nullptr;         // 18 doubles per edge of a big landmark
 	int nblk = 0;
 	int *hsc_rowptr = nullptr, *hsc_colind = nullptr;
-	int* pair_blk = nullptr;           // destination block of each (i<j) product, landmark-major
-	long long* lm_pair_base = nullptr; // [Lf] offset of a landmark's pairs in pair_blk
 	int* lm_nfree = nullptr;           // [Lf] number of edges of the landmark whose pose is free
 	int *adj_ptr = nullptr, *adj_blk = nullptr, *adj_col = nullptr;  // adj_blk bit 31 = use transposed
 	// the first 20*ell_m entries of every adjacency row again, padded to a fixed width and interleaved so that lane
@@ -78,13 +76,6 @@ struct DeviceStructure
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
 	Scalar *cb_wi = nullptr, *cb_wj = nullptr;                                    // weights of the fine (row, column) poses of every list entry in the linear coarse functions
-	// halo lists of the coarse aggregates (ba_structure.hip: halo_lists_kernel) for the single-kernel PCG iteration
-	int *hal_n = nullptr, *hal_nj = nullptr;       // [nc] poses / aggregates in the halo of each aggregate
-	int *hal_pose = nullptr, *hal_aloc = nullptr;  // [nc * hmax] the poses (ascending) and the local index of each one's aggregate
-	int* hagg_id = nullptr;                        // [nc * jmax] the aggregates
-	int* ell_loc = nullptr;                        // parallel to ell: local (halo) index of the entry's column
-	int* own_loc = nullptr;                        // [Pf] local index of a pose in its OWN aggregate's halo list
-	int hmax = 0, jmax = 0;
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w' (sign bit = stereo), r[3], landmark (integer bits)}
 	int mixed = 0;                     // fp64 library only: 1 = records and the per-edge arithmetic of the pose / block passes in fp32
 };
@@ -138,10 +129,6 @@ struct DeviceSystem
 	                           // indexed by the workgroup's position inside its aggregate (P^T q is summed from these:
 	                           // aggregates are whole multiples of spmv_rows rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
-	// single-kernel iteration (pcg1_kernel, Chronopoulos-Gear recurrences): w = A u (ping-pong with ap), s = A p (ping-pong),
-	// the restricted vectors P^T w and P^T s (ping-pong, 2 x coarse dimension each; P^T r lives in rc), alpha of the last two iterations
-	int cg1 = 0;               // 1: the iteration graphs hold one pcg1_kernel per iteration instead of SpMV + fused kernel
-	Scalar *w2 = nullptr, *s0 = nullptr, *s1 = nullptr, *cw = nullptr, *cs = nullptr, *alpha = nullptr;
 };
 
 // residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
@@ -150,13 +137,11 @@ void launch_residual_chi2(const DeviceGraph& g, Scalar* parts, Scalar* slots, Sc
 
 // mode 0: assemble only (Hpp -> diagonal blocks of hsc, bp, Hll/bl -> lm_sys, max diagonal of Hll)
 // mode 1: full linearise + Schur reduction with damping lambda (hsc, bsc, bp, inv(Hll+lambda)/bl -> lm_sys)
-// launch_linearize: landmark-major kernel with fp64 atomics on the pose side (first design, kept for A/B runs)
-// launch_linearize_dm: destination-major, atomic-free and bitwise reproducible (default):
+// launch_linearize_dm: destination-major, atomic-free and bitwise reproducible:
 //   landmark pass (Hll/bl, inverse, per-edge record) -> pose pass (diagonal blocks, bp, bsc) -> block pass (off-diagonal blocks)
 // backupSrc != nullptr: the landmark pass's launch also copies backupCount numbers backupSrc -> backupDst (the LM loop's push())
 void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
 	const Scalar* backupSrc = nullptr, Scalar* backupDst = nullptr, size_t backupCount = 0);
-void launch_linearize(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s);
 
 // max over the diagonal of the diagonal blocks of hsc (Hpp after an assemble pass) folded into sys.maxdiag
 void launch_pose_maxdiag(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);
@@ -191,11 +176,6 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
-// single-kernel PCG iteration: can this configuration run it (kernel instantiation + LDS)?  / the per-solve initialisation that
-// follows pcg_setup + fused(doUpdate = 0) + SpMV(k = 0) / one iteration (eager launch; the graphs add the same node)
-bool pcg1_supported(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys);
-void launch_pcg1_init(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
-void launch_pcg1(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s);   // n x n inverse -> sys.acinv32 layout
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
@@ -213,10 +193,6 @@ void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, co
 
 // out3 = {chi2 total, landmark scale part, pose scale part} gathered from the result slots of the kernels enqueued before
 void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s);
-
-// forcing term of the inexact LM step: fills the extra partial behind the r_0.z_0 partials (sys.nrz0 counts it) with
-// max(0, eta2 * *ref - r_0.z_0); isFirst != 0 stores r_0.z_0 into *ref instead (first solve of an LM run)
-void launch_pcg_forcing(const DeviceSystem& sys, Scalar eta2, int isFirst, Scalar* ref, hipStream_t s);
 
 // copies {fail, iters, done} into sys.host_flags (what the last node of an iteration graph does anyway)
 void launch_pcg_report(const DeviceSystem& sys, hipStream_t s);

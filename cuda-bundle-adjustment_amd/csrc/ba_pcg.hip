@@ -1,0 +1,1001 @@
+// ba_pcg.hip -- the reduced solve: block preconditioned conjugate gradients on Hsc dxp = bsc, in the seat of cuSOLVER's sparse
+// Cholesky (/root/reference/src/cuda_linear_solver.cpp:147-232, 301-335).  Two launches per iteration -- SpMV on a row-ordered
+// copy of the upper-triangular BSR matrix (pcg_spmv_kernel / pcg_spmv_row_kernel), then update + restriction + two-level
+// preconditioner + r.z in one kernel (pcg2_fused_kernel; pcg_update_kernel in block-Jacobi-only mode) --, all CG scalars on
+// the device as per-workgroup partial sums in fixed order, iterations replayed as hipGraphs (graph_add_pcg_chunk).
+
+#include "ba_device.hpp"
+
+namespace cubahip
+{
+
+// ---------------------------------------------------------------------------------------------------
+// Block-Jacobi preconditioned conjugate gradients on Hsc dxp = bsc  (replaces cuSOLVER csrchol,
+// /root/reference/src/cuda_linear_solver.cpp:147-232,301-335).  Scalars never leave the device:
+//   rz[k] = r_k . z_k, pq[k] = p_k . A p_k live in NSLOT partial-sum slots per iteration;
+//   every workgroup re-derives alpha / beta / the stop test from them, so a finished solve turns the
+//   remaining queued launches into no-ops without a host round trip.
+// ---------------------------------------------------------------------------------------------------
+// ROWCOPY: also store the damped diagonal block into the row-ordered copy of the matrix (the fused launch: its expand workgroups
+// leave the diagonal entries alone, because this body rewrites the diagonal blocks they would read)
+template <bool ROWCOPY>
+__device__ __forceinline__ void pcg_setup_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, int bid, int nb)
+{
+	// one pose per thread, 64 poses per workgroup (only its first wave works): every load / store of a thread is 288 bytes from its
+	// neighbour's, so the set-up is the address path of the CUs it runs on -- spread over four times as many of them
+	const int i = threadIdx.x < PCG_SETUP_POSES ? bid * PCG_SETUP_POSES + (int)threadIdx.x : g.Pf;
+	Scalar rz = 0;
+	if (i < g.Pf)
+	{
+		Scalar* blk = sys.hsc + 36 * (size_t)st.hsc_rowptr[i];
+		Scalar A[36], Ai[36];
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+#pragma unroll
+			for (int r = 0; r <= c; r++)
+			{
+				Scalar v = blk[c * 6 + r];
+				if (r == c) v += lambda;
+				A[c * 6 + r] = v;
+				A[r * 6 + c] = v;
+			}
+#pragma unroll
+		for (int k = 0; k < 36; k++) blk[k] = A[k];   // full symmetric diagonal block, damping included
+		if (ROWCOPY)
+		{
+			// adjacency of a row = its lower neighbours, then its own blocks, the diagonal one first
+			const int pos = (st.adj_ptr[i + 1] - st.adj_ptr[i]) - (st.hsc_rowptr[i + 1] - st.hsc_rowptr[i]);
+			if (pos < 20 * st.ell_m)
+			{
+				Scalar* dst = sys.hrow + 36 * ((size_t)i * st.ell_m * 20 + pos);
+#pragma unroll
+				for (int k = 0; k < 36; k++) dst[k] = A[k];      // (symmetric: row-major = column-major)
+			}
+		}
+		if (!spd6_inverse(A, Ai)) *sys.fail = 1;
+#pragma unroll
+		for (int k = 0; k < 36; k++) sys.minv[36 * (size_t)i + k] = Ai[k];
+		Scalar rr[6];
+#pragma unroll
+		for (int k = 0; k < 6; k++) rr[k] = sys.bsc[6 * (size_t)i + k];
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+		{
+			Scalar z = 0;
+#pragma unroll
+			for (int c = 0; c < 6; c++) z += Ai[c * 6 + r] * rr[c];
+			sys.r[6 * (size_t)i + r] = rr[r];
+			sys.z[6 * (size_t)i + r] = z;   // overwritten by pcg2_fused_kernel when the coarse level is on
+			sys.xp[6 * (size_t)i + r] = 0;
+			sys.p0[6 * (size_t)i + r] = 0;
+			sys.p1[6 * (size_t)i + r] = 0;
+			rz += rr[r] * z;
+		}
+	}
+	rz = wave_sum(rz);
+	if (sys.agg == 0)   // block-Jacobi only: this kernel produces r0.z0 -> slot 0 and, as "r_k.z_k for k = 0", ring slot 1
+	{
+		if (threadIdx.x == 0)
+		{
+			const Scalar s2 = rz;
+			sys.rz[bid] = s2;
+			sys.rz[sys.rzStride + bid] = s2;
+		}
+		for (int t = nb + bid * 256 + threadIdx.x; t < sys.nrz; t += nb * 256) sys.rz[sys.rzStride + t] = 0;
+	}
+	if (bid == 0 && threadIdx.x == 0) { *sys.iters = 0; *sys.done = 0; *sys.kbase = 0; }
+}
+
+__global__ __launch_bounds__(256) void pcg_setup_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
+{
+	pcg_setup_body<false>(g, st, sys, lambda, blockIdx.x, gridDim.x);
+}
+
+void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
+{
+	if (g.Pf > 0) hipLaunchKernelGGL(pcg_setup_kernel, dim3((g.Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES), dim3(256), 0, s, g, st, sys, lambda);
+}
+
+__device__ __forceinline__ bool pcg_active(const DeviceSystem& sys, int k, int maxIter, Scalar tol2, int lane, Scalar& rzk)
+{
+	if (*sys.done) return false;
+	rzk = wave_sum(load_parts(rz_slot(sys, k), rz_count(sys, k), lane));
+	const Scalar rz0 = wave_sum(load_parts(sys.rz, sys.nrz0, lane));
+	const bool on = k < maxIter && *sys.fail == 0 && rzk > tol2 * rz0 && rzk == rzk;
+	if (!on && blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: a failed solve, not a converged one
+	return on;
+}
+
+// A(k): p_k = z_k + beta p_{k-1} (recomputed on the fly for the neighbour rows), q = A p_k, pq slot k = p.q partials.
+// A p_k is formed as A z_k + beta A p_{k-1} from two accumulators, so beta enters only after the last FMA.  The kernel has
+// two memory round trips: (1) the fixed-width index rows and the reduction partials (addresses known at launch: slots
+// depend on the chunk-local k & 3), (2) all operands of the row in one batch.  k's parity equals the parity of the
+// chunk-local argument (chunk lengths are multiples of 4), so the p ping-pong needs no load either.
+// spmv_entry: rows wider than the fixed-width part read their remaining entries from the upper-triangular storage.
+__device__ __forceinline__ void spmv_entry(const DeviceStructure& st, const DeviceSystem& sys, const Scalar* pold, int a, int rr,
+	Scalar& accz, Scalar& accp)
+{
+	const int bi = st.adj_blk[a];
+	const int j = st.adj_col[a];
+	const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
+	const int sr = bi < 0 ? 6 : 1, sc = bi < 0 ? 1 : 6;   // transposed read of the stored upper block for the lower half
+	Scalar av[6], zv[6], pv[6];
+#pragma unroll
+	for (int c = 0; c < 6; c++)
+	{
+		av[c] = B[rr * sr + c * sc];
+		zv[c] = sys.z[6 * (size_t)j + c];
+		pv[c] = pold[6 * (size_t)j + c];
+	}
+#pragma unroll
+	for (int c = 0; c < 6; c++) { accz += av[c] * zv[c]; accp += av[c] * pv[c]; }
+}
+
+typedef Scalar Scalar2 __attribute__((ext_vector_type(2)));
+
+// Row-ordered copy of the reduced matrix for the SpMV: entry (row, m, slot) of the fixed-width adjacency rows holds its
+// 6x6 block as seen from that row (transposed for the lower half), row-major, so that lane (slot, rr) reads the six
+// numbers it needs as three aligned 16-byte loads (half as many load instructions as element-wise strided reads of
+// the upper storage; the per-CU load path, not bandwidth, limits this kernel at KITTI-00 size).
+// FUSED: runs beside pcg_setup_body in one launch, which damps and symmetrises the diagonal blocks meanwhile -- they are left to it.
+template <bool FUSED>
+__device__ __forceinline__ void hsc_expand_body(const DeviceStructure& st, const DeviceSystem& sys, size_t total, size_t bid)
+{
+	const size_t t = bid * 256 + threadIdx.x;
+	if (t >= total) return;
+	const size_t slot = t / 36;
+	const int e = (int)(t - 36 * slot);
+	const int2 en = st.ell[slot];
+	if (en.y < 0) return;
+	const int rr = e / 6, c = e - 6 * rr;
+	const Scalar* B = sys.hsc + 36 * (size_t)(en.x & 0x7fffffff);
+	if (FUSED && en.y == (int)(slot / ((size_t)st.ell_m * 20))) return;       // the row's own diagonal block: written by the set-up body
+	sys.hrow[t] = B[en.x < 0 ? rr * 6 + c : c * 6 + rr];
+}
+
+__global__ __launch_bounds__(256) void hsc_expand_kernel(DeviceStructure st, DeviceSystem sys, size_t total)
+{
+	hsc_expand_body<false>(st, sys, total, blockIdx.x);
+}
+
+// pcg_setup (a handful of workgroups, one 6x6 inverse per thread: 11 us of latency) and the row-ordered copy (9 us of streaming)
+// in one launch
+// (+ optionally, in the last nCopy workgroups, the copy of a freshly inverted coarse matrix into the buffer the iteration graphs read)
+__global__ __launch_bounds__(256) void pcg_setup_expand_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda, int nSetup, size_t total,
+	unsigned nExpand, const Scalar2* __restrict__ copySrc, Scalar2* __restrict__ copyDst, size_t copyPairs)
+{
+	if ((int)blockIdx.x < nSetup) pcg_setup_body<true>(g, st, sys, lambda, blockIdx.x, nSetup);
+	else if (blockIdx.x < nSetup + nExpand) hsc_expand_body<true>(st, sys, total, blockIdx.x - nSetup);
+	else
+	{
+		const size_t stride = (size_t)(gridDim.x - nSetup - nExpand) * 256;
+		for (size_t i = (size_t)(blockIdx.x - nSetup - nExpand) * 256 + threadIdx.x; i < copyPairs; i += stride) copyDst[i] = copySrc[i];
+	}
+}
+
+void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s)
+{
+	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
+	if (total) hipLaunchKernelGGL(hsc_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st, sys, total);
+}
+
+void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s,
+	const Scalar* copySrc, Scalar* copyDst, size_t copyCount)
+{
+	if (g.Pf <= 0) return;
+	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
+	const int nSetup = (g.Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES;
+	const unsigned nExpand = (unsigned)((total + 255) / 256);
+	const size_t pairs = copySrc ? copyCount / 2 : 0;            // (coarse dimensions are even)
+	const unsigned nCopy = pairs ? (unsigned)std::min<size_t>(1024, (pairs + 255) / 256) : 0;
+	hipLaunchKernelGGL(pcg_setup_expand_kernel, dim3(nSetup + nExpand + nCopy), dim3(256), 0, s, g, st, sys, lambda, nSetup, total, nExpand,
+		reinterpret_cast<const Scalar2*>(copySrc), reinterpret_cast<Scalar2*>(copyDst), pairs);
+}
+
+// N entries of one lane at once: all 9 N (16-byte) loads are issued before the first use. Padding entries (column -1)
+// read z / p of column 0 against a zero matrix entry.
+template <int N>
+__device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar* pold, const int2 (&e)[3], const Scalar* Arow, int rr, Scalar& accz, Scalar& accp)
+{
+	Scalar2 av[N][3], zv[N][3], pv[N][3];
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+		const size_t j = e[n].y >= 0 ? e[n].y : 0;
+		const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + (size_t)n * (20 * 36) + 6 * rr);
+		const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
+		const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
+		// the matrix entry of a padding slot is never fetched (the lanes are masked off for these loads: ~25 % of the
+		// fixed-width slots are padding, and at S2M / G4M size their bytes show); z / p of column 0 are cache hits
+		const bool on = e[n].y >= 0;
+#pragma unroll
+		for (int c = 0; c < 3; c++) { av[n][c] = on ? A2[c] : Scalar2{ 0, 0 }; zv[n][c] = z2[c]; pv[n][c] = p2[c]; }
+	}
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			const Scalar a0 = av[n][c].x, a1 = av[n][c].y;
+			accz += a0 * zv[n][c].x; accp += a0 * pv[n][c].x;
+			accz += a1 * zv[n][c].y; accp += a1 * pv[n][c].y;
+		}
+	}
+}
+
+// MIN_WAVES = 4 caps the kernel at 128 VGPRs (a few spills): worth it only when the rows need more than one round of
+// waves at occupancy 3 -- at S2M / G4M size the kernel is bound by waves in flight x latency -- not at KITTI-00 size.
+// ROWS = block rows per workgroup (2 or 4): more rows per workgroup mean fewer row-sum partials for the two-level kernel
+// to add up (large graphs), fewer rows mean more workgroups to spread over the CUs (small graphs).
+template <int ROWS, int MIN_WAVES>
+__global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int half = wv & 1, lr = wv >> 1;          // the two waves of a row take 10 of its 20 entry slots each
+	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
+	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
+	const int row = blockIdx.x * ROWS + lr;
+	TRACE_DECL
+	TRACE_MARK();
+	// scalar loads, consumed at the very end (k is chunk-local here; the absolute number only enters the tests)
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
+	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
+	const Scalar s_m = load_parts(rz_slot(sys, k - 1), sys.nrz, lane);
+
+	// every index comes from an address known at launch (fixed-width rows): one memory round trip for the indices and
+	// the reduction scalars, one for all matrix / vector operands of the row
+	const bool rowOn = row < g.Pf;
+	const int slot = half * 10 + lane / 6, rr = lane % 6;
+	int2 e[3];
+	int a0 = 0, a1 = 0;
+#pragma unroll
+	for (int m = 0; m < 3; m++)
+		e[m] = (rowOn && lane < 60 && m < st.ell_m) ? st.ell[((size_t)row * st.ell_m + m) * 20 + slot] : int2{ 0, -1 };
+	if (rowOn && st.ell_over && lane < 60) { a0 = st.adj_ptr[row] + 20 * st.ell_m + slot; a1 = st.adj_ptr[row + 1]; }
+	Scalar accz = 0, accp = 0, zi = 0, pi_old = 0;
+	if (rowOn && half == 0 && lane < 6)
+	{
+		zi = sys.z[6 * (size_t)row + lane];
+		pi_old = pold[6 * (size_t)row + lane];
+	}
+	TRACE_MARK();
+	k += __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
+		return;
+	}
+	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
+	if (rowOn)
+	{
+		int cnt = 0;                       // wave-uniform: entries of the fullest slot
+#pragma unroll
+		for (int m = 0; m < 3; m++) cnt += __any(e[m].y >= 0) ? 1 : 0;
+		const Scalar* Arow = sys.hrow + 36 * ((size_t)row * st.ell_m * 20 + slot);     // entry (row, m, slot) at + m * 20 * 36
+		if (cnt == 3) spmv_batch<3>(sys, pold, e, Arow, rr, accz, accp);
+		else if (cnt == 2) spmv_batch<2>(sys, pold, e, Arow, rr, accz, accp);
+		else if (cnt == 1) spmv_batch<1>(sys, pold, e, Arow, rr, accz, accp);
+		for (int a = a0; a < a1; a += 20) spmv_entry(st, sys, pold, a, rr, accz, accp);   // rows wider than the fixed part
+	}
+	TRACE_MARK();
+	// fold the 10 slots onto lanes 0..5
+	accz += __shfl_down(accz, 30); accp += __shfl_down(accp, 30);
+	Scalar tz = accz, tp = accp;
+	tz += __shfl_down(accz, 6);  tp += __shfl_down(accp, 6);
+	tz += __shfl_down(accz, 12); tp += __shfl_down(accp, 12);
+	tz += __shfl_down(accz, 18); tp += __shfl_down(accp, 18);
+	tz += __shfl_down(accz, 24); tp += __shfl_down(accp, 24);
+	__shared__ Scalar other[ROWS][12];
+	__shared__ Scalar qrow[ROWS][6];
+	__shared__ Scalar part[ROWS];
+	if (half == 1 && lane < 6) { other[lr][lane] = tz; other[lr][6 + lane] = tp; }
+	__syncthreads();
+	TRACE_MARK();
+	Scalar dot = 0;
+	if (half == 0)
+	{
+		Scalar q = 0;
+		if (row < g.Pf && lane < 6)
+		{
+			tz += other[lr][lane]; tp += other[lr][6 + lane];
+			const Scalar pi = zi + beta * pi_old;
+			q = tz + beta * tp;
+			pnew[6 * (size_t)row + lane] = pi;
+			sys.ap[6 * (size_t)row + lane] = q;
+			dot = pi * q;
+		}
+		if (lane < 6) qrow[lr][lane] = q;
+		dot = wave_sum(dot);
+		if (lane == 0) part[lr] = dot;
+	}
+	__syncthreads();
+	if (threadIdx.x < 6 * sys.cl)   // (weighted) row sums of q over this workgroup's rows: the two-level kernel builds P^T q from these
+	{
+		const int a = threadIdx.x / 6, c = threadIdx.x - 6 * a;
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < ROWS; w++)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		if (sys.qpart && sys.agg > 0)
+		{
+			// layout [m][coarse unknown], m = position of this workgroup inside its aggregate: the two-level kernel then reads
+			// consecutive addresses across a wave for every m
+			const int per = sys.agg / ROWS, J = blockIdx.x / per, m = blockIdx.x - J * per;
+			sys.qpart[(size_t)m * (6 * sys.cl * sys.nc) + 6 * sys.cl * J + threadIdx.x] = s2;
+		}
+	}
+	if (threadIdx.x == 64)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < ROWS; w++) s2 += part[w];
+		pq_slot(sys, k)[blockIdx.x] = s2;
+	}
+	TRACE_MARK();
+	TRACE_FLUSH(0, blockIdx.x * 2 * ROWS + wv);
+}
+
+// One wave per block row (large graphs).  With two waves per row S2M / G4M need 10 000 / 20 000 waves of ~5 KB each, i.e.
+// 2.5 / 5 rounds of resident waves whose life is two dependent round trips + a barrier: the launch is bound by
+// wave slots x latency, not by bytes.  Here lane (slot, r2) = (lane / 3, lane % 3) takes block rows 2 r2 and 2 r2 + 1 of one of
+// the 20 entry slots: half the waves, twice the bytes per wave, no cross-wave exchange.  Two levels of the fixed-width row are
+// in flight at once (96 VGPRs of operands: occupancy 3); the third level, which few rows have, follows.
+template <int N>
+__device__ __forceinline__ void spmv_batch2(const DeviceSystem& sys, const Scalar* pold, const int2* e, const Scalar* Arow, int r2,
+	Scalar& az0, Scalar& ap0, Scalar& az1, Scalar& ap1)
+{
+	Scalar2 a0v[N][3], a1v[N][3], zv[N][3], pv[N][3];
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+		const size_t j = e[n].y >= 0 ? e[n].y : 0;
+		const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + (size_t)n * (20 * 36) + 12 * r2);
+		const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
+		const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
+		const bool on = e[n].y >= 0;       // padding slots: matrix entry not fetched
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			a0v[n][c] = on ? A2[c] : Scalar2{ 0, 0 }; a1v[n][c] = on ? A2[3 + c] : Scalar2{ 0, 0 };
+			zv[n][c] = z2[c]; pv[n][c] = p2[c];
+		}
+	}
+#pragma unroll
+	for (int n = 0; n < N; n++)
+	{
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			az0 += a0v[n][c].x * zv[n][c].x; ap0 += a0v[n][c].x * pv[n][c].x;
+			az0 += a0v[n][c].y * zv[n][c].y; ap0 += a0v[n][c].y * pv[n][c].y;
+			az1 += a1v[n][c].x * zv[n][c].x; ap1 += a1v[n][c].x * pv[n][c].x;
+			az1 += a1v[n][c].y * zv[n][c].y; ap1 += a1v[n][c].y * pv[n][c].y;
+		}
+	}
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	const int lane = threadIdx.x & 63, lr = threadIdx.x >> 6;
+	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
+	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
+	const int row = blockIdx.x * ROWS + lr;
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
+	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
+	const Scalar s_m = load_parts(rz_slot(sys, k - 1), sys.nrz, lane);
+	const bool rowOn = row < g.Pf;
+	const int slot = lane / 3, r2 = lane - 3 * slot;
+	int2 e[3];
+	int a0 = 0, a1 = 0;
+#pragma unroll
+	for (int m = 0; m < 3; m++)
+		e[m] = (rowOn && lane < 60 && m < st.ell_m) ? st.ell[((size_t)row * st.ell_m + m) * 20 + slot] : int2{ 0, -1 };
+	if (rowOn && st.ell_over && lane < 60) { a0 = st.adj_ptr[row] + 20 * st.ell_m + slot; a1 = st.adj_ptr[row + 1]; }
+	Scalar zi = 0, pi_old = 0;
+	if (rowOn && lane < 6)
+	{
+		zi = sys.z[6 * (size_t)row + lane];
+		pi_old = pold[6 * (size_t)row + lane];
+	}
+	k += __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
+		return;
+	}
+	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
+	Scalar az0 = 0, ap0 = 0, az1 = 0, ap1 = 0;
+	if (rowOn)
+	{
+		int cnt = 0;                       // wave-uniform: entries of the fullest slot
+#pragma unroll
+		for (int m = 0; m < 3; m++) cnt += __any(e[m].y >= 0) ? 1 : 0;
+		const Scalar* Arow = sys.hrow + 36 * ((size_t)row * st.ell_m * 20 + slot);     // entry (row, m, slot) at + m * 20 * 36
+		if (cnt >= 2) spmv_batch2<2>(sys, pold, e, Arow, r2, az0, ap0, az1, ap1);
+		else if (cnt == 1) spmv_batch2<1>(sys, pold, e, Arow, r2, az0, ap0, az1, ap1);
+		if (cnt == 3) spmv_batch2<1>(sys, pold, e + 2, Arow + 2 * (20 * 36), r2, az0, ap0, az1, ap1);
+		for (int a = a0; a < a1; a += 20)          // rows wider than the fixed part: from the upper-triangular storage
+		{
+			const int bi = st.adj_blk[a];
+			const size_t j = st.adj_col[a];
+			const Scalar* B = sys.hsc + 36 * (size_t)(bi & 0x7fffffff);
+			const int sr = bi < 0 ? 6 : 1, sc = bi < 0 ? 1 : 6;   // transposed read of the stored upper block for the lower half
+#pragma unroll
+			for (int c = 0; c < 6; c++)
+			{
+				const Scalar zc = sys.z[6 * j + c], pc = pold[6 * j + c];
+				const Scalar b0 = B[(2 * r2) * sr + c * sc], b1 = B[(2 * r2 + 1) * sr + c * sc];
+				az0 += b0 * zc; ap0 += b0 * pc; az1 += b1 * zc; ap1 += b1 * pc;
+			}
+		}
+	}
+	// fold the 20 slots (lanes 3 apart) onto lanes 0..2, then spread the six block rows over lanes 0..5
+	az0 += __shfl_down(az0, 30); ap0 += __shfl_down(ap0, 30); az1 += __shfl_down(az1, 30); ap1 += __shfl_down(ap1, 30);
+	az0 += __shfl_down(az0, 15); ap0 += __shfl_down(ap0, 15); az1 += __shfl_down(az1, 15); ap1 += __shfl_down(ap1, 15);
+	Scalar t0 = az0, u0 = ap0, t1 = az1, u1 = ap1;
+#pragma unroll
+	for (int d = 3; d <= 12; d += 3) { t0 += __shfl_down(az0, d); u0 += __shfl_down(ap0, d); t1 += __shfl_down(az1, d); u1 += __shfl_down(ap1, d); }
+	const Scalar tzA = __shfl(t0, lane >> 1), tzB = __shfl(t1, lane >> 1), tpA = __shfl(u0, lane >> 1), tpB = __shfl(u1, lane >> 1);
+	const Scalar tz = (lane & 1) ? tzB : tzA, tp = (lane & 1) ? tpB : tpA;
+	__shared__ Scalar qrow[ROWS][6];
+	__shared__ Scalar part[ROWS];
+	Scalar q = 0, dot = 0;
+	if (rowOn && lane < 6)
+	{
+		const Scalar pi = zi + beta * pi_old;
+		q = tz + beta * tp;
+		pnew[6 * (size_t)row + lane] = pi;
+		sys.ap[6 * (size_t)row + lane] = q;
+		dot = pi * q;
+	}
+	if (lane < 6) qrow[lr][lane] = q;
+	dot = wave_sum(dot);
+	if (lane == 0) part[lr] = dot;
+	__syncthreads();
+	if (threadIdx.x < 6 * sys.cl)   // (weighted) row sums of q over this workgroup's rows: the two-level kernel builds P^T q from these
+	{
+		const int a = threadIdx.x / 6, c = threadIdx.x - 6 * a;
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < ROWS; w++)
+			s2 += (a == 0 ? Scalar(1) : agg_weight(blockIdx.x * ROWS + w, sys.agg, g.Pf)) * qrow[w][c];
+		if (sys.qpart && sys.agg > 0)
+		{
+			const int per = sys.agg / ROWS, J = blockIdx.x / per, m = blockIdx.x - J * per;
+			sys.qpart[(size_t)m * (6 * sys.cl * sys.nc) + 6 * sys.cl * J + threadIdx.x] = s2;
+		}
+	}
+	if (threadIdx.x == 64)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < ROWS; w++) s2 += part[w];
+		pq_slot(sys, k)[blockIdx.x] = s2;
+	}
+}
+
+// B(k): alpha = rz[k]/pq[k]; x += alpha p; r -= alpha q; z = Minv r; rz[k+1] += r.z
+__global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	k += *sys.kbase;
+	Scalar rzk;
+	if (!pcg_active(sys, k, maxIter, tol2, lane, rzk)) return;
+	const Scalar pqk = wave_sum(load_parts(pq_slot(sys, k), sys.npq, lane));
+	if (!(pqk > 0))
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;   // not positive definite along p
+		return;
+	}
+	const Scalar alpha = rzk / pqk;
+	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;   // what A(k) wrote
+	const int pose = (blockIdx.x * 4 + wv) * 10 + lane / 6;
+	const int rr = lane % 6;
+	Scalar rnew = 0;
+	const bool on = lane < 60 && pose < g.Pf;
+	if (on)
+	{
+		const size_t idx = 6 * (size_t)pose + rr;
+		sys.xp[idx] += alpha * p[idx];
+		rnew = sys.r[idx] - alpha * sys.ap[idx];
+		sys.r[idx] = rnew;
+	}
+	Scalar z = 0;
+	const int base = lane - rr;
+#pragma unroll
+	for (int c = 0; c < 6; c++)
+	{
+		const Scalar rc = __shfl(rnew, base + c);
+		if (on) z += sys.minv[36 * (size_t)pose + c * 6 + rr] * rc;
+	}
+	Scalar dot = 0;
+	if (on)
+	{
+		sys.z[6 * (size_t)pose + rr] = z;
+		dot = rnew * z;
+	}
+	dot = wave_sum(dot);
+	__shared__ Scalar part[4];
+	if (lane == 0) part[wv] = dot;
+	__syncthreads();
+	if (threadIdx.x == 0) rz_slot_w(sys, k + 1)[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+	if (blockIdx.x == 0 && threadIdx.x == 0) *sys.iters = k + 1;
+}
+
+// Fused B(k) of the two-level PCG: [x += alpha p; r -= alpha q;]  rc = P^T r;  z = Minv r + P (Ac^-1 rc);
+// rz[kOut] = r.z.  One 512-thread workgroup per aggregate; only the owner of an aggregate stores x, r, z.
+// Every workgroup needs the WHOLE restricted residual rc = P^T r_k - alpha P^T q_k (6*nc values). Neither term is
+// rebuilt from the full vectors: P^T r_k was stored by the owners one iteration earlier (sys.rc, ping-pong), and
+// P^T q_k is summed from the per-workgroup row sums the SpMV kernel leaves in sys.qpart.  Together with the local-k
+// slot addressing every global load of the kernel is issued in its first instructions (one memory round trip).
+// doUpdate = 0 (once per solve: z_0 = M^-1 r_0) still restricts r directly.
+constexpr int PCG2_T = 512;
+
+__device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
+{
+	Scalar v0 = 0, v1 = 0;
+	int t = threadIdx.x;
+	for (; t + PCG2_T < n; t += 2 * PCG2_T)
+	{
+		const Scalar a = p[t], b = p[t + PCG2_T];
+		v0 += a; v1 += b;
+	}
+	const Scalar e = t < n ? p[t] : Scalar(0);
+	return (v0 + e) + v1;
+}
+
+// CL = coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose index.  Coarse
+// unknown (aggregate J, function a, component c) has index (6 CL) J + 6 a + c.
+// AC2: further column pairs per lane and row, fetched in a second batch once the restricted sums have freed their registers
+// (coarse dimensions beyond 128 AC = 1536: large graphs with small aggregates; a column-by-column tail would pay one memory
+// round trip per 64 columns)
+// W: numbers per 16-byte load of the coarse inverse = 2 when it is stored in the library's Scalar, 4 when the fp64 library keeps it
+// in fp32 (option "precond_fp32": the preconditioner only has to be a fixed SPD operator close to the inverse, so its storage
+// precision changes the iteration count by nothing measurable and the solution not at all, while its bytes and its load
+// instructions -- what bounds this kernel on the one CU a workgroup runs on -- halve).  With W = 4 the rows are padded to a
+// multiple of 4 numbers (zeros), and so are the two coarse vectors in LDS.
+template <typename T, int W> struct InvVec;
+template <typename T> struct InvVec<T, 2> { typedef T type __attribute__((ext_vector_type(2))); };
+template <typename T> struct InvVec<T, 4> { typedef T type __attribute__((ext_vector_type(4))); };
+
+template <int CL, int AC, int AC2, int W>
+__global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
+{
+	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
+	constexpr int QV = 16;             // SpMV-workgroup partials prefetched per coarse unknown
+	typedef typename std::conditional<W == 4, float, Scalar>::type PT;       // storage type of the coarse inverse
+	typedef typename InvVec<PT, W>::type AV;
+	extern __shared__ __align__(16) unsigned char pcg2_lds[];
+	const int Nc = CD * sys.nc;
+	const int NcP = (Nc + 3) & ~3;     // padded length of the coarse vectors in LDS (and of the rows of a W = 4 inverse)
+	const int ld = W == 4 ? NcP : Nc;
+	const PT* acinv = W == 4 ? reinterpret_cast<const PT*>(sys.acinv32) : reinterpret_cast<const PT*>(sys.acinv);
+	Scalar* sR = reinterpret_cast<Scalar*>(pcg2_lds);
+	Scalar* sQ = sR + NcP;
+	Scalar* part = sQ + NcP;          // [8 waves][CD], reused for the 8 x CD partial sums of P^T r_{k+1}
+	Scalar* yc = part + 8 * CD;
+	Scalar* wsum = yc + CD;           // [4][8]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
+	Scalar* rown = wsum + 32;
+	Scalar* qown = rown + 6 * sys.agg;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;
+	// the residual is double-buffered: other workgroups still read r_k of this aggregate while its owner stores r_{k+1}
+	const Scalar* rin = (k & 1) ? sys.r2 : sys.r;
+	Scalar* rout = (k & 1) ? sys.r : sys.r2;
+	const Scalar* rcin = sys.rc + ((k & 1) ? Nc : 0);
+	Scalar* rcout = sys.rc + ((doUpdate != 0) == ((k & 1) != 0) ? 0 : Nc);    // doUpdate = 0 stores P^T r_0 where k = 0 reads it
+	const int I = blockIdx.x;
+	TRACE_DECL
+	TRACE_MARK();
+	const int kb_v = vector_load_flag(sys.kbase);          // k, kOut are chunk-local: slots depend on k & 3 only, the tests use k + kb
+	const int failed_v = vector_load_flag(sys.fail) | (doUpdate ? vector_load_flag(sys.done) : 0);
+	// ---- every global load of the common case is issued here, before the first use of any of them ----------------
+	const int t = threadIdx.x;
+	const int own0 = 6 * I * sys.agg;
+	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
+	const int per = sys.agg / sys.spmv_rows;             // SpMV workgroups per aggregate
+	Scalar e_k = 0, e_0 = 0, e_q0 = 0, e_q1 = 0;        // reduction partials
+	Scalar pre_r = 0, pre_q = 0, pre_p = 0, pre_x = 0, pre_m[6] = { 0, 0, 0, 0, 0, 0 };   // own rows
+	Scalar2 sr = { 0, 0 }, qv[QV];                       // restricted sums: thread t takes the coarse unknowns 2 t, 2 t + 1 (Nc is even)
+	// coarse inverse: rows CD I .. CD I + CD - 1 (= columns: symmetric, contiguous).  Wave w applies rows w, w + 8 (< CD) to
+	// the whole coarse vector -- lane l takes the columns l, l + 64, ... -- so that a row costs ONE wave reduction in one
+	// wave (a thread-per-column layout needs CD reductions in every wave plus a cross-wave stage).
+	constexpr int AR = (CD + 7) / 8;   // rows per wave
+	// AC = prefetched column PAIRS per lane and row (covers a coarse dimension of 128 AC; the rest is read later): 6 for
+	// coarse dimensions up to 768 (KITTI-00: 672), 12 beyond -- every prefetch slot past the row's end is still a load
+	// instruction on the workgroup's one CU, which is what bounds this kernel
+	AV ainv[AR][AC];
+#pragma unroll
+	for (int m = 0; m < QV; m++) qv[m] = Scalar2{ 0, 0 };
+	if (doUpdate)
+	{
+		if (t < sys.nrz) e_k = rz_slot(sys, k)[t];
+		if (t < sys.nrz0) e_0 = sys.rz[t];
+		if (t < sys.npq) e_q0 = pq_slot(sys, k)[t];
+		if (t + PCG2_T < sys.npq) e_q1 = pq_slot(sys, k)[t + PCG2_T];
+	}
+	if (t < ownN)
+	{
+		const size_t gi = (size_t)own0 + t;
+		pre_r = rin[gi];
+		if (doUpdate) { pre_q = sys.ap[gi]; pre_p = p[gi]; pre_x = sys.xp[gi]; }
+		const size_t pose = gi / 6; const int comp = (int)(gi - 6 * pose);
+#pragma unroll
+		for (int c = 0; c < 6; c++) pre_m[c] = sys.minv[36 * pose + c * 6 + comp];
+	}
+	if (doUpdate && 2 * t < Nc)
+	{
+		sr = *reinterpret_cast<const Scalar2*>(rcin + 2 * t);
+#pragma unroll
+		for (int m = 0; m < QV; m++)      // (m < per is uniform over the grid; sets of workgroups that do not exist stay zero)
+			if (m < per) qv[m] = *reinterpret_cast<const Scalar2*>(sys.qpart + (size_t)m * Nc + 2 * t);
+	}
+#pragma unroll
+	for (int a = 0; a < AR; a++)
+	{
+#pragma unroll
+		for (int m = 0; m < AC; m++) ainv[a][m] = AV(0);
+		if (wv + 8 * a < CD)                               // wave-uniform
+		{
+			const PT* Arow = acinv + (size_t)(CD * I + wv + 8 * a) * ld;
+#pragma unroll
+			for (int m = 0; m < AC; m++) ainv[a][m] = *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * m, ld - W));   // ld is a multiple of W
+		}
+	}
+	TRACE_MARK();      // (trace build only: waits for every load issued above)
+	// ---- rare remainders (more partials / coarse unknowns / own rows than threads) and the arithmetic ------------
+	Scalar a_k = e_k, a_0 = e_0, a_q = e_q0 + e_q1;
+	if (doUpdate)
+	{
+		for (int u = t + PCG2_T; u < sys.nrz; u += PCG2_T) a_k += rz_slot(sys, k)[u];
+		for (int u = t + PCG2_T; u < sys.nrz0; u += PCG2_T) a_0 += sys.rz[u];
+		for (int u = t + 2 * PCG2_T; u < sys.npq; u += PCG2_T) a_q += pq_slot(sys, k)[u];
+	}
+	if (t < ownN) { rown[t] = pre_r; qown[t] = pre_q; }
+	for (int w = t + PCG2_T; w < ownN; w += PCG2_T)
+	{
+		rown[w] = rin[own0 + w];
+		qown[w] = doUpdate ? sys.ap[own0 + w] : Scalar(0);
+	}
+	// restricted sums P^T r_k and P^T q_k (fixed summation order => reproducible)
+	if (doUpdate)
+	{
+		for (int pj = t; 2 * pj < Nc; pj += PCG2_T)
+		{
+			Scalar2 s1, s2 = { 0, 0 };
+			if (pj == t)
+			{
+				s1 = sr;
+#pragma unroll
+				for (int m = 0; m < QV; m++) s2 += qv[m];
+			}
+			else s1 = *reinterpret_cast<const Scalar2*>(rcin + 2 * pj);
+			for (int m0 = pj == t ? QV : 0; m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
+			{
+				Scalar2 qx[QV];
+				const Scalar* src = sys.qpart + (size_t)m0 * Nc + 2 * pj;
+#pragma unroll
+				for (int m = 0; m < QV; m++) qx[m] = m0 + m < per ? *reinterpret_cast<const Scalar2*>(src + (size_t)m * Nc) : Scalar2{ 0, 0 };      // uniform condition
+#pragma unroll
+				for (int m = 0; m < QV; m++) s2 += qx[m];
+			}
+			*reinterpret_cast<Scalar2*>(sR + 2 * pj) = s1;
+			*reinterpret_cast<Scalar2*>(sQ + 2 * pj) = s2;
+		}
+		if (t < NcP - Nc) { sR[Nc + t] = 0; sQ[Nc + t] = 0; }      // padding of the coarse vectors (a 4-wide last load of a row)
+	}
+	else
+	{
+		for (int jc = t; jc < Nc; jc += PCG2_T)       // once per solve: P^T r_0 from the residual itself
+		{
+			const int Jj = jc / CD, rem = jc - CD * Jj;
+			const int a = rem / 6, c = rem - 6 * a;
+			const int i0 = Jj * sys.agg, i1 = min(g.Pf, i0 + sys.agg);
+			Scalar s1 = 0;
+			for (int i = i0; i < i1; i += 8)
+			{
+				Scalar rv[8];
+#pragma unroll
+				for (int m = 0; m < 8; m++) rv[m] = i + m < i1 ? rin[6 * (size_t)(i + m) + c] : Scalar(0);
+#pragma unroll
+				for (int m = 0; m < 8; m++) s1 += (a == 0 ? Scalar(1) : agg_weight_local(Jj, i + m - i0, sys, g.Pf)) * rv[m];
+			}
+			sR[jc] = s1; sQ[jc] = 0;
+		}
+		if (t < NcP - Nc) { sR[Nc + t] = 0; sQ[Nc + t] = 0; }
+	}
+	AV ainv2[AR][AC2 > 0 ? AC2 : 1];
+	if (AC2 > 0 && Nc > 64 * W * AC)                    // (uniform over the grid)
+	{
+#pragma unroll
+		for (int a = 0; a < AR; a++)
+		{
+			const PT* Arow = acinv + (size_t)(CD * I + min(wv + 8 * a, CD - 1)) * ld;
+#pragma unroll
+			for (int m = 0; m < AC2; m++) ainv2[a][m] = *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * (AC + m), ld - W));
+		}
+	}
+	TRACE_MARK();
+	a_k = wave_sum(a_k); a_0 = wave_sum(a_0); a_q = wave_sum(a_q);
+	if (lane == 0) { wsum[wv] = a_k; wsum[8 + wv] = a_0; wsum[16 + wv] = a_q; }
+	__syncthreads();
+	Scalar alpha = 0;
+	const int kabs = k + __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	if (doUpdate)
+	{
+		Scalar rzk = 0, rz0 = 0, pqk = 0;
+#pragma unroll
+		for (int w = 0; w < PCG2_T / 64; w++) { rzk += wsum[w]; rz0 += wsum[8 + w]; pqk += wsum[16 + w]; }
+		if (!(kabs < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }
+			return;
+		}
+		if (!(pqk > 0))
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
+			return;
+		}
+		alpha = rzk / pqk;
+	}
+	TRACE_MARK();
+	// ---- own rows: r_{k+1}, x_{k+1} ---------------------------------------------------------------------------
+	const int ow = t;
+	for (int w = ow; w < ownN; w += PCG2_T)
+	{
+		const Scalar r = rown[w] - alpha * qown[w];      // rown[w] / qown[w] were written by this very thread
+		rown[w] = r;
+		if (doUpdate)
+		{
+			rout[own0 + w] = r;
+			sys.xp[own0 + w] = (w == ow ? pre_x : sys.xp[own0 + w]) + alpha * (w == ow ? pre_p : p[own0 + w]);
+		}
+	}
+	// ---- yc = Ac^-1[CD I .. CD I + CD - 1, :] (P^T r - alpha P^T q) --------------------------------------------------
+#pragma unroll
+	for (int a = 0; a < AR; a++)
+	{
+		const int row = wv + 8 * a;
+		Scalar acc = 0;
+#pragma unroll
+		for (int m = 0; m < AC; m++)
+		{
+			const int j = W * lane + 64 * W * m;
+			if (j < Nc)
+			{
+#pragma unroll
+				for (int i = 0; i < W; i++) acc += (Scalar)ainv[a][m][i] * (sR[j + i] - alpha * sQ[j + i]);
+			}
+		}
+		if (AC2 > 0 && Nc > 64 * W * AC)
+		{
+#pragma unroll
+			for (int m = 0; m < AC2; m++)
+			{
+				const int j = W * lane + 64 * W * (AC + m);
+				if (j < Nc)
+				{
+#pragma unroll
+					for (int i = 0; i < W; i++) acc += (Scalar)ainv2[a][m][i] * (sR[j + i] - alpha * sQ[j + i]);
+				}
+			}
+		}
+		if (row < CD)
+			for (int j = lane + 64 * W * (AC + AC2); j < Nc; j += 64) acc += (Scalar)acinv[(size_t)(CD * I + row) * ld + j] * (sR[j] - alpha * sQ[j]);
+		acc = wave_sum(acc);
+		if (lane == 0 && row < CD) yc[row] = acc;
+	}
+	__syncthreads();
+	TRACE_MARK();
+	// ---- z = Minv r + P yc for the poses of this aggregate; r.z ---------------------------------------------------
+	Scalar dot = 0;
+	for (int w = ow; w < ownN; w += PCG2_T)
+	{
+		const int il = w / 6, comp = w - 6 * il;
+		Scalar z = yc[comp];
+		if (CL == 2) z += agg_weight_local(I, il, sys, g.Pf) * yc[6 + comp];
+#pragma unroll
+		for (int c = 0; c < 6; c++)
+			z += (w == ow ? pre_m[c] : sys.minv[36 * ((size_t)I * sys.agg + il) + c * 6 + comp]) * rown[6 * il + c];
+		sys.z[(size_t)own0 + w] = z;
+		dot += rown[w] * z;
+	}
+	dot = wave_sum(dot);
+	if (lane == 0) wsum[24 + wv] = dot;
+	// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves: 8 interleaved partial
+	// sums per coarse unknown here, folded after the barrier (a single thread per unknown would chain `agg` LDS reads)
+	if (t < 8 * CD)
+	{
+		const int u = t % CD, h = t / CD, a = u / 6, c = u - 6 * a;
+		Scalar s3 = 0;
+		for (int il = h; 6 * il + c < ownN; il += 8)
+			s3 += (a == 0 ? Scalar(1) : agg_weight_local(I, il, sys, g.Pf)) * rown[6 * il + c];
+		part[t] = s3;
+	}
+	__syncthreads();
+	if (t >= 64 && t < 64 + CD)
+	{
+		const int u = t - 64;
+		Scalar s3 = 0;
+#pragma unroll
+		for (int h = 0; h < 8; h++) s3 += part[CD * h + u];
+		rcout[CD * I + u] = s3;
+	}
+	if (threadIdx.x == 0)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < PCG2_T / 64; w++) s2 += wsum[24 + w];
+		rz_slot_w(sys, kOut)[blockIdx.x] = s2;
+		if (!doUpdate) sys.rz[blockIdx.x] = s2;          // r_0.z_0: kept in slot 0 for the stop test
+		if (doUpdate && blockIdx.x == 0) *sys.iters = kabs + 1;
+	}
+	TRACE_MARK();
+	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
+}
+
+static void* pcg2_kernel_for(const DeviceSystem& sys)
+{
+	const int Nc = 6 * sys.cl * sys.nc;
+	if (sys.acinv32 && sizeof(Scalar) == 8)
+	{
+		// fp32 storage of the coarse inverse: a 16-byte load carries 4 columns, 3 / 6 / 6 + 3 loads per lane and row cover 768 / 1536 / 2304
+		if (sys.cl == 2) return Nc <= 768 ? (void*)pcg2_fused_kernel<2, 3, 0, 4> : Nc <= 1536 ? (void*)pcg2_fused_kernel<2, 6, 0, 4> : (void*)pcg2_fused_kernel<2, 6, 3, 4>;
+		return Nc <= 768 ? (void*)pcg2_fused_kernel<1, 3, 0, 4> : Nc <= 1536 ? (void*)pcg2_fused_kernel<1, 6, 0, 4> : (void*)pcg2_fused_kernel<1, 6, 3, 4>;
+	}
+	const bool small = Nc <= 768;
+	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0, 2> : (void*)pcg2_fused_kernel<2, 12, 6, 2>;
+	return small ? (void*)pcg2_fused_kernel<1, 6, 0, 2> : (void*)pcg2_fused_kernel<1, 12, 6, 2>;
+}
+
+static size_t pcg2_lds_bytes(const DeviceSystem& sys)
+{
+	const size_t cd = 6 * (size_t)sys.cl;
+	const size_t ncp = (cd * sys.nc + 3) & ~(size_t)3;
+	return sizeof(Scalar) * (2 * ncp + 8 * cd + cd + 32 + 12 * (size_t)sys.agg);
+}
+
+void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
+{
+	const size_t lds = pcg2_lds_bytes(sys);
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
+}
+
+static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
+int spmv_rows_for(int Pf)
+{
+	return 2 * (long long)Pf > 3 * 1024 ? 4 : 2;
+}                            // (the 4-row workgroup needs the 128-VGPR instantiation)
+// large graphs (4 rows per workgroup): one wave per block row; small ones: two waves per row, 2 rows per workgroup
+// (measured: S2M 17.0 -> 15.6 us, G4M 28.5 -> 25.0 us with the row-per-wave kernel; at KITTI-00 size 7.1 vs 5.9 us)
+static bool spmv_row_per_wave(const DeviceSystem& sys) { return sys.spmv_rows >= 4; }
+static void* spmv_kernel_for(const DeviceGraph& g, const DeviceSystem& sys)
+{
+	if (sys.spmv_rows == 4) return (void*)pcg_spmv_row_kernel<4>;
+	return spmv_wants_occupancy(g) ? (void*)pcg_spmv_kernel<2, 4> : (void*)pcg_spmv_kernel<2, 1>;
+}
+static dim3 spmv_block_for(const DeviceSystem& sys) { return dim3((spmv_row_per_wave(sys) ? 64 : 128) * sys.spmv_rows); }
+
+void launch_pcg_spmv(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
+{
+	const dim3 grid((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows);
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar))spmv_kernel_for(g, sys), grid, spmv_block_for(sys), 0, s, g, st, sys, k, maxIter, tol2);
+}
+
+void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, s, g, st, sys, k, maxIter, tol2);
+}
+
+// last node of an iteration graph: advance the iteration offset and report the solver's flags straight into the
+// device-mapped host block the host looks at after synchronising (no copy kernels on the way)
+// (one wave.  tol2 >= 0: the node also runs the stop test on the residual the chunk's last iteration left -- r.z of iteration
+// kbase + n lives in the ring slot of chunk-local index 0, chunk lengths being multiples of 4 -- so that a batch of exactly as many
+// iterations as the solve needs is recognised as converged without a further iteration launch)
+__global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n, int report, Scalar tol2)
+{
+	if (tol2 >= 0 && n > 0)
+	{
+		const int lane = threadIdx.x;
+		const Scalar rzk = wave_sum(load_parts(rz_slot(sys, 0), sys.nrz, lane)), rz0 = wave_sum(load_parts(sys.rz, sys.nrz0, lane));
+		if (lane == 0 && *sys.done == 0 && *sys.fail == 0 && !(rzk > tol2 * rz0))
+		{
+			*sys.done = 1;
+			if (!(rzk == rzk)) *sys.fail = 3;
+		}
+	}
+	if (threadIdx.x != 0) return;
+	*sys.kbase += n;
+	if (report && sys.host_flags)
+	{
+		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
+		__threadfence_system();
+		sys.host_flags[3] = ++(*sys.ticket);      // the host spins on this word instead of paying a stream-synchronise round trip
+	}
+}
+
+// {chi2, landmark part of the gain-ratio denominator, pose part} of the evaluation just enqueued -> three device scalars
+// (the multi-GPU driver all-reduces the first two in-stream instead of reading them back rank by rank)
+__global__ void collect_eval_kernel(const Scalar* slots, Scalar* out)
+{
+	if (threadIdx.x == 0) { out[0] = slots[0]; out[1] = slots[NSLOT]; out[2] = slots[3 * NSLOT]; }
+}
+
+void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s)
+{
+	hipLaunchKernelGGL(collect_eval_kernel, dim3(1), dim3(64), 0, s, sys.slots, out3);
+}
+
+void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, 0, 1, Scalar(-1));
+}
+
+void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s)
+{
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, n, 1, Scalar(-1));
+}
+
+void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
+{
+	launch_pcg_spmv(g, st, sys, k, maxIter, tol2, s);
+	launch_pcg_update(g, st, sys, k, maxIter, tol2, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hipGraph of `chunk` PCG iterations + the kbase advance, built node by node (no stream capture: captures are
+// invalidated by unrelated work other host threads put on the legacy stream meanwhile, e.g. a second solver handle).
+// ---------------------------------------------------------------------------------------------------
+template <typename... Args>
+static hipError_t add_kernel_node(hipGraph_t graph, hipGraphNode_t& last, void* fn, dim3 grid, dim3 block, unsigned lds, Args... args)
+{
+	void* ptrs[] = { (void*)&args... };
+	hipKernelNodeParams p = {};
+	p.func = fn; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = lds; p.kernelParams = ptrs; p.extra = nullptr;
+	hipGraphNode_t node = nullptr;
+	const hipError_t e = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p);
+	last = node;
+	return e;
+}
+
+hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int chunk, int maxIter, Scalar tol2, int report)
+{
+	hipGraphNode_t last = nullptr;
+	hipError_t e = hipSuccess;
+	for (int k = 0; k < chunk && e == hipSuccess; k++)
+	{
+		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
+		if (e != hipSuccess) break;
+		if (sys.agg > 0)
+		{
+			e = add_kernel_node(graph, last, pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T),
+				(unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
+		}
+		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
+	}
+	if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_advance_kernel, dim3(1), dim3(64), 0, sys, chunk, report, tol2);
+	return e;
+}
+
+
+}  // namespace cubahip
+
+
+#ifdef CUBA_HIP_TRACE
+extern "C" int cuba_hip_debug_read_trace(unsigned long long* out)   // 3 x 8192 x 8 timestamps (100 MHz)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cubahip::cuba_trace_buf), sizeof(unsigned long long) * 3 * 8192 * 8);
+}
+#endif
+

@@ -1,7 +1,7 @@
 // ba_solver.hip -- host orchestration of one bundle-adjustment problem on one MI355X + the C ABI
 // (include/cuba_hip.h).  Behavioural counterpart of class CudaBlockSolver and of the LM loop in
 // CudaBundleAdjustmentImpl::optimize (/root/reference/src/cuda_bundle_adjustment.cpp:73-673, 793-857),
-// re-organised around landmark-sorted edges and fused kernels (see ba_kernels.hip).
+// re-organised around landmark-sorted edges and fused kernels (ba_edge.hip, ba_linearize.hip, ba_pcg.hip, ba_coarse.hip).
 //
 // There is deliberately no CPU fallback: every entry point fails with CUBA_HIP_ERR_NO_DEVICE /
 // CUBA_HIP_ERR_RUNTIME when no gfx950 device is usable.
@@ -98,13 +98,10 @@ struct cuba_hip_solver
 	// options
 	double pcgTol = sizeof(Scalar) == 8 ? 1e-7 : 1e-4;       // relative M^-1-norm residual; the objective is second-order in the solve error
 	int pcgMaxIter = 0;          // 0 = automatic
-	int pcgCheckEvery = 0;       // PCG iterations per host look at the device stop flag; 0 = adaptive (sized from the previous solve)
 	int coarseLinear = 1;        // 1: constant + linear coarse functions per aggregate (12 unknowns), 0: constant only (6)
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
-	int coarseMaxAge = 3;        // reuse the coarse inverse for this many further solves (a preconditioner may lag: it
-	                             // changes the iteration count only); refreshed early when the count degrades
 	// device-side set-up (ba_structure.hip): the edge sort and the whole symbolic structure are built on the GPU; the host
-	// pipeline below stays for landmark-partitioned handles and the first-generation atomic Schur kernel
+	// pipeline below stays as the independent cross-check ("device_setup" = 0) and for graphs without edges
 	bool deviceSetup = true;
 	bool devTopology = false;    // the sorted edge arrays / permutation exist on the device only (host copies are stale)
 	bool hostTopoValid = false;  // perm / h_lmptr / h_epose / h_spose / h_slm describe the current graph
@@ -127,7 +124,6 @@ struct cuba_hip_solver
 	std::vector<int> poseNewOfOld, poseOldOfNew;     // free poses only; identity unless reorderActive
 	DevBuf<int> d_rawEpCaller, d_poseMap;
 	bool mixedPrecision = false; // fp64 library: records + per-edge arithmetic of the pose / block passes in fp32 (sums, reduced system, PCG in fp64)
-	bool schurAtomic = false;    // true: first-generation landmark-major Schur kernel with fp64 atomics (A/B runs)
 	bool profile = false;
 
 	// host copy of the problem (solver order) and of the sort permutation
@@ -146,7 +142,7 @@ struct cuba_hip_solver
 	void dropSnapshots() { d_snapshots.clear(); }
 	DevBuf<int> d_epose, d_elm, d_lmptr;
 	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
-	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_pairBlk, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
+	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
 	DevBuf<int2> d_ell;
 	DevBuf<long long> d_bigOfs, d_lmPairBase;
 	DevBuf<Scalar> d_bigHpl;
@@ -155,12 +151,6 @@ struct cuba_hip_solver
 	DevBuf<unsigned long long> d_maxdiag;
 	DevBuf<int> d_fail, d_iters, d_kbase, d_done, d_ticket;
 	DevBuf<Scalar> d_eval;       // {chi2, landmark scale part, pose scale part} of cuba_hip_evaluate_device
-	// Forcing term of the inexact LM step (option "pcg_forcing" = eta, 0 = off): inside an LM run (cuba_hip_optimize, or a driver's
-	// cuba_hip_begin_run + stage calls) a solve stops at r.z <= pcg_tol^2 max(r_0.z_0, eta^2 ref), ref = r_0.z_0 of the run's first solve --
-	// late solves, whose right-hand side is orders of magnitude below the first one's, are not driven pcg_tol below THEIR start
-	DevBuf<Scalar> d_rzRef;
-	double pcgForcing = 0;
-	bool inRun = false, forcingSlotDirty = false;
 	DevBuf<Scalar> d_coarse[3], d_gjPivots, d_rc, d_r2, d_qpart, d_hrow;   // coarse: two work buffers of the inversion + the inverse in use
 	DevBuf<float> d_coarse32[2];  // option precond_fp32 (fp64 library): the inverse in use in fp32 [0] + the staging copy an overlapped inversion leaves [1]
 	// The inverse the FIRST solve of the previous LM run was given (same damping regime: lambda_0 = tau * max diagonal): it serves the first
@@ -174,14 +164,6 @@ struct cuba_hip_solver
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
 	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
-	// single-kernel PCG iteration: halo lists of the aggregates + its vectors
-	DevBuf<int> d_halN, d_halNJ, d_halPose, d_halAloc, d_haggId, d_ellLoc, d_ownLoc;
-	DevBuf<Scalar> d_w2, d_s0, d_s1, d_cw, d_cs, d_alpha;
-	// option "pcg_single_kernel": 1 = one launch per PCG iteration where the configuration allows it.  Built and measured in round 3
-	// (profiles/r03t_trace_pcg1_kitti00.txt): 21 us per iteration at KITTI-00 against 13 + 2 x 1.45 for the two-kernel iteration -- each of
-	// the 84 workgroups pulls 4-6 x the coarse-inverse rows of the fused kernel through its one CU (4.7 us until the loads land) and
-	// redoes residual and preconditioner on a ~50-pose halo -- so it stays OFF by default; iteration counts are identical.
-	int pcgSingleKernel = 0;
 	bool localRanges = false;
 	DevBuf<Scalar> d_erec;
 	DevBuf<int> d_cbI, d_cbJ, d_cbPtr, d_cbBlk;
@@ -226,8 +208,7 @@ struct cuba_hip_solver
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
 	{
-		if (sys.agg > 0 && sys.cg1) launch_pcg1(g, st, sys, k, maxIter, tol2, s);
-		else if (sys.agg > 0)
+		if (sys.agg > 0)
 		{
 			launch_pcg_spmv(g, st, sys, k, maxIter, tol2, s);
 			launch_pcg2_fused(g, sys, k, k + 1, maxIter, tol2, 1, s);
@@ -265,22 +246,18 @@ struct cuba_hip_solver
 	Scalar pcgGraphTol2 = 0; int pcgGraphMaxIter = 0;
 	double graphBuildSeconds = 0;
 
-	bool coarseValid = false, coarseFresh = false;
+	bool coarseValid = false;
 	// overlapped refresh: while the PCG of trial k runs (with the inverse built from trial k-1's matrix), a second stream
 	// assembles and inverts trial k's coarse matrix for trial k+1
 	// Pays since the sweep became light (look-ahead pivot inversion: one workgroup runs the 16-step chain, the others ~2 us of
 	// tile products): 9.43 -> 9.09 ms at KITTI-00 with a refresh under every trial; at S2M ten 0.85 ms sweeps per run cost the
 	// latency-bound PCG kernels more than they save (28.7 vs 28.4 ms), one under every third trial does pay (27.1 ms; G4M 67.6 -> 65.3).
-	int coarseOverlap = -1;       // -1 automatic, 0 off, 1 on
-	int coarseCuMask = 0;         // > 1: the second stream may use every n-th CU only (set before the first solve)
-	int coarseOverlapPeriod = -1; // trials between two overlapped refreshes: -1 automatic (1 up to a coarse dimension of 512, 2 up to 1024, 3 beyond)
 	int sideAge = 0;
-	bool overlapActive() const { return coarseOverlap != 0; }
 	int overlapPeriod() const
 	{
 		// KITTI-07 (Nc 372): 4.20 / 4.79 ms with period 1 / 2; KITTI-00 (672): 8.55 / 8.33 / 8.41 ms with 1 / 2 / 3; S2M (1500): 28.7 / 27.7 / 27.1 / 27.1 with 1 / 2 / 3 / 4
 		const int Nc = 6 * sys.cl * sys.nc;
-		return coarseOverlapPeriod > 0 ? coarseOverlapPeriod : Nc <= 512 ? 1 : Nc <= 1024 ? 2 : 3;
+		return Nc <= 512 ? 1 : Nc <= 1024 ? 2 : 3;
 	}
 	hipStream_t gjStream = nullptr;
 	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr, evFirstInv = nullptr;
@@ -291,20 +268,9 @@ struct cuba_hip_solver
 		if (gjStream) return;
 		int prioLow = 0, prioHigh = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-		// The sweep must not delay the latency-bound PCG kernels it runs under.  A low priority alone does not do it: a Gauss-Jordan
-		// step is ~1000 workgroups that fill every CU for ~10 us, and a PCG kernel that arrives meanwhile waits for them (gaps of
-		// 18-59 us inside the iteration graphs, profiles/r03p_*).  Option "coarse_cu_mask" = n > 1 confines the second stream to every
-		// n-th compute unit instead (hipExtStreamCreateWithCUMask): the sweep takes longer, the other CUs stay free.
-		if (coarseCuMask > 1)
-		{
-			hipDeviceProp_t prop;
-			HIP_TRY(hipGetDeviceProperties(&prop, device));
-			const int nCu = prop.multiProcessorCount;
-			std::vector<uint32_t> mask((size_t)(nCu + 31) / 32, 0u);
-			for (int c = 0; c < nCu; c += coarseCuMask) mask[c >> 5] |= 1u << (c & 31);
-			HIP_TRY(hipExtStreamCreateWithCUMask(&gjStream, (uint32_t)mask.size(), mask.data()));
-		}
-		else HIP_TRY(hipStreamCreateWithPriority(&gjStream, hipStreamNonBlocking, prioLow));   // fills the gaps of the latency-bound PCG kernels
+		// (low priority: the sweep fills the gaps of the latency-bound PCG kernels it runs under; confining it to every n-th CU instead
+		// was measured at <= 1 %, profiles/r03*)
+		HIP_TRY(hipStreamCreateWithPriority(&gjStream, hipStreamNonBlocking, prioLow));
 		HIP_TRY(hipEventCreateWithFlags(&evSetup, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&evAssembled, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&evInverse, hipEventDisableTiming));
@@ -318,8 +284,6 @@ struct cuba_hip_solver
 		if (pendingInv >= 0) { HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0)); pendingInv = -1; }
 		assemblePending = false;
 	}
-	int coarseAge = 0, lastSolveIters = 0, itersAtRefresh = 0;
-	double coarseGrowth = 1.6;   // refresh the coarse inverse early once a solve needs this many times the iterations of the solve it was built for
 	struct PatternEntry { uint64_t key; int ea, eb; };   // (column << 32 | product id + 1), the product's two sorted-edge ids
 	std::vector<PatternEntry> h_ent; std::vector<int> h_work[6];   // work arrays of build_structure
 	std::vector<double> h_chiSorted;         // per-edge chi2 in sorted order (staging of chi_squares)
@@ -358,16 +322,12 @@ struct cuba_hip_solver
 	// block: a spin on host memory sees it ~1 us after the kernel, hipStreamSynchronize only after ~20 us.
 	bool failDirty = true;       // the device-side failure flag of the PCG may be non-zero
 	int expectedTicket = 0;
-	bool spinWait = true;
 	bool hintSameEdges = false, hintSameValues = false;   // cuba_hip_hint_unchanged: promises about the next set_graph call
 	bool fusedTail = true;       // optimize(): back-substitution, update and evaluation of a trial in one pass over the edges (option "fused_tail")
-	bool speculateTail = false;  // optimize(): enqueue back-substitution/update/evaluation behind the first PCG batch. Measured with
-	                             // spin_wait on: 12.01 vs 11.95 ms (the saved host look is cheap now, a misprediction is not) -> off
 	void noteReport() { expectedTicket++; }
 	void waitReport()
 	{
 		volatile int* flags = (volatile int*)((char*)h_pinned + 1024);
-		if (spinWait)
 		{
 			const auto t0 = Clock::now();
 			for (long spins = 0; flags[3] != expectedTicket; spins++)
@@ -518,7 +478,7 @@ struct cuba_hip_solver
 		};
 		const DeviceGraph gOld = g;
 		bool sameTopology = false;
-		const bool useDev = deviceSetup && !schurAtomic && E > 0;
+		const bool useDev = deviceSetup && E > 0;
 		if (!useDev && (!hostTopoValid || reorderActive)) sameInput = false;      // the host-side sort of the previous call does not exist (device path)
 		if (useDev)
 		{
@@ -657,7 +617,7 @@ struct cuba_hip_solver
 			if (std::memcmp(&a, &b, sizeof(DeviceGraph)) != 0) dropPcgGraph();
 			haveStructure = true;
 		}
-		coarseValid = false; startRunHistory(); inRun = false;
+		coarseValid = false; startRunHistory();
 		haveGraph = true;
 		lambda = 0;
 		for (double& v : prof) v = 0;
@@ -679,7 +639,7 @@ struct cuba_hip_solver
 		if (!haveGraph) throw StateError{ "set_graph must be called first" };
 		if (haveStructure) return;
 		if (gjStream) { HIP_TRY(hipStreamSynchronize(gjStream)); pendingInv = -1; assemblePending = false; }   // an overlapped coarse inversion uses the old structure
-		if (devTopology && deviceSetup && !schurAtomic) { buildStructureDevice(); return; }      // (landmark partitions included)
+		if (devTopology && deviceSetup) { buildStructureDevice(); return; }      // (landmark partitions included)
 		localRanges = false;
 		if (reorderActive) { std::vector<int> id(Pf); for (int i = 0; i < Pf; i++) id[i] = i; applyPoseOrder(id); }   // the host pipeline runs in the caller's order
 		ensureHostTopology();
@@ -817,9 +777,8 @@ struct cuba_hip_solver
 		const long long nprodLocal = rowProducts[Pf];
 		h_colind.assign(nblk, 0);
 		std::vector<int> blkRow(nblk), prodPtr(nblk + 1, 0), odBlocks;
-		std::vector<int>&prodEa = h_work[2], &prodEb = h_work[3], &pairBlk = h_work[4];
+		std::vector<int>&prodEa = h_work[2], &prodEb = h_work[3];
 		prodEa.resize((size_t)nprodLocal); prodEb.resize((size_t)nprodLocal);
-		pairBlk.resize(schurAtomic ? (size_t)npairs : 0);                  // product -> block, only the first-generation kernel wants it
 		parallelRows(Pf, rowStart, [&](int i) {
 			int k = h_rowptr[i] - 1; uint32_t last = 0xffffffffu;
 			long long out = rowProducts[i];
@@ -828,7 +787,6 @@ struct cuba_hip_solver
 				const uint32_t c = (uint32_t)(ent[x].key >> 32); const uint32_t id = (uint32_t)ent[x].key;
 				if (c != last) { k++; h_colind[k] = (int)c; blkRow[k] = i; prodPtr[k] = (int)out; last = c; }
 				if (!id) continue;
-				if (schurAtomic) pairBlk[id - 1] = k | ((int)c == i ? 0x40000000 : 0);
 				if ((long long)id - 1 >= idLo && (long long)id - 1 < idHi) { prodEa[out] = ent[x].ea; prodEb[out] = ent[x].eb; out++; }
 			}
 		});
@@ -867,26 +825,9 @@ struct cuba_hip_solver
 			for (int c = 0; c <= maxCnt; c++) start[c + 1] += start[c];
 			odBlocks.resize(start[maxCnt + 1]);
 			for (int k = 0; k < nblk; k++) { const int c = prodPtr[k + 1] - prodPtr[k]; if (c > 0) odBlocks[start[maxCnt - c]++] = k; }
-			if (std::getenv("CUBA_HIP_BLOCK_ORDER_ROW")) { odBlocks.clear(); for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) odBlocks.push_back(k); }   // A/B: row order (measured slower: 174 vs 135 us at KITTI-00, the long lists must start first)
+			// (plain row order was measured slower: 174 vs 135 us at KITTI-00 -- the long lists must start first; an XCD-aware order cut the
+			// HBM-side fetch 2-3 x and bought nothing: the pass is latency-bound, profiles/r03j_block_order.txt)
 			if (rowGroupedBlocks(nprodLocal)) odBlocks = rowGroupedOrder(blkRow.data(), [&](int k) { return prodPtr[k + 1] - prodPtr[k]; }, nblk, h_colind.data());
-			if (const char* xe = std::getenv("CUBA_HIP_BLOCK_ORDER_XCD"))
-			{
-				// A/B (host pipeline only): blocks of the x-th eighth of the rows go to the workgroups that land on XCD x (workgroup w of the
-				// merged Schur launch runs on XCD (w + pose workgroups) mod 8), row-major inside an XCD (mode 1) or longest first inside
-				// an XCD (mode 2); unused slots hold -1
-				const int mode = std::atoi(xe), np = (Pf + 3) / 4;
-				std::vector<std::vector<int>> per(8);
-				for (int k = 0; k < nblk; k++) if (prodPtr[k + 1] > prodPtr[k]) per[std::min(7, (int)((long long)blkRow[k] * 8 / std::max(1, Pf)))].push_back(k);
-				if (mode == 2) for (auto& v : per) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return prodPtr[a + 1] - prodPtr[a] > prodPtr[b + 1] - prodPtr[b]; });
-				size_t slots = 0;
-				for (auto& v : per) slots = std::max(slots, (v.size() + 15) / 16);
-				odBlocks.assign(slots * 8 * 16, -1);
-				for (int x = 0; x < 8; x++)
-				{
-					const int lane8 = ((x - np) % 8 + 8) % 8;            // workgroup indices w with (w + np) % 8 == x are w = 8 s + lane8
-					for (size_t i = 0; i < per[x].size(); i++) odBlocks[((i / 16) * 8 + lane8) * 16 + (i % 16)] = per[x][i];
-				}
-			}
 		}
 		lap("structure: product lists");
 		// per free pose: its edges inside this handle's landmark range (a contiguous run of the global list)
@@ -932,7 +873,7 @@ struct cuba_hip_solver
 		d_waveLm.upload(waveLm, stream); d_bigLm.upload(bigLm, stream); d_bigOfs.upload(bigOfs, stream);
 		d_bigHpl.resize((size_t)bigEdges * 18);
 		d_rowptr.upload(h_rowptr, stream); d_colind.upload(h_colind, stream);
-		d_pairBlk.upload(pairBlk, stream); d_lmPairBase.upload(pairBase, stream); d_lmNfree.upload(nfree, stream);
+		d_lmNfree.upload(nfree, stream);
 		d_adjPtr.upload(adjPtr, stream); d_adjBlk.upload(adjBlk, stream); d_adjCol.upload(adjCol, stream);
 		int ellM = 0, ellOver = 0;
 		{
@@ -986,9 +927,9 @@ struct cuba_hip_solver
 		sync();
 		lap("structure: coarse lists + sync");
 		diagProdBlocks = 0; for (int k : odBlocks) diagProdBlocks += k >= 0 && blkRow[k] == h_colind[k];
-		heavyBlocks = 0;        // (the list is sorted by length; an XCD-aware experiment order is not: all blocks then take the 16-lane path)
-		if (!std::getenv("CUBA_HIP_BLOCK_ORDER_XCD") && !std::getenv("CUBA_HIP_BLOCK_ORDER_ROW") && !rowGroupedBlocks(nprodLocal))
-			for (int k : odBlocks) heavyBlocks += prodPtr[k + 1] - prodPtr[k] > heavyThreshold();
+		heavyBlocks = 0;        // (the plain list is sorted by length; the tile-grouped one is not: all blocks then take the 16-lane path)
+		if (!rowGroupedBlocks(nprodLocal))
+			for (int k : odBlocks) heavyBlocks += prodPtr[k + 1] - prodPtr[k] > BP_HEAVY;
 		publishStructure(nblk, (int)waveLm.size() / 2, (int)bigLm.size(), (int)odBlocks.size(), (int)cbI.size(), ellM, ellOver, cc);
 		hostPatternValid = true;
 		const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
@@ -1037,9 +978,8 @@ struct cuba_hip_solver
 		d_rc.resize((size_t)12 * c.cl * c.nc); d_r2.resize((size_t)6 * Pf);
 		maxIterAlloc = pcgMaxIter > 0 ? pcgMaxIter : std::min(32768, std::max(64, 4 * 6 * Pf));
 		const int gridSetup = (Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + c.spmvRows - 1) / c.spmvRows;
-		rzStrideCfg = std::max(1, std::max(std::max(gridSetup, gridUpd), c.nc)) + 1; pqStrideCfg = std::max(1, gridSpmv);   // (+ 1: the forcing term's extra partial of slot 0)
+		rzStrideCfg = std::max(1, std::max(std::max(gridSetup, gridUpd), c.nc)); pqStrideCfg = std::max(1, gridSpmv);
 		d_rz.resize((size_t)5 * rzStrideCfg); d_pq.resize((size_t)4 * pqStrideCfg);
-		d_rz.zero(stream); d_rzRef.resize(1);
 	}
 
 	// kernel-argument structures from the device buffers (identical for the host-built and the device-built structure)
@@ -1048,19 +988,14 @@ struct cuba_hip_solver
 	// outstanding misses (PMC: 4.6 L1->L2 requests per product, 546 cycles each, the L1 stalled on pending misses for 70 % of the launch:
 	// profiles/r03zw_pmc_schur_and_pcg_kernels.txt) --, tiles' leftovers re-chunked in tile order (neighbouring tiles share records too),
 	// chunks ordered by their longest list, -1 padding.  KITTI-00: linearise + Schur 110.7 -> 102.3 us, S2M 399 -> 358 us.
-	static bool rowGroupedBlocks(long long products)
-	{
-		static const int forced = std::getenv("CUBA_HIP_BLOCK_ORDER_ROWGROUP") ? std::atoi(std::getenv("CUBA_HIP_BLOCK_ORDER_ROWGROUP")) : -1;   // A/B knob: 0 / 1
-		return forced >= 0 ? forced != 0 : products > (1LL << 19);
-	}
+	static bool rowGroupedBlocks(long long products) { return products > (1LL << 19); }
 	template <class Cnt>
 	std::vector<int> rowGroupedOrder(const int* blkRow, Cnt&& cntOf, int nblk, const int* blkCol = nullptr) const
 	{
-		// groups are t x (16 / t) tiles of the block matrix, t = 4 (A/B knob CUBA_HIP_BLOCK_ORDER_TILE = 1, 2, 4, 8): a-side records are shared
-		// by 16 / t blocks of a workgroup, b-side records by t.  KITTI-00 linearise + Schur: pieces of one row (t = 1) 102.9 us, 2 x 8 tiles
-		// 99.3, 4 x 4 tiles 99.6; S2M 356 / 341.6 / 340.9 us
-		static const int tile = std::getenv("CUBA_HIP_BLOCK_ORDER_TILE") ? std::atoi(std::getenv("CUBA_HIP_BLOCK_ORDER_TILE")) : 4;
-		const int tr = blkCol && (tile == 2 || tile == 4 || tile == 8) ? tile : 1, tc = 16 / tr;
+		// groups are t x (16 / t) tiles of the block matrix, t = 4: a-side records are shared by 16 / t blocks of a workgroup, b-side
+		// records by t.  KITTI-00 linearise + Schur: pieces of one row (t = 1) 102.9 us, 2 x 8 tiles 99.3, 4 x 4 tiles 99.6; S2M 356 /
+		// 341.6 / 340.9 us (profiles/r03fin3_block_order_tiles.txt)
+		const int tr = blkCol ? 4 : 1, tc = 16 / tr;
 		const int nColTiles = (Pf + tc - 1) / tc;
 		std::vector<std::vector<int>> rows(tr > 1 ? 0 : Pf);
 		if (tr > 1)
@@ -1094,7 +1029,6 @@ struct cuba_hip_solver
 	}
 	int diagProdBlocks = 0;      // diagonal blocks with products (duplicate observations), set by the structure builders
 	int heavyBlocks = 0;         // blocks with more than BP_HEAVY products (the first ones of d_odBlocks), set by the structure builders
-	static int heavyThreshold() { static const int v = std::getenv("CUBA_HIP_BP_HEAVY") ? std::atoi(std::getenv("CUBA_HIP_BP_HEAVY")) : BP_HEAVY; return v; }   // (A/B knob)
 	void publishStructure(int nblk, int nWaves, int nBig, int nOd, int nCb, int ellM, int ellOver, const CoarseCfg& c)
 	{
 		const int agg = c.agg, cl = c.cl, nc = c.nc, spmvRows = c.spmvRows;
@@ -1103,15 +1037,15 @@ struct cuba_hip_solver
 		st.nWaves = nWaves; st.wave_lm = d_waveLm.data();
 		st.nBig = nBig; st.big_lm = d_bigLm.data(); st.big_scratch_ofs = d_bigOfs.data(); st.big_hpl = d_bigHpl.data();
 		st.nblk = nblk; st.hsc_rowptr = d_rowptr.data(); st.hsc_colind = d_colind.data();
-		st.pair_blk = d_pairBlk.data(); st.lm_pair_base = d_lmPairBase.data(); st.lm_nfree = d_lmNfree.data();
+		st.lm_nfree = d_lmNfree.data();
 		st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
 		st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
 		st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data(); st.nHeavy = std::min(heavyBlocks, nOd);
 		// (whole-wave blocks shorten the longest dependent chain of the block pass: 51 -> 37 us at KITTI-07; on graphs whose pass is bound by its
 		// gathers they only add waves: 114 -> 122 us at KITTI-00, 405 -> 411 us at S2M -- profiles/r03z_block_pass_ab.txt)
-		if (d_prodEa.size() > ((size_t)1 << 19) && !std::getenv("CUBA_HIP_BP_HEAVY")) st.nHeavy = 0;
+		if (d_prodEa.size() > ((size_t)1 << 19)) st.nHeavy = 0;
 		// (64-byte rows of the landmark inverses: block pass -3 us / landmark pass +5 us at KITTI-00, -16 / +3 us at S2M)
-		st.inv_rows8 = std::getenv("CUBA_HIP_BLOCK_PASS_INV_FROM_LM_SYS") ? 0 : std::getenv("CUBA_HIP_BLOCK_PASS_INV_ROWS8") ? 1 : Lf >= 250000;
+		st.inv_rows8 = Lf >= 250000;
 		st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 		if (!localRanges) fillProdLm();          // (a device-built partition needed it earlier)
 		st.prod_lm = d_prodLm.data();
@@ -1128,44 +1062,16 @@ struct cuba_hip_solver
 		dropPcgGraph();
 		firstInvValid = false; firstInvPending = false; prevRunIters.clear();
 		sys.rzStride = rzStrideCfg; sys.pqStride = pqStrideCfg; sys.npq = gridSpmv;
-		sys.nrz0 = (agg > 0 ? nc : gridSetup) + 1; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();   // (slot 0: the partials of r_0.z_0 + the forcing term's, zero unless "pcg_forcing" is at work)
-		forcingSlotDirty = false;
+		sys.nrz0 = agg > 0 ? nc : gridSetup; sys.nrz = agg > 0 ? nc : gridUpd; sys.done = d_done.data();
 		coarseValid = false;
 		d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); d_gjPivots.resize(2 * 32 * 32); sys.gj_pivots = d_gjPivots.data();
 		sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 		d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
 		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
-		d_hrow.zero(stream);         // (padding slots are never written: the single-kernel iteration reads them unmasked)
+		d_hrow.zero(stream);         // (padding slots are never written)
 		sys.spmv_rows = spmvRows;
 		sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 		sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
-		// single-kernel iteration: halo lists of the aggregates (two small launches + one read-back of their maximal lengths)
-		sys.cg1 = 0;
-		if (agg > 0 && pcgSingleKernel && !ellOver && ellM >= 1 && topo::halo_lds_bytes(Pf, nc) <= 48 * 1024)
-		{
-			d_counters.resize(topo::CNT_COUNT);
-			HIP_TRY(hipMemsetAsync(d_counters.data() + topo::CNT_MAXH, 0, 2 * sizeof(int), stream));
-			d_halN.resize(nc); d_halNJ.resize(nc);
-			topo::launch_halo_count(d_ell.data(), Pf, ellM, agg, nc, d_halN.data(), d_halNJ.data(), d_counters.data(), stream);
-			int mx[2] = { 0, 0 };
-			HIP_TRY(hipMemcpyAsync(mx, d_counters.data() + topo::CNT_MAXH, sizeof mx, hipMemcpyDeviceToHost, stream));
-			sync();
-			st.hmax = mx[0]; st.jmax = mx[1];
-			d_halPose.resize((size_t)nc * st.hmax); d_halAloc.resize((size_t)nc * st.hmax); d_haggId.resize((size_t)nc * st.jmax);
-			d_ellLoc.resize((size_t)Pf * ellM * 20); d_ownLoc.resize(Pf);
-			HIP_TRY(hipMemsetAsync(d_halPose.data(), 0xff, sizeof(int) * d_halPose.size(), stream));     // -1 padding: the iteration kernel loads the
-			HIP_TRY(hipMemsetAsync(d_haggId.data(), 0xff, sizeof(int) * d_haggId.size(), stream));       // lists at their full width
-			HIP_TRY(hipMemsetAsync(d_halAloc.data(), 0, sizeof(int) * d_halAloc.size(), stream));
-			topo::launch_halo_fill(d_ell.data(), Pf, ellM, agg, nc, st.hmax, st.jmax, d_halPose.data(), d_halAloc.data(), d_haggId.data(), d_ellLoc.data(), d_ownLoc.data(), stream);
-			st.hal_n = d_halN.data(); st.hal_nj = d_halNJ.data(); st.hal_pose = d_halPose.data(); st.hal_aloc = d_halAloc.data();
-			st.hagg_id = d_haggId.data(); st.ell_loc = d_ellLoc.data(); st.own_loc = d_ownLoc.data();
-			const size_t Ncs = (size_t)6 * sys.cl * nc;
-			d_w2.resize((size_t)6 * Pf); d_s0.resize((size_t)6 * Pf); d_s1.resize((size_t)6 * Pf); d_cw.resize(2 * Ncs); d_cs.resize(2 * Ncs); d_alpha.resize(2);
-			d_cw.zero(stream); d_cs.zero(stream); d_alpha.zero(stream); d_s0.zero(stream); d_s1.zero(stream); d_w2.zero(stream);
-			sys.w2 = d_w2.data(); sys.s0 = d_s0.data(); sys.s1 = d_s1.data(); sys.cw = d_cw.data(); sys.cs = d_cs.data(); sys.alpha = d_alpha.data();
-			sys.cg1 = pcg1_supported(g, st, sys) ? 1 : 0;
-			if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] single-kernel PCG iteration: %s (halo <= %d poses, %d aggregates)\n", sys.cg1 ? "on" : "off", st.hmax, st.jmax);
-		}
 		haveStructure = true;
 	}
 	bool hostPatternValid = false;     // h_rowptr / h_colind describe the current structure (the device-built one downloads them on demand)
@@ -1458,7 +1364,7 @@ struct cuba_hip_solver
 			topo::launch_segment_subrange(d_prodPtr.data(), nblk, d_prodLm.data(), lo, hi, d_prodBeg.data(), d_prodEnd.data(), stream);
 		}
 		topo::launch_od_keys(localRanges ? d_prodBeg.data() : d_prodPtr.data(), localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1,
-			d_blkrow.data(), d_colind.data(), nblk, farOffset(), heavyThreshold(), d_k32a.data(), d_v32a.data(), cnt, stream);
+			d_blkrow.data(), d_colind.data(), nblk, farOffset(), BP_HEAVY, d_k32a.data(), d_v32a.data(), cnt, stream);
 		if (nblk) HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), nblk, 32, stream));
 		topo::launch_copy_u32_to_int(d_v32b.data(), d_odBlocks.data(), nblk, stream);
 		// 7. symmetric adjacency: the lower part of every row comes from the (column, row)-sorted list of the off-diagonal blocks
@@ -1497,7 +1403,6 @@ struct cuba_hip_solver
 		const int ellM = std::min(3, (maxRow + 19) / 20), ellOver = maxRow > 20 * ellM;
 		d_ell.resize((size_t)Pf * ellM * 20);
 		topo::launch_ell(d_adjPtr.data(), d_adjBlk.data(), d_adjCol.data(), Pf, ellM, d_ell.data(), stream);
-		d_pairBlk.resize(0);
 		if (!reorderActive && !reorderTried && tryReorder(nblk, hc[topo::CNT_FARBLOCKS]))
 		{
 			reorderTried = true;
@@ -1575,23 +1480,20 @@ struct cuba_hip_solver
 		return readSlots(0);
 	}
 
-	// [hsc | bsc | bp] needs zeroing only where a block may have no writer: the atomic Schur kernel accumulates, and a landmark
-	// partition leaves blocks without local products; on the default path the pose pass writes every diagonal block, bp and bsc
+	// [hsc | bsc | bp] needs zeroing only where a block may have no writer: a landmark
+	// partition leaves blocks without local products; otherwise the pose pass writes every diagonal block, bp and bsc
 	// and the block pass every off-diagonal block
 	// (force: the assemble-only mode writes the diagonal blocks' upper triangles and bp only -- off-diagonal blocks, bsc and the lower
 	// triangles would otherwise keep a previous trial's values, which the stage API exposes through cuba_hip_get_array /
 	// cuba_hip_reduction_buffer and a multi-GPU driver sums)
-	void zeroReduced(bool force = false) { waitAssembled(); if (force || schurAtomic || partHi >= 0 || !reducedZeroed) { d_red.zero(stream); reducedZeroed = true; } }
+	void zeroReduced(bool force = false) { waitAssembled(); if (force || partHi >= 0 || !reducedZeroed) { d_red.zero(stream); reducedZeroed = true; } }
 	bool reducedZeroed = false;
 
 	// withBackup: the state is also copied into its backup (push() of the LM loop) -- inside the landmark pass's launch where possible
 	void linearize(int mode, double lam, bool withBackup = false)
 	{
 		waitAssembled();            // an overlapped coarse assembly may still be reading the previous reduced matrix
-		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
-		if (schurAtomic || separateCopies) { if (withBackup) push(); withBackup = false; }
-		if (schurAtomic) launch_linearize(g, st, sys, mode, lam, stream);
-		else launch_linearize_dm(g, st, sys, mode, lam, stream, withBackup ? d_state.data() : nullptr, d_backup.data(), d_state.size());
+		launch_linearize_dm(g, st, sys, mode, lam, stream, withBackup ? d_state.data() : nullptr, d_backup.data(), d_state.size());
 	}
 
 	// assemble only: Hpp -> diagonal blocks, bp, raw Hll/bl, landmark part of the max diagonal
@@ -1657,45 +1559,25 @@ struct cuba_hip_solver
 		linearize(1, lambda, withBackup);
 	}
 
-	// `tail` (optional): work that only makes sense once the solve has converged (back-substitution, update, evaluation of
-	// the trial) but is enqueued right behind the FIRST batch of iterations, speculating that the predicted batch size was
-	// enough -- it is for ~9 solves in 10, and then the whole trial costs one host look instead of two.  If the batch was
-	// too short, `undo` restores what the tail changed, the iterations continue, and *tailValid stays false.
 	// A PCG that BREAKS DOWN (p.Ap <= 0 or a NaN -- not a solve that merely runs out of iterations) while the coarse inverse is stored in
 	// fp32 is repeated once with fp64 storage, which the handle then keeps: rounding a symmetrised inverse to fp32 perturbs it by
 	// ~6e-8 ||Ac^-1||, which can cost positive definiteness once lambda_max(block) / lambda_min(Ac) approaches 1e7 (weakly constrained
 	// graphs at very small damping; round-3 advisor).  Counted in "precond_fp32_fallbacks".
 	bool lastSolveBrokeDown = false;
-	bool solveReduced(const std::function<void()>* tail = nullptr, const std::function<void()>* undo = nullptr, bool* tailValid = nullptr)
+	bool solveReduced()
 	{
-		const bool ok = solveReducedOnce(tail, undo, tailValid);
+		const bool ok = solveReducedOnce();
 		if (ok || !lastSolveBrokeDown || !fp32Inverse() || sys.agg <= 0) return ok;
 		precondFp32 = false; sys.acinv32 = nullptr;
 		dropPcgGraph();
 		coarseValid = false; firstInvValid = false; firstInvPending = false;
 		cntFp32Fallbacks++;
 		if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG broke down with the fp32-stored coarse inverse: repeating the solve with fp64 storage\n");
-		return solveReducedOnce(nullptr, nullptr, nullptr);
+		return solveReducedOnce();
 	}
 
-	// between the first preconditioner application of a solve (which leaves the partials of r_0.z_0) and its first iteration
-	void applyForcing()
+	bool solveReducedOnce()
 	{
-		if (inRun && pcgForcing > 0)
-		{
-			launch_pcg_forcing(sys, (Scalar)(pcgForcing * pcgForcing), runIters.empty() ? 1 : 0, d_rzRef.data(), stream);
-			forcingSlotDirty = true;
-		}
-		else if (forcingSlotDirty)
-		{
-			HIP_TRY(hipMemsetAsync(sys.rz + (sys.nrz0 - 1), 0, sizeof(Scalar), stream));
-			forcingSlotDirty = false;
-		}
-	}
-
-	bool solveReducedOnce(const std::function<void()>* tail, const std::function<void()>* undo, bool* tailValid)
-	{
-		if (tailValid) *tailValid = false;
 		lastSolveBrokeDown = false;
 		need();
 		StageTimer tm(this, 6);
@@ -1708,29 +1590,20 @@ struct cuba_hip_solver
 		// graphs read within the next launch
 		const size_t invCount = (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
 		bool takeInverse = false;
-		if (twoLevel && overlapActive() && coarseValid && pendingInv >= 0)
+		if (twoLevel && coarseValid && pendingInv >= 0)
 		{
 			HIP_TRY(hipStreamWaitEvent(stream, evInverse, 0));     // normally long done
 			takeInverse = true; pendingInv = -1;
 		}
 		// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
-		static const bool separateCopies = std::getenv("CUBA_HIP_SEPARATE_COPIES") != nullptr;     // A/B knob
-		if (takeInverse && separateCopies)
-		{
-			if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_coarse32[0].data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, stream));
-			else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invCount * sizeof(Scalar), hipMemcpyDeviceToDevice, stream));
-			takeInverse = false;
-		}
 		if (fp32Inverse())     // the overlapped inversion left an fp32 copy in the staging buffer: that is what moves into the buffer in use
 			launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? reinterpret_cast<const Scalar*>(d_coarse32[1].data()) : nullptr,
 				reinterpret_cast<Scalar*>(d_coarse32[0].data()), inv32Count() / 2);
 		else launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
-		if (!twoLevel) applyForcing();
 		if (twoLevel)
 		{
 			// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
 			const int gjSteps = (6 * sys.cl * sys.nc + 31) / 32, first = gjSteps & 1;
-			if (overlapActive())
 			{
 				// The inverse in use lives in d_coarse[2] (the iteration graphs have the pointer baked in); d_coarse[0 / 1] are
 				// the work buffers of the sweep, which leaves its result in d_coarse[0].
@@ -1790,38 +1663,16 @@ struct cuba_hip_solver
 					pendingInv = 0;
 					assemblePending = true; cntCoarseRefresh++;
 				}
-				coarseFresh = false;
-			}
-			else
-			{
-				const bool refresh = !coarseValid || coarseAge >= coarseMaxAge || lastSolveIters > coarseGrowth * itersAtRefresh + 8;
-				if (refresh)
-				{
-					drainInversion();
-					sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
-					if (fp32Inverse()) launch_coarse_to_fp32(sys.acinv, d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
-					coarseValid = true; coarseAge = 0; cntCoarseRefresh++; cntCoarseInline++;
-				}
-				else coarseAge++;
-				coarseFresh = refresh;
 			}
 			launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
-			applyForcing();
-			if (sys.cg1)
-			{
-				// single-kernel iterations start from u_0 (just computed), w_0 = A u_0 and their restricted vectors
-				launch_pcg_spmv(g, st, sys, 0, maxIter, tol2, stream);
-				launch_pcg1_init(g, sys, stream);
-			}
 		}
 		// first solve on this structure: the usual chunk lengths at once (0.5 ms), not one by one inside later runs
-		if (useGraph && pcgCheckEvery <= 0 && pcgGraphs.empty())
+		if (useGraph && pcgGraphs.empty())
 			for (int c = 4; c <= 64; c *= 2) (void)pcgGraph(c, maxIter, tol2);
 		// Iterations are enqueued in chunks (graphs of 4/8/.../256 iterations; chunk lengths are multiples of 4
 		// because the kernels address their reduction slots by the chunk-local k & 3) and the host looks at the device
 		// stop flag after each batch.  A launch after convergence still costs ~2.5 us per kernel and a look costs a
 		// host round trip, so the first batch is sized from the previous solve of this run.
-		const int fixedChunk = pcgCheckEvery > 0 ? (pcgCheckEvery + 3) / 4 * 4 : 0;
 		volatile int* hInts = (volatile int*)((char*)h_pinned + 1024);   // fail, iterations done, stop flag: written by the device
 		bool converged = false;
 		int k0 = 0, looks = 0;
@@ -1847,18 +1698,18 @@ struct cuba_hip_solver
 		}
 		// (the last node of every iteration graph runs the stop test on the residual its chunk left: a batch of exactly the needed
 		// length is recognised as converged)
-		int target = fixedChunk ? fixedChunk : (predicted + 3) / 4 * 4;
+		int target = (predicted + 3) / 4 * 4;
 		while (k0 < maxIter && !converged)
 		{
 			int todo = std::max(4, std::min(target, maxIter) - k0);
 			while (todo > 0)
 			{
-				int c = fixedChunk;
-				if (!c) for (c = 256; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
+				int c = 256;
+				for (; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
 				// a batch length that comes back (repeated runs on one structure) gets a graph of exactly that length: one hand-over per
 				// batch instead of one per power of two.  Not on the first request -- the reference's timing protocol meets most lengths for
 				// the first time inside its timed part, and an instantiation costs ~2 us per node.
-				if (!fixedChunk && useGraph && exactBatchGraphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
+				if (useGraph && exactBatchGraphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
 				{
 					if (pcgGraphs.count(std::make_pair(todo, (const Scalar*)sys.acinv)) || ++batchRequests[todo] >= 2) c = todo;
 				}
@@ -1866,18 +1717,11 @@ struct cuba_hip_solver
 				else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				k0 += c; todo -= c;
 			}
-			const bool speculate = tail && looks == 0;
-			if (speculate) (*tail)();                                             // ends with its own report
-			else if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (the graphs end with this report)
+			if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (the graphs end with this report)
 			waitReport();
-			if (hInts[0] != 0) { lastSolveBrokeDown = true; cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; lastSolveIters = 0; failDirty = true; return false; }
+			if (hInts[0] != 0) { lastSolveBrokeDown = true; cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; failDirty = true; return false; }
 			if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
-			if (speculate)
-			{
-				if (converged || k0 >= maxIter) *tailValid = true;
-				else (*undo)();
-			}
-			target = k0 + (fixedChunk ? fixedChunk : (looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
+			target = k0 + ((looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
 			looks++; cntPcgLooks++;
 		}
 		if (std::getenv("CUBA_HIP_DEBUG"))
@@ -1893,8 +1737,6 @@ struct cuba_hip_solver
 		cntPcgIters += itersDone; cntPcgEnqueued += k0;
 		if (runIters.empty()) firstSolveIters = itersDone;
 		runIters.push_back(itersDone);
-		lastSolveIters = itersDone;
-		if (coarseFresh) itersAtRefresh = itersDone;
 		if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);   // drivers that never call set_graph again: keep the latest
 		pcgHistory.push_back(converged ? itersDone : -itersDone);
 		if (!converged)
@@ -1953,8 +1795,6 @@ struct cuba_hip_solver
 		need();
 		coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
 		startRunHistory();
-		inRun = true;
-		struct EndRun { bool& f; ~EndRun() { f = false; } } endRun{ inRun };
 		const int maxq = 10;
 		const double tau = 1e-5;
 		double nu = 2, lam = 0, F = 0;
@@ -1971,14 +1811,9 @@ struct cuba_hip_solver
 				cntTrials++;
 				lambda = lam;
 				schur(true);          // (with the push() of the reference's loop: the backup of the state rides in the landmark pass's launch)
-				// back-substitution, update and evaluation of the trial ride behind the first batch of PCG iterations
-				const std::function<void()> tail = [&] { backSubstitute(); update(); enqueueEvaluate(lam, true); };
-				const std::function<void()> undo = [&] { pop(); };
-				bool tailValid = false;
-				const bool ok = speculateTail ? solveReduced(&tail, &undo, &tailValid) : solveReduced();
+				const bool ok = solveReduced();
 				double Fhat = 0, scale = 0;
-				if (ok && tailValid) readEvaluate(true, &Fhat, &scale);     // already there: it came with the solver's flags
-				else if (ok && !profile && partHi < 0 && fusedTail && !schurAtomic && trial_tail_parts(g, st) <= d_parts.size())
+				if (ok && !profile && partHi < 0 && fusedTail && trial_tail_parts(g, st) <= d_parts.size())
 				{
 					// back-substitution + update + evaluation in one pass over the edges (reads the pre-trial estimate from the backup
 					// schur(true) has just made), then sums + report: two launches, one host look
@@ -2109,12 +1944,7 @@ struct cuba_hip_solver
 		if (sys.agg > 0)
 		{
 			msOut[3] = timeit([&] { launch_pcg2_fused(g, sys, 0, 1, 1 << 30, -1.0, 1, stream); });
-			msOut[5] = 0;   // the single-kernel iteration, where it is in use
-			if (sys.cg1)
-			{
-				launch_pcg1_init(g, sys, stream);
-				msOut[5] = timeit([&] { launch_pcg1(g, st, sys, 0, 1 << 30, -1.0, stream); });
-			}
+			msOut[5] = 0;
 			msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream); });
 		}
 		else
@@ -2256,33 +2086,18 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		if (!key) throw ArgError{ "null key" };
 		const std::string k(key);
 		if (k == "pcg_tol") s->pcgTol = value;
-		else if (k == "pcg_forcing") s->pcgForcing = std::max(0.0, value);
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
-		else if (k == "coarse_refresh_growth") s->coarseGrowth = value;
-		else if (k == "spin_wait") s->spinWait = value != 0;
-		else if (k == "speculate_tail") s->speculateTail = value != 0;
 		else if (k == "fused_tail") s->fusedTail = value != 0;
 		else if (k == "pcg_exact_batch_graphs") s->exactBatchGraphs = value != 0;
 		else if (k == "pcg_repeat_prediction") s->repeatPrediction = value != 0;
-		else if (k == "pcg_single_kernel") { s->pcgSingleKernel = value != 0; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
-		else if (k == "coarse_overlap_period") s->coarseOverlapPeriod = (int)value;
-		else if (k == "coarse_cu_mask")
-		{
-			if (s->gjStream) throw StateError{ "coarse_cu_mask must be set before the first solve" };
-			s->coarseCuMask = (int)value;
-		}
-		else if (k == "coarse_overlap") { s->coarseOverlap = value < 0 ? -1 : (value != 0 ? 1 : 0); s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }
 		else if (k == "mixed_precision") s->mixedPrecision = value != 0 && sizeof(Scalar) == 8;
 		else if (k == "pcg_accept_unconverged") s->acceptUnconverged = value != 0;
-		else if (k == "pcg_check_every") s->pcgCheckEvery = std::max(1, (int)value);
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
-		else if (k == "schur_atomic") { s->schurAtomic = value != 0; s->haveStructure = false; }   // the product -> block map is built on demand
-		else if (k == "coarse_max_age") s->coarseMaxAge = std::max(0, (int)value);
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
@@ -2615,7 +2430,7 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 
 int cuba_hip_begin_run(cuba_hip_solver* s)
 {
-	return guarded(s, [&] { s->need(); s->coarseValid = false; s->startRunHistory(); s->inRun = true; });
+	return guarded(s, [&] { s->need(); s->coarseValid = false; s->startRunHistory(); });
 }
 
 int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream)

@@ -286,71 +286,6 @@ __global__ __launch_bounds__(T) void ell_kernel(const int* adjPtr, const int* ad
 	ell[x] = e < n ? int2{ adjBlk[a0 + e], adjCol[a0 + e] } : int2{ 0, -1 };
 }
 
-// ---- halo lists of the aggregates (single-kernel PCG iteration) ------------------------------------------------------------------
-// One workgroup per aggregate I: the set H_I of poses that the block rows of I touch (their columns, the rows themselves included)
-// and the set of aggregates those poses belong to, as bitmaps in LDS; ranks inside the sets are the local indices the iteration
-// kernel addresses its LDS copies of the halo vectors with.  FILL = false: sizes only (nH, nJ, their maxima -> counters).
-template <bool FILL>
-__global__ __launch_bounds__(256) void halo_lists_kernel(const int2* __restrict__ ell, int Pf, int M, int agg, int nc, int* __restrict__ nH, int* __restrict__ nJ,
-	int* __restrict__ counters, int HMAX, int JMAX, int* __restrict__ hal_pose, int* __restrict__ hal_aloc, int* __restrict__ hagg_id,
-	int* __restrict__ ell_loc, int* __restrict__ own_loc)
-{
-	extern __shared__ unsigned halo_lds[];
-	const int WP = (Pf + 31) >> 5, WA = (nc + 31) >> 5;
-	unsigned* bmP = halo_lds; unsigned* bmA = bmP + WP;
-	int* prefP = reinterpret_cast<int*>(bmA + WA); int* prefA = prefP + WP;
-	const int I = blockIdx.x, r0 = I * agg, r1 = min(Pf, r0 + agg);
-	for (int w = threadIdx.x; w < WP + WA; w += 256) halo_lds[w] = 0u;
-	__syncthreads();
-	const int W = 20 * M;
-	const int nEnt = (r1 - r0) * W;
-	for (int x = threadIdx.x; x < nEnt; x += 256)
-	{
-		const int col = ell[(size_t)r0 * W + x].y;
-		if (col >= 0) { atomicOr(&bmP[col >> 5], 1u << (col & 31)); const int a = col / agg; atomicOr(&bmA[a >> 5], 1u << (a & 31)); }
-	}
-	for (int i = r0 + (int)threadIdx.x; i < r1; i += 256) { atomicOr(&bmP[i >> 5], 1u << (i & 31)); atomicOr(&bmA[I >> 5], 1u << (I & 31)); }
-	__syncthreads();
-	if (threadIdx.x == 0)
-	{
-		int run = 0;
-		for (int w = 0; w < WP; w++) { prefP[w] = run; run += __popc(bmP[w]); }
-		const int h = run;
-		run = 0;
-		for (int w = 0; w < WA; w++) { prefA[w] = run; run += __popc(bmA[w]); }
-		if (!FILL) { nH[I] = h; nJ[I] = run; atomicMax(&counters[CNT_MAXH], h); atomicMax(&counters[CNT_MAXJ], run); }
-	}
-	if (!FILL) return;
-	__syncthreads();
-	auto rankA = [&](int a) { return prefA[a >> 5] + __popc(bmA[a >> 5] & ((1u << (a & 31)) - 1u)); };
-	auto rankP = [&](int j) { return prefP[j >> 5] + __popc(bmP[j >> 5] & ((1u << (j & 31)) - 1u)); };
-	for (int w = threadIdx.x; w < WP; w += 256)
-	{
-		unsigned bits = bmP[w];
-		int rk = prefP[w];
-		while (bits)
-		{
-			const int b = __ffs(bits) - 1; bits &= bits - 1;
-			const int pose = 32 * w + b;
-			hal_pose[(size_t)I * HMAX + rk] = pose;
-			hal_aloc[(size_t)I * HMAX + rk] = rankA(pose / agg);
-			if (pose >= r0 && pose < r1) own_loc[pose] = rk;
-			rk++;
-		}
-	}
-	for (int w = threadIdx.x; w < WA; w += 256)
-	{
-		unsigned bits = bmA[w];
-		int rk = prefA[w];
-		while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; hagg_id[(size_t)I * JMAX + rk++] = 32 * w + b; }
-	}
-	for (int x = threadIdx.x; x < nEnt; x += 256)
-	{
-		const int col = ell[(size_t)r0 * W + x].y;
-		ell_loc[(size_t)r0 * W + x] = col >= 0 ? rankP(col) : -1;
-	}
-}
-
 __global__ __launch_bounds__(T) void coarse_keys_kernel(const int* adjRow, const int* adjCol, int nAdj, int agg, int nc, uint32_t* keys, uint32_t* vals)
 {
 	const int a = blockIdx.x * T + threadIdx.x;
@@ -562,20 +497,6 @@ void launch_ell(const int* adjPtr, const int* adjBlk, const int* adjCol, int Pf,
 {
 	const size_t n = (size_t)Pf * 20 * M;
 	if (n > 0) hipLaunchKernelGGL(ell_kernel, grid_for(n), dim3(T), 0, s, adjPtr, adjBlk, adjCol, Pf, M, ell);
-}
-
-size_t halo_lds_bytes(int Pf, int nc) { return 2 * sizeof(unsigned) * (size_t)(((Pf + 31) >> 5) + ((nc + 31) >> 5)); }
-
-void launch_halo_count(const int2* ell, int Pf, int M, int agg, int nc, int* nH, int* nJ, int* counters, hipStream_t s)
-{
-	if (nc > 0) hipLaunchKernelGGL(halo_lists_kernel<false>, dim3(nc), dim3(256), halo_lds_bytes(Pf, nc), s, ell, Pf, M, agg, nc, nH, nJ, counters, 0, 0,
-		(int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
-}
-
-void launch_halo_fill(const int2* ell, int Pf, int M, int agg, int nc, int HMAX, int JMAX, int* hal_pose, int* hal_aloc, int* hagg_id, int* ell_loc, int* own_loc, hipStream_t s)
-{
-	if (nc > 0) hipLaunchKernelGGL(halo_lists_kernel<true>, dim3(nc), dim3(256), halo_lds_bytes(Pf, nc), s, ell, Pf, M, agg, nc, (int*)nullptr, (int*)nullptr, (int*)nullptr,
-		HMAX, JMAX, hal_pose, hal_aloc, hagg_id, ell_loc, own_loc);
 }
 
 void launch_coarse_keys(const int* adjRow, const int* adjCol, int nAdj, int agg, int nc, uint32_t* keys, uint32_t* vals, hipStream_t s)

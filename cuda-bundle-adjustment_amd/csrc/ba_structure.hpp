@@ -30,7 +30,7 @@ hipError_t exclusive_scan_i64(void* temp, size_t tempBytes, const long long* in,
 hipError_t inclusive_scan_i32(void* temp, size_t tempBytes, const int* in, int* out, size_t n, hipStream_t s);
 
 // counters the kernels fill (one device int each), read back by the host at its synchronisation points
-enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_MAXH, CNT_MAXJ, CNT_NHEAVY, CNT_COUNT = 16 };
+enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_NHEAVY, CNT_COUNT = 16 };
 
 // ---- A. edges ------------------------------------------------------------------------------------------------------
 // keys[e] = landmark << 32 | pose, vals[e] = e; counters[CNT_BAD] = 1 / 2 / 3 for an index out of range / a bad dimension /
@@ -50,13 +50,6 @@ void launch_lm_pairs(const int* lm_ptr, const int* e_pose, int Lf, int Pf, int* 
 // pose key of every sorted edge (Pf for edges whose pose is fixed) + identity values, for the per-pose edge lists
 void launch_pose_keys(const int* e_pose, int E, int Pf, uint32_t* keys, uint32_t* vals, hipStream_t s);
 void launch_copy_u32_to_int(const uint32_t* in, int* out, int n, hipStream_t s);
-// halo lists of the coarse aggregates for the single-kernel PCG iteration (ba_kernels.hip: pcg1_kernel): per aggregate the poses its
-// block rows touch (hal_pose, stride HMAX, ascending; hal_aloc = local index of each one's aggregate), the aggregates those poses
-// belong to (hagg_id, stride JMAX), the local index of every fixed-width adjacency entry's column (ell_loc, parallel to ell) and of
-// every pose inside its own aggregate's list (own_loc).  count -> nH / nJ per aggregate and their maxima in counters[CNT_MAXH / CNT_MAXJ].
-size_t halo_lds_bytes(int Pf, int nc);
-void launch_halo_count(const int2* ell, int Pf, int M, int agg, int nc, int* nH, int* nJ, int* counters, hipStream_t s);
-void launch_halo_fill(const int2* ell, int Pf, int M, int agg, int nc, int HMAX, int JMAX, int* hal_pose, int* hal_aloc, int* hagg_id, int* ell_loc, int* own_loc, hipStream_t s);
 void launch_gather_int(const int* idx, const int* src, size_t n, int* dst, hipStream_t s);     // dst[i] = src[idx[i]]
 // pattern entries: Pf diagonal seeds first, then every pair (a < c) of free-pose edges of every free landmark in
 // product-id order: key = row << 32 | column, value = (edge a + 1) << 32 | (edge c + 1), 0 for a seed

@@ -407,7 +407,7 @@ private:
 	static constexpr size_t kPrefetch = 12;      // objects ahead of the one being read in the pointer-chasing loops
 	static unsigned hostThreads(size_t items)
 	{
-		static const size_t grain = std::getenv("CUBA_HIP_HOST_GRAIN") ? (size_t)std::max(1, std::atoi(std::getenv("CUBA_HIP_HOST_GRAIN"))) : 20000;   // A/B knob: items per thread
+		static const size_t grain = 20000;   // items per host thread
 		return (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)cubahip::HostPool::instance().maxThreads(), items / grain + 1));
 	}
 

@@ -86,41 +86,37 @@ void cuba_hip_host_free(void* p);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Tunables: "pcg_tol" (relative preconditioned-residual tolerance, default 1e-7), "pcg_max_iter"
-   (default 4*6*Pf capped at 32768), "pcg_check_every" (PCG iterations between host looks at the device stop flag; default 0 =
-   batches sized from the iteration growth of the run), "pcg_aggregate" (poses per coarse aggregate of the two-level
-   preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses and max(16, Pf/min(180, max(115, Pf/32))) above with linear coarse functions, max(12, Pf/160) without; 0 = block-Jacobi
-   only), "coarse_linear" (default 1: constant + linear-in-pose-index coarse functions per aggregate, 12 unknowns each;
-   0 = constant only, 6 unknowns), "coarse_overlap" (default 1: the coarse matrix of a trial is assembled and inverted on a second,
-   low-priority stream under that trial's PCG and serves from the next trial on -- only the first solve of a run inverts in line;
-   0 = invert in line, on the policy of the next two options), "coarse_first_reuse" (default 1: the first solve of an LM run starts with the
-   inverse the first solve of the PREVIOUS run on this structure had -- same damping regime -- while its own inversion runs on the second stream, so
-   that only the very first run on a structure inverts in line; 0 = every run inverts in line for its first solve), "coarse_overlap_period" (trials between two overlapped inversions;
-   -1 = automatic: every trial up to a coarse dimension of 512, every second up to 1024, every third beyond), "coarse_max_age" (in-line mode; default 3: the coarse
-   inverse of the two-level preconditioner is reused for up to three further solves of a run; 0 = rebuild it for every
-   solve), "coarse_refresh_growth" (in-line mode; default 1.6: rebuild early once a solve needs that many times the iterations of
-   the solve the inverse was built for), "spin_wait" (default 1: the host learns that a batch of work has finished from a ticket
-   the device writes into mapped host memory, not from hipStreamSynchronize), "precond_fp32" (fp64 library only, default 1: the explicit coarse inverse of the two-level
-   preconditioner is STORED in fp32 -- symmetrised, applied with fp64 accumulation; it only has to be a fixed SPD operator, so neither parity
-   nor bit-reproducibility change, while the bytes and load instructions of the kernel that applies it halve; 0 = fp64 storage), "pcg_single_kernel" (default 0; 1 = one launch per PCG iteration -- Chronopoulos-Gear recurrences, a workgroup
-   per coarse aggregate that recomputes residual and preconditioned residual on the aggregate's halo -- wherever the two-level preconditioner is on and
-   the configuration fits the kernel (block rows within the fixed-width part, halo <= 170 poses, coarse dimension within the instantiated widths);
-   measured slower than the two-kernel iteration (SpMV, then update + restriction + preconditioner) at every BASELINE shape: 21 vs 16 us at KITTI-00,
-   DESIGN.md section 4), "fused_tail" (default 1: optimize() runs back-substitution, update and evaluation of a trial
-   as ONE pass over the edges -- two launches between a converged solve and the LM decision instead of four; 0 = the four-launch tail), "speculate_tail" (default 0; 1 = optimize()
-   enqueues back-substitution, update and evaluation behind the first batch of PCG iterations and undoes them if the batch
-   was too short -- measured slightly slower), "pcg_graph" (default 1: replay the PCG iterations as hipGraphs of 4 ... 256 iterations), "pcg_exact_batch_graphs" (default 1: a batch length that is asked for a second time on one structure gets a graph of exactly that length -- one hand-over per batch instead of one per power of two; 0 = powers of two only), "pcg_repeat_prediction" (default 1: a run that has repeated the previous run on the same structure solve for solve so far sizes its next batch of iterations from that run instead of extrapolating), "schur_atomic"
-   (1 = first-generation Schur kernel with fp64 atomics instead of the atomic-free default), "mixed_precision" (fp64 library
-   only, default 0; 1 = the per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in
-   fp32, every sum over edges, the reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29,
-   applied where it is second-order for the objective), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history), "pose_reorder" (default 1: when most blocks of the reduced matrix lie far off its diagonal in
-   the caller's pose numbering -- arbitrary vertex ids --, the free poses are renumbered internally along the trajectory found by a
-   strongest-neighbour walk over the co-visibility counts, which the aggregates of the two-level preconditioner need; every host-pointer
+/* Options (16).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
+   "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
+   "pcg_aggregate" (poses per coarse aggregate of the two-level preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses,
+   max(16, Pf/min(180, max(115, Pf/32))) above; 0 = block-Jacobi only), "coarse_linear" (default 1: constant + linear-in-pose-index
+   coarse functions per aggregate, 12 unknowns each; 0 = constant only, 6 unknowns), "precond_fp32" (fp64 library only, default 1: the
+   explicit coarse inverse is STORED in fp32 -- symmetrised, applied with fp64 accumulation; a solve whose PCG breaks down with it is
+   repeated with fp64 storage, which the handle then keeps; 0 = fp64 storage), "mixed_precision" (fp64 library only, default 0; 1 =
+   per-edge linearisation records and the per-edge arithmetic of the pose / block Schur passes in fp32, every sum over edges, the
+   reduced system and the PCG in fp64 -- the reference's USE_FLOAT32 idea, src/scalar.h:25-29, applied where it is second-order for
+   the objective).
+   The coarse matrix of a trial is assembled and inverted on a second, low-priority stream under that trial's PCG and serves from a
+   later trial on (every trial up to a coarse dimension of 512, every second up to 1024, every third beyond); only the first solve
+   on a structure inverts in line.
+   Run-to-run heuristics (exact when a run repeats the previous one, harmless otherwise; bench.py prices them): "coarse_first_reuse"
+   (default 1: the first solve of an LM run starts with the inverse the first solve of the PREVIOUS run on this structure had -- same
+   damping regime -- while its own inversion runs on the second stream), "pcg_repeat_prediction" (default 1: a run that has repeated
+   the previous run solve for solve so far sizes its next batch of iterations from that run instead of extrapolating),
+   "pcg_exact_batch_graphs" (default 1: a batch length that is asked for a second time on one structure gets a hipGraph of exactly
+   that length -- one hand-over per batch instead of one per power of two).
+   Execution: "pcg_graph" (default 1: PCG iterations are replayed as hipGraphs of 4 ... 256 iterations; 0 = eager launches),
+   "fused_tail" (default 1: cuba_hip_optimize runs back-substitution, update and evaluation of a trial as ONE pass over the edges;
+   0 = the four-launch tail, which a landmark partition and "profile" use in any case), "device_setup" (default 1: the edge sort of
+   cuba_hip_set_graph and the whole symbolic analysis of cuba_hip_build_structure run on the GPU; 0 = the host pipeline, the
+   independent cross-check of the tests), "pose_reorder" (default 1: when most blocks of the reduced matrix lie far off its diagonal
+   in the caller's pose numbering -- arbitrary vertex ids --, the free poses are renumbered internally along the trajectory found by
+   a strongest-neighbour walk over the co-visibility counts, which the aggregates of the preconditioner need; every host-pointer
    entry point keeps the caller's numbering, only cuba_hip_device_pointer / cuba_hip_reduction_buffer expose the internal one),
-   "device_setup" (default 1: the edge sort of cuba_hip_set_graph and
-   the whole symbolic analysis of cuba_hip_build_structure run on the GPU; 0 = the host pipeline, which landmark-partitioned
-   handles and "schur_atomic" use in any case), "profile" (0/1: per-stage
-   synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47). */
+   "profile" (0/1: per-stage synchronising wall-clock like the reference's get_time_point(), src/cuda_bundle_adjustment.cpp:43-47).
+   Variants that were built, measured slower and removed again (first-generation Schur kernel with fp64 atomics, single-launch
+   PCG iteration, speculative trial tail, in-line coarse refresh policy, CU-masked side stream, forcing term on the PCG tolerance)
+   are documented with their numbers in DESIGN.md section 4 and profiles/. */
 int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value);
 
 /* ---- graph upload ---------------------------------------------------------------------------- */
@@ -268,7 +264,7 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
 /* Measurement hook for bench.py: average device milliseconds per launch, taken with HIP events on the
    handle's stream over `reps` back-to-back launches, of
      [0] residual_chi2  [1] linearize+Schur  [2] pcg_spmv  [3] pcg_update (+restrict)  [4] back_substitute
-     [5] pcg_single (the single-kernel PCG iteration, where option pcg_single_kernel is in effect; 0 otherwise)
+     [5] reserved (0)
      [6] coarse_setup (assemble + invert the coarse matrix, once per solve; 0 if disabled).
    Clobbers the increments and the reduced system (not the estimates). */
 enum { CUBA_HIP_TIMED_KERNELS = 7 };

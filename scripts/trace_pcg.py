@@ -20,16 +20,19 @@ from cuba_amd.synth import synth_named  # noqa: E402
 shape = sys.argv[1] if len(sys.argv) > 1 else "kitti00"
 fp = flatten(synth_named(shape))
 rk = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
-h = capi.HipSolver(fp, rk, pcg_single_kernel=float(os.environ.get("CUBA_TRACE_CG1", "1")))
+h = capi.HipSolver(fp, rk)
 h.build_structure()
 h.optimize(3)
 lib = capi.load_library("f64")
 buf = np.zeros((3, 8192, 8), dtype=np.uint64)
-rc = lib.cuba_hip_debug_read_trace(buf.ctypes.data_as(C.c_void_p))
+rc = lib.cuba_hip_debug_read_trace(buf.ctypes.data_as(C.c_void_p))          # the PCG translation unit's stamps (kernels 0, 1)
 assert rc == 0, rc
+gj = np.zeros((3, 8192, 8), dtype=np.uint64)
+rc = lib.cuba_hip_debug_read_trace_coarse(gj.ctypes.data_as(C.c_void_p))    # the coarse translation unit's (kernel 2)
+assert rc == 0, rc
+buf[2] = gj[2]
 for kid, name, stages in ((0, "pcg_spmv", ["entry", "indices+scalars", "operands", "fold+barrier", "end"]),
-                          ((1, "pcg1 (single-kernel iteration)", ["entry", "all loads landed", "restricted vectors + barrier", "coarse correction", "halo r, u + 2 barriers", "SpMV + barrier", "end"])
-                           if os.environ.get("CUBA_TRACE_CG1", "1") != "0" else (1, "pcg2_fused", ["entry", "loads landed", "restricted sums", "barrier 1", "barrier yc", "end"])),
+                          (1, "pcg2_fused", ["entry", "loads landed", "restricted sums", "barrier 1", "barrier yc", "end"]),
                           (2, "dense_gj_step (last launch that has a look-ahead workgroup... the last step has none)", ["entry", "tile loads", "tiles done", "end (look-ahead chain in one workgroup)"])):
     t = buf[kid].astype(np.int64)
     if kid == 2:

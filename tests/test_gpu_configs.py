@@ -371,7 +371,7 @@ def test_duplicate_observations_of_one_pose(solvers):
     md = o.max_diagonal(); lam = 1e-5 * md
     H, b = dense_normal_equations(o, fp, lam)
     x = np.linalg.solve(H, b)
-    for opts in (dict(), dict(schur_atomic=1)):
+    for opts in (dict(), dict(device_setup=0)):
         h = HipSolver(fp, RK_HUBER, pcg_tol=1e-12, **opts)
         assert h.max_diagonal() == pytest.approx(md, rel=1e-12)
         h.set_lambda(lam); assert h.solve()

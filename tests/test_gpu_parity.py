@@ -330,8 +330,9 @@ def test_fused_trial_tail_equals_the_four_launch_tail(solvers, small_graph, case
 
 
 def test_schur_paths_agree_and_default_is_reproducible(solvers, small_graph):
-    """The atomic-free destination-major Schur assembly (default) against the first-generation atomic kernel,
-    and bitwise reproducibility of the default path."""
+    """The atomic-free destination-major Schur assembly against the oracle's reduced system, with the device-built and the
+    host-built structure, and its bitwise reproducibility.  (The first-generation kernel with fp64 atomics -- 3.25 ms against
+    0.1 ms, profiles/r01c_* -- left the library in round 4.)"""
     HipSolver, OracleSolver = solvers
     g = with_fixed(small_graph, fixed_pose_rows=[7], fixed_lm_rows=[5, 50, 500])
     fp = flatten(g)
@@ -340,7 +341,7 @@ def test_schur_paths_agree_and_default_is_reproducible(solvers, small_graph):
     lam = 1e-5 * md; o.set_lambda(lam); o.schur()
     _, _, vo = o.hsc()
     outs = []
-    for opts in (dict(), dict(), dict(schur_atomic=1)):
+    for opts in (dict(), dict(), dict(device_setup=0)):
         h = HipSolver(fp, RK_HUBER, **opts)
         assert h.max_diagonal() == pytest.approx(md, rel=1e-12)
         h.set_lambda(lam); h.schur()
@@ -349,7 +350,8 @@ def test_schur_paths_agree_and_default_is_reproducible(solvers, small_graph):
         assert rel(v[~diag], vo[~diag]) < ASM_TOL
         assert rel(h.array("bsc"), o.array("bsc")) < ASM_TOL and rel(h.array("bp"), o.array("bp")) < ASM_TOL
         outs.append((v.copy(), h.array("bsc"), h.array("lm_sys")))
-    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))       # default path: bit-for-bit repeatable
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))       # bit-for-bit repeatable
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[2]))       # ... and independent of which pipeline built the lists
     # no atomics anywhere on the default path (Schur passes, CG dot products, chi2 / scale reductions all sum in a
     # fixed order): whole LM runs are reproducible bit for bit, estimates included
     h1, h2 = HipSolver(fp, RK_HUBER), HipSolver(fp, RK_HUBER)
@@ -378,12 +380,12 @@ def test_preconditioner_modes_agree(solvers, small_fp):
 def test_coarse_inverse_storage_precision(solvers):
     """Option precond_fp32 (default 1 in the fp64 library): the explicit coarse inverse of the two-level preconditioner is stored in
     fp32 and applied with fp64 accumulation.  A preconditioner only has to be a fixed SPD operator: same solutions to the solver
-    tolerance, iteration counts within a few per cent of the fp64-stored inverse, runs still bit-reproducible; every refresh path
-    (in line, overlapped + staged copy, every coarse-dimension class of the kernel) is exercised."""
+    tolerance, iteration counts within a few per cent of the fp64-stored inverse, runs still bit-reproducible; the refresh path
+    (first inversion in line, then overlapped + staged copy) and every coarse-dimension class of the kernel are exercised."""
     HipSolver, OracleSolver = solvers
     fp = flatten(synth_ba(200, 8000, 32000, seed=13))
     ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
-    for opts in (dict(), dict(coarse_overlap=0), dict(pcg_aggregate=2), dict(pcg_aggregate=2, coarse_linear=0), dict(pcg_aggregate=3, coarse_linear=0),
+    for opts in (dict(), dict(pcg_aggregate=2), dict(pcg_aggregate=2, coarse_linear=0), dict(pcg_aggregate=3, coarse_linear=0),
                  dict(pcg_aggregate=1)):
         a = HipSolver(fp, RK_HUBER, pcg_tol=1e-10, **opts); ra = a.optimize(6)["chi2"]
         b = HipSolver(fp, RK_HUBER, pcg_tol=1e-10, precond_fp32=0, **opts); rb = b.optimize(6)["chi2"]
@@ -426,61 +428,24 @@ def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small
     assert rel(h.optimize(4)["chi2"], moved) < 1e-9
 
 
-def test_single_kernel_pcg_iteration_agrees(solvers):
-    """Option pcg_single_kernel = 1 (round 3, off by default because it measured slower): one launch per PCG iteration --
-    Chronopoulos-Gear recurrences, one workgroup per coarse aggregate that redoes residual and preconditioner on the aggregate's halo.
-    Same preconditioner, same stop quantity: identical iteration counts, solutions equal to the solver tolerance, and the LM
-    trajectory follows the oracle; aggregates of 2 / 5 / 16 poses exercise several halo sizes and coarse-row batch counts."""
-    HipSolver, OracleSolver = solvers
-    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
-    o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
-    lam = 1e-7 * o.max_diagonal()
-    o.set_lambda(lam); assert o.solve()
-    for agg in (16, 5, 2):
-        a = HipSolver(fp, RK_HUBER, pcg_aggregate=agg, pcg_tol=1e-9, pcg_single_kernel=1)
-        b = HipSolver(fp, RK_HUBER, pcg_aggregate=agg, pcg_tol=1e-9)
-        for h in (a, b):
-            h.set_lambda(lam); assert h.solve()
-            assert rel(h.array("xp"), o.array("xp")) < 1e-6 and rel(h.array("xl"), o.array("xl")) < 1e-6
-        ia, ib = a.pcg_history()[0][-1], b.pcg_history()[0][-1]
-        assert abs(int(ia) - int(ib)) <= 2, (agg, ia, ib)
-        assert rel(a.array("xp"), b.array("xp")) < 1e-7
-    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
-    h = HipSolver(fp, RK_HUBER, pcg_single_kernel=1)
-    got = h.optimize(6)["chi2"]
-    assert rel(got, ref) < CHI2_TOL and h.pcg_history()[1] == 0
-    assert np.array_equal(HipSolver(fp, RK_HUBER, pcg_single_kernel=1).optimize(6)["chi2"], got)
-
-
-def test_coarse_refresh_modes(solvers):
-    """The coarse inverse of trial k is built on a second stream for a later trial (default: under every trial for a coarse dimension
-    up to 512, under every second up to 1024, every third beyond); coarse_overlap=0 inverts in line and reuses the inverse for up to coarse_max_age solves.
-    Every mode solves the same problems, deterministically."""
+def test_coarse_refresh_schedule(solvers):
+    """The coarse inverse of trial k is built on a second stream for a later trial (under every trial for a coarse dimension up to
+    512, under every second up to 1024, every third beyond); only the first solve on a structure inverts in line.  Deterministic,
+    and the eager-launch path (pcg_graph = 0) solves the same problems."""
     HipSolver, OracleSolver = solvers
     fp = flatten(synth_ba(200, 8000, 32000, seed=13))
     ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
-    h = HipSolver(fp, RK_HUBER, speculate_tail=1, spin_wait=0)      # the off-by-default paths ride along
+    h = HipSolver(fp, RK_HUBER)
     a = h.optimize(6)["chi2"]
     assert rel(a, ref) < CHI2_TOL
-    assert h.counters()["coarse_refreshes"] >= 6          # one in line + one under every trial
-    h2 = HipSolver(fp, RK_HUBER, speculate_tail=1)
-    assert np.array_equal(h2.optimize(6)["chi2"], a)          # still deterministic
-    runs = {}
-    for name, opts in (("period 3", dict(coarse_overlap_period=3)), ("in line", dict(coarse_overlap=0)),
-                       ("in line, every solve", dict(coarse_overlap=0, coarse_max_age=0))):
-        g1 = HipSolver(fp, RK_HUBER, **opts); c1 = g1.optimize(6)["chi2"]
-        g2 = HipSolver(fp, RK_HUBER, **opts); c2 = g2.optimize(6)["chi2"]
-        assert rel(c1, ref) < CHI2_TOL, name
-        assert np.array_equal(c1, c2), name
-        runs[name] = g1.counters()["coarse_refreshes"]
-    assert runs["period 3"] < h.counters()["coarse_refreshes"] and runs["in line"] < runs["in line, every solve"], runs
-    # switching modes on a live handle (a pending inversion of the other mode must not leak into the next run)
-    h.set_option("coarse_overlap", 0)
-    b = h.optimize(3)["chi2"]                                  # continues from the result of the first run
+    assert h.counters()["coarse_refreshes"] >= 6 and h.counter("coarse_inline_inversions") == 1     # one in line + one under every trial
+    h2 = HipSolver(fp, RK_HUBER)
+    assert np.array_equal(h2.optimize(6)["chi2"], a)          # deterministic
+    e = HipSolver(fp, RK_HUBER, pcg_graph=0)
+    assert rel(e.optimize(6)["chi2"], ref) < CHI2_TOL
+    b = h.optimize(3)["chi2"]                                  # a second run on the structure continues from the first one's result:
     assert np.isfinite(b).all() and b[0] <= a[-1] * (1 + 1e-12) and np.all(np.diff(b) <= 0)
-    h.set_option("coarse_overlap", 1)
-    c = h.optimize(2)["chi2"]
-    assert np.isfinite(c).all() and c[0] <= b[-1] * (1 + 1e-12)
+    assert h.counter("coarse_inline_inversions") == 1        # ... its first solve started with the carried-over inverse
 
 
 def test_golden_trajectories_on_gpu(solvers):
