@@ -175,7 +175,9 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 // returns whichever of the two buffers holds the inverse
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
-void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s);
+// what the last node of an iteration graph does, as a launch: advance the iteration offset by n, run the stop test on the residual the
+// chunk left (tol2 >= 0), report to the host
+void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s, Scalar tol2 = Scalar(-1));
 void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s);   // n x n inverse -> sys.acinv32 layout
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 

@@ -942,9 +942,9 @@ void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
 	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, 0, 1, Scalar(-1));
 }
 
-void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s)
+void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s, Scalar tol2)
 {
-	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, n, 1, Scalar(-1));
+	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, n, 1, tol2);
 }
 
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)
