@@ -70,6 +70,8 @@ def load_library(precision="f64"):
         "cuba_hip_set_stream": [H, C.c_void_p],
         "cuba_hip_set_option": [H, C.c_char_p, C.c_double],
         "cuba_hip_set_graph": [H, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _ip, _u8p, _dp, _dp],
+        "cuba_hip_set_graph_begin": [H, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _ip, _u8p, _dp, _dp],
+        "cuba_hip_set_graph_end": [H],
         "cuba_hip_set_robust_kernel": [H, C.c_int, C.c_int, C.c_double],
         "cuba_hip_build_structure": [H],
         "cuba_hip_compute_errors": [H, _dp],
@@ -200,7 +202,9 @@ class HipSolver:
         """promise about the NEXT set_graph call only (cuba_hip_hint_unchanged)"""
         self._ck(self.lib.cuba_hip_hint_unchanged(self.h, int(bool(same_edges)), int(bool(same_values))))
 
-    def set_graph(self, fp):
+    def set_graph(self, fp, two_step=False):
+        """two_step: cuba_hip_set_graph_begin + cuba_hip_build_structure + cuba_hip_set_graph_end (what the C++ layer does: the
+        measurements cross PCIe on a second stream while the structure analysis runs)"""
         self.fp = fp
         q, t, cam, Xw = (np.ascontiguousarray(a, dtype=np.float64) for a in (fp.q, fp.t, fp.cam, fp.Xw))
         eP = np.ascontiguousarray(fp.eP, dtype=np.int32)
@@ -208,9 +212,14 @@ class HipSolver:
         eD = np.ascontiguousarray(fp.eDim, dtype=np.uint8)
         meas = np.ascontiguousarray(fp.meas, dtype=np.float64)
         om = np.ascontiguousarray(fp.omega, dtype=np.float64)
-        self._ck(self.lib.cuba_hip_set_graph(self.h, fp.Pt, fp.Pf, fp.Lt, fp.Lf, _d(q), _d(t), _d(cam), _d(Xw), len(eP),
-                                             eP.ctypes.data_as(_ip), eL.ctypes.data_as(_ip), eD.ctypes.data_as(_u8p),
-                                             _d(meas), _d(om)))
+        fn = self.lib.cuba_hip_set_graph_begin if two_step else self.lib.cuba_hip_set_graph
+        self._ck(fn(self.h, fp.Pt, fp.Pf, fp.Lt, fp.Lf, _d(q), _d(t), _d(cam), _d(Xw), len(eP),
+                    eP.ctypes.data_as(_ip), eL.ctypes.data_as(_ip), eD.ctypes.data_as(_u8p), _d(meas), _d(om)))
+        if two_step == "begin_only":                                 # (test hook: the arrays are kept alive by the caller of this method)
+            self._pending_upload = (meas, om)
+        elif two_step:
+            self.build_structure()
+            self._ck(self.lib.cuba_hip_set_graph_end(self.h))        # (meas / om stay referenced until here)
 
     # ---- stages --------------------------------------------------------------------------------
     def build_structure(self): self._ck(self.lib.cuba_hip_build_structure(self.h))

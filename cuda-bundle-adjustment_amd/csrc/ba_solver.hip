@@ -382,6 +382,7 @@ struct cuba_hip_solver
 		dropPcgGraph();
 		if (gjStream) { (void)hipStreamSynchronize(gjStream); (void)hipStreamDestroy(gjStream); (void)hipEventDestroy(evSetup); (void)hipEventDestroy(evAssembled); (void)hipEventDestroy(evInverse); (void)hipEventDestroy(evFirstInv); }
 		if (captureStream) (void)hipStreamDestroy(captureStream);
+		if (upStream) { (void)hipStreamSynchronize(upStream); (void)hipStreamDestroy(upStream); (void)hipEventDestroy(evValues); }
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
 	}
@@ -496,9 +497,23 @@ struct cuba_hip_solver
 	};
 
 	// ---------------------------------------------------------------------------------------------
-	void setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,
-		int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega)
+	// deferValues (cuba_hip_set_graph_begin): the caller keeps meas / omega valid until cuba_hip_set_graph_end, so their 32 bytes per
+	// edge may still be crossing PCIe -- on a second stream -- while the structure analysis (which needs the index arrays only) runs
+	hipStream_t upStream = nullptr; hipEvent_t evValues = nullptr;
+	bool valuesPending = false, deferredUpload = false;
+	void finishValues()
 	{
+		if (!valuesPending) return;
+		valuesPending = false;
+		HIP_TRY(hipStreamWaitEvent(stream, evValues, 0));
+		topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
+			nullptr, nullptr, d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
+	}
+	void setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,
+		int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega, bool deferValues = false)
+	{
+		if (valuesPending) { HIP_TRY(hipStreamSynchronize(upStream)); valuesPending = false; }      // (a begin without its end: the old upload must not outlive its arrays' replacement)
+		deferredUpload = false;
 		if (Pt_ < 0 || Lt_ < 0 || E_ < 0 || Pf_ < 0 || Pf_ > Pt_ || Lf_ < 0 || Lf_ > Lt_) throw ArgError{ "bad vertex counts" };
 		if (Pt_ >= STEREO_BIT) throw ArgError{ "too many poses" };
 		// the per-edge linearisation record carries 2*landmark+stereo in a Scalar slot: exact in fp32 only below 2^24
@@ -565,15 +580,19 @@ struct cuba_hip_solver
 				HIP_TRY(hipMemcpyAsync(d_rawEp.data(), d_rawEpCaller.data(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, stream));
 			}
 			const bool keepValues = promisedValues && reuseSort && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
-			if (!keepValues) { d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream); }
+			const bool defer = deferValues && !keepValues && E > 0;
+			deferredUpload = defer;          // (enqueued LAST, below: the copy engine serves its queue in order, and the small uploads of this call must not wait behind 18 MB)
+			if (defer) { d_rawMeas.resize((size_t)3 * E); d_rawOmega.resize(E); }
+			else if (!keepValues) { d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream); }
 			lap("set_graph: raw uploads enqueued");
-			if (!reuseSort) runDeviceEdgeSort();
-			else if (!keepValues)
+			if (!reuseSort) runDeviceEdgeSort(!defer);
+			else if (!keepValues && !defer)
 			{
 				d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
 				topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
 					nullptr, nullptr, d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
 			}
+			if (defer) { d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E); valuesPending = true; }
 			sameTopology = sameCounts && reuseSort;
 			devTopology = true; hostTopoValid = false;
 			if (reorderActive) { stageState(); permuteStateRows(state, camv); }          // the caller's rows -> the internal pose order kept from the last call
@@ -666,6 +685,16 @@ struct cuba_hip_solver
 		}
 		d_parts.resize(8192 + (size_t)E + 64); d_maxdiag.resize(64); d_fail.resize(1); d_iters.resize(1); d_kbase.resize(1); d_done.resize(1); d_ticket.resize(1);
 		d_fail.zero(stream); d_iters.zero(stream); d_kbase.zero(stream); d_done.zero(stream); d_ticket.zero(stream);
+		if (deferredUpload)
+		{
+			if (!upStream) { HIP_TRY(hipStreamCreateWithFlags(&upStream, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&evValues, hipEventDisableTiming)); }
+			// (the raw buffers may still be read by a gather of the previous call on the work stream)
+			HIP_TRY(hipEventRecord(evValues, stream)); HIP_TRY(hipStreamWaitEvent(upStream, evValues, 0));
+			HIP_TRY(hipMemcpyAsync(d_rawMeas.data(), meas, sizeof(double) * 3 * (size_t)E, hipMemcpyHostToDevice, upStream));
+			HIP_TRY(hipMemcpyAsync(d_rawOmega.data(), omega, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, upStream));
+			HIP_TRY(hipEventRecord(evValues, upStream));
+			deferredUpload = false;
+		}
 		sync(); expectedTicket = 0; ((volatile int*)((char*)h_pinned + 1024))[3] = 0;
 		sync();   // host staging vectors go out of scope
 
@@ -1229,8 +1258,9 @@ struct cuba_hip_solver
 	}
 
 	// keys (landmark, pose) of the raw device edge arrays -> sort permutation, sorted edge arrays, landmark pointers
-	void runDeviceEdgeSort()
+	void runDeviceEdgeSort(bool withValues = true)
 	{
+		if (withValues && valuesPending) { valuesPending = false; HIP_TRY(hipStreamWaitEvent(stream, evValues, 0)); }     // (a re-sort under a new pose order: the values must have landed)
 		d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
 		d_k64a.resize(E); d_k64b.resize(E); d_v32a.resize(E); d_perm.resize(E); d_counters.resize(topo::CNT_COUNT);
 		d_epose.resize(E); d_elm.resize(E); d_lmptr.resize((size_t)Lt + 1);
@@ -1240,7 +1270,7 @@ struct cuba_hip_solver
 		d_topoTemp.resize(std::max(tb, d_topoTemp.size()));
 		HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), d_topoTemp.size(), d_k64a.data(), d_k64b.data(), d_v32a.data(), d_perm.data(), E, 32 + bitsFor(Lt), stream));
 		topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
-			d_epose.data(), d_elm.data(), d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
+			d_epose.data(), d_elm.data(), withValues ? d_mu.data() : nullptr, d_mv.data(), d_mr.data(), d_w.data(), stream);
 		topo::launch_segment_ptr(d_elm.data(), E, Lt, d_lmptr.data(), stream);
 	}
 
@@ -1582,7 +1612,7 @@ struct cuba_hip_solver
 		hostPatternValid = true;
 	}
 
-	void need() { if (!haveGraph) throw StateError{ "set_graph must be called first" }; buildStructure(); g.rk[0] = rk[0]; g.rk[1] = rk[1]; st.mixed = mixedPrecision ? 1 : 0; }
+	void need() { if (!haveGraph) throw StateError{ "set_graph must be called first" }; buildStructure(); finishValues(); g.rk[0] = rk[0]; g.rk[1] = rk[1]; st.mixed = mixedPrecision ? 1 : 0; }
 
 	double readSlots(int which)
 	{
@@ -2254,6 +2284,22 @@ int cuba_hip_set_graph(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf, const
 	const double* meas, const double* omega)
 {
 	return guarded(s, [&] { s->setGraph(Pt, Pf, Lt, Lf, q, t, cam, Xw, E, edge_pose, edge_landmark, edge_dim, meas, omega); });
+}
+
+int cuba_hip_set_graph_begin(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf, const double* q, const double* t, const double* cam,
+	const double* Xw, int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
+	const double* meas, const double* omega)
+{
+	return guarded(s, [&] { s->setGraph(Pt, Pf, Lt, Lf, q, t, cam, Xw, E, edge_pose, edge_landmark, edge_dim, meas, omega, true); });
+}
+
+int cuba_hip_set_graph_end(cuba_hip_solver* s)
+{
+	return guarded(s, [&] {
+		if (!s->haveGraph) throw StateError{ "set_graph_begin must be called first" };
+		if (s->upStream) HIP_TRY(hipStreamSynchronize(s->upStream));      // the caller's meas / omega are free again
+		s->finishValues();
+	});
 }
 
 int cuba_hip_set_robust_kernel(cuba_hip_solver* s, int edge_type, int kind, double delta)

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(T) void gather_edges_kernel(const uint32_t* perm, c
 	const size_t e = perm[i];
 	const bool stereo = dim[e] == 3;
 	if (e_pose) { e_pose[i] = ep[e] | (stereo ? STEREO_BIT : 0); e_lm[i] = el[e]; }
+	if (!mu) return;                   // (index arrays only: the values are still on their way from the host)
 	mu[i] = (Scalar)meas[3 * e]; mv[i] = (Scalar)meas[3 * e + 1];
 	mr[i] = stereo ? (Scalar)meas[3 * e + 2] : Scalar(0);
 	w[i] = (Scalar)omega[e];

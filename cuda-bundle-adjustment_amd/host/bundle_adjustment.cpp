@@ -332,10 +332,14 @@ public:
 			// what initialize() learned while it re-read the graph: the index arrays / the edge values are those of the last upload
 			const bool sameEdges = uploadedOnce_ && !edgesChangedSinceUpload_;
 			check(cuba_hip_hint_unchanged(solver_, sameEdges ? 1 : 0, sameEdges && !valuesChangedSinceUpload_ ? 1 : 0), "cuba_hip_hint_unchanged");
-			check(cuba_hip_set_graph(solver_, static_cast<int>(activePoses_.size()), numFreePoses_,
+			// two-step upload: the measurements / information (32 of the 41 bytes per edge; page-locked staging arrays of this object,
+			// untouched until the next initialize()) cross PCIe on a second stream while the structure analysis runs on the index arrays
+			check(cuba_hip_set_graph_begin(solver_, static_cast<int>(activePoses_.size()), numFreePoses_,
 				static_cast<int>(activeLandmarks_.size()), numFreeLandmarks_, q_.data(), t_.data(), cam_.data(), Xw_.data(),
 				static_cast<int>(activeEdges_.size()), edgePose_.data(), edgeLandmark_.data(), edgeDim_.data(), meas_.data(), omega_.data()),
-				"cuba_hip_set_graph");
+				"cuba_hip_set_graph_begin");
+			check(cuba_hip_build_structure(solver_), "cuba_hip_build_structure");
+			check(cuba_hip_set_graph_end(solver_), "cuba_hip_set_graph_end");
 			graphDirty_ = false;
 			uploadedOnce_ = true; edgesChangedSinceUpload_ = valuesChangedSinceUpload_ = false;       // from here on the device holds exactly these edges and values
 		}

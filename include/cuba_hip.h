@@ -132,6 +132,18 @@ int cuba_hip_set_graph(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
 	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
 	const double* meas, const double* omega);
 
+/* The same upload in two steps, for a caller whose meas / omega arrays stay valid (and unchanged) until cuba_hip_set_graph_end: _begin
+   returns once every other argument has been consumed, while the 32 bytes per edge of measurements and information may still be
+   crossing PCIe on a second stream; the caller then typically calls cuba_hip_build_structure -- the symbolic analysis needs the index
+   arrays only, so the transfer hides under it (0.7 ms of a 1.2 ms analysis at KITTI-00 size) -- and cuba_hip_set_graph_end, which
+   waits for the transfer.  Any entry point that needs the values finishes the transfer itself; page-locked arrays
+   (cuba_hip_host_alloc) are what makes the transfer asynchronous.  A cuba_hip_hint_unchanged promise covers _begin like set_graph. */
+int cuba_hip_set_graph_begin(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
+	const double* q, const double* t, const double* cam, const double* Xw,
+	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
+	const double* meas, const double* omega);
+int cuba_hip_set_graph_end(cuba_hip_solver* s);
+
 /* A promise about the NEXT cuba_hip_set_graph call only (it is consumed by that call, successful or not):
    same_edges  != 0: edge_pose / edge_landmark / edge_dim and all five counts are identical to those of the previous successful call
                      (the library then skips its own comparison of the index arrays);

@@ -136,6 +136,27 @@ def test_push_pop_and_set_state(solvers, small_fp):
     assert np.array_equal(h0.optimize(4)["chi2"], a)         # without the reuse every run is a function of its start alone
 
 
+def test_two_step_set_graph_equals_the_one_call_form(solvers, small_fp):
+    """cuba_hip_set_graph_begin / _end (values on a second stream while the structure is analysed) leaves exactly the state of
+    cuba_hip_set_graph: bit-identical LM runs, also after a re-upload with changed measurements and through the shuffled-id
+    (internal renumbering re-sorts the edges) and host-pipeline paths."""
+    from test_gpu_configs import shuffled_pose_ids
+    HipSolver, _ = solvers
+    for fp, opts in ((small_fp, {}), (small_fp, dict(device_setup=0)), (flatten(shuffled_pose_ids(synth_ba(200, 8000, 32000, seed=13), seed=2)), {})):
+        a = HipSolver(fp, RK_HUBER, **opts); ra = a.optimize(4)["chi2"]
+        b = HipSolver(None, RK_HUBER, **opts); b.set_graph(fp, two_step=True); rb = b.optimize(4)["chi2"]
+        assert np.array_equal(ra, rb), opts
+        assert all(np.array_equal(x, y) for x, y in zip(a.state(), b.state()))
+        fp2 = copy.copy(fp); fp2.meas = fp.meas + 0.25
+        a.set_graph(fp2); b.set_graph(fp2, two_step=True)
+        assert np.array_equal(a.optimize(3)["chi2"], b.optimize(3)["chi2"]), opts
+        assert np.array_equal(a.chi_squares(), b.chi_squares())
+        # a begin without its end: the next call that needs the values finishes the transfer itself
+        c = HipSolver(None, RK_HUBER, **opts)
+        c.set_graph(fp, two_step="begin_only")
+        assert c.compute_errors() == HipSolver(fp, RK_HUBER, **opts).compute_errors()
+
+
 def test_snapshot_slots_and_named_counters(solvers, small_fp):
     """cuba_hip_snapshot_state_slot / _restore_state_slot: several device-side copies of the estimates (bench.py's non-replay
     protocol); slot 0 is the slot-less pair; an absent or out-of-range slot is a reported error.  cuba_hip_get_counter: the
