@@ -89,11 +89,13 @@ __device__ __forceinline__ Scalar (*gj_pivot_inverse(Scalar (*Dcur)[GJ_B + 1], S
 {
 	const int c = tid & 31, rb = tid >> 5;
 	const int wv2 = 2 * __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int bkPad = (bk + 1) & ~1;
+	(void)bk;          // a short block arrives padded with the identity, on which every step below is an exact no-op: always 16 steps,
+	                   // fully unrolled -- every LDS address is then an immediate offset and every pivot-position test a constant
 	Scalar d[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++) d[u] = Dcur[rb + 8 * u][c];
-	for (int p = 0; p < bkPad; p += 2)
+#pragma unroll
+	for (int p = 0; p < GJ_B; p += 2)
 	{
 		const Scalar a00 = Dcur[p][p], a01 = Dcur[p][p + 1], a10 = Dcur[p + 1][p], a11 = Dcur[p + 1][p + 1];
 		const Scalar m0 = Dcur[p][c], m1 = Dcur[p + 1][c];
@@ -123,7 +125,7 @@ __device__ __forceinline__ Scalar (*gj_pivot_inverse(Scalar (*Dcur)[GJ_B + 1], S
 				const Scalar vCol = -(mi0[u] * wA + mi1[u] * wB);
 				v = jp ? vCol : vGen;
 			}
-			if (r < bkPad && c < bkPad) { d[u] = v; Dnext[r][c] = v; }
+			d[u] = v; Dnext[r][c] = v;
 		}
 		__syncthreads();
 		Scalar (*tmp)[GJ_B + 1] = Dcur; Dcur = Dnext; Dnext = tmp;
