@@ -1,7 +1,9 @@
 """Round-4 experiment: Schur block pass with the operands of a workgroup's 16 blocks staged in LDS (block_pass_tiles_body).
 The tile lists -- per workgroup: stages; per stage: unique a-edges / b-edges / landmarks; per product: packed LDS slots -- are built HERE
 with numpy from the library's own block order and product lists (debug hooks) and handed in; the reduced matrix must come out
-bit-identical, and linearise + Schur is timed with cuba_hip_time_kernels before and after."""
+bit-identical, and linearise + Schur is timed with cuba_hip_time_kernels before and after.
+NOTE: the kernel and the two debug hooks this script drives (cuba_hip_debug_get_ints / _set_tiles) exist in commit c43c0bc only; they were
+removed after the measurement (profiles/r04j_block_pass_lds_tiles_experiment.txt): check that commit out to re-run it."""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
