@@ -368,6 +368,7 @@ struct cuba_hip_solver
 	int64_t cntPcgIters = 0, cntTrials = 0, cntCoarseRefresh = 0, cntPcgLooks = 0, cntPcgEnqueued = 0, cntPcgUnconverged = 0;
 	int64_t cntCoarseInline = 0;      // coarse inversions that ran on the WORK stream (in front of a solve), a subset of cntCoarseRefresh
 	int64_t cntFp32Fallbacks = 0;     // solves repeated with the fp64 coarse inverse after the fp32-stored one broke the PCG down
+	int64_t cntUploads = 0;           // successful cuba_hip_set_graph calls on this handle (never reset: identifies what the device holds)
 	bool acceptUnconverged = false;   // true: a solve that hits max_iter hands back its best iterate as a success (inexact LM step)
 	std::vector<int> pcgHistory;      // PCG iterations of every reduced solve since set_graph (negative = stopped at max_iter)
 	double prof[CUBA_HIP_PROFILE_ITEMS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -383,6 +384,8 @@ struct cuba_hip_solver
 		if (gjStream) { (void)hipStreamSynchronize(gjStream); (void)hipStreamDestroy(gjStream); (void)hipEventDestroy(evSetup); (void)hipEventDestroy(evAssembled); (void)hipEventDestroy(evInverse); (void)hipEventDestroy(evFirstInv); }
 		if (captureStream) (void)hipStreamDestroy(captureStream);
 		if (upStream) { (void)hipStreamSynchronize(upStream); (void)hipStreamDestroy(upStream); (void)hipEventDestroy(evValues); }
+		if (h_tileStage) (void)hipHostFree(h_tileStage);
+		if (evTileInputs) (void)hipEventDestroy(evTileInputs);
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
 	}
@@ -501,6 +504,7 @@ struct cuba_hip_solver
 	// edge may still be crossing PCIe -- on a second stream -- while the structure analysis (which needs the index arrays only) runs
 	hipStream_t upStream = nullptr; hipEvent_t evValues = nullptr;
 	bool valuesPending = false, deferredUpload = false;
+	int* h_tileStage = nullptr; size_t tileStageCap = 0; hipEvent_t evTileInputs = nullptr;     // page-locked staging of the tile-order inputs
 	void finishValues()
 	{
 		if (!valuesPending) return;
@@ -723,6 +727,7 @@ struct cuba_hip_solver
 		cntPcgIters = cntTrials = cntCoarseRefresh = cntPcgLooks = cntPcgEnqueued = cntPcgUnconverged = 0;
 		cntCoarseInline = cntFp32Fallbacks = 0;
 		pcgHistory.clear();
+		cntUploads++;
 		prof[0] += std::chrono::duration<double>(Clock::now() - t0).count();
 	}
 
@@ -1499,6 +1504,24 @@ struct cuba_hip_solver
 		topo::launch_blocks_from_entries(d_k64b.data(), d_v64b.data(), d_tmpI1.data(), nEnt, Pf, d_colind.data(), d_blkrow.data(), d_prodPtr.data(),
 			d_prodEa.data(), d_prodEb.data(), stream);
 		topo::launch_segment_ptr(d_blkrow.data(), nblk, Pf, d_rowptr.data(), stream);
+		// (the tile order of the Schur block pass -- a host computation over the block list -- needs only what exists from here on: its
+		// inputs start their way to a page-locked staging block now, and the host works on them while the device runs steps 6-8)
+		const bool earlyTiles = rowGroupedBlocks(npairs) && nblk > 0 && !localRanges;
+		if (earlyTiles)
+		{
+			if (tileStageCap < (size_t)3 * nblk + 1)
+			{
+				if (h_tileStage) (void)hipHostFree(h_tileStage);
+				h_tileStage = nullptr; tileStageCap = 0;
+				HIP_TRY(hipHostMalloc((void**)&h_tileStage, sizeof(int) * ((size_t)3 * nblk + 1), hipHostMallocDefault));
+				tileStageCap = (size_t)3 * nblk + 1;
+			}
+			if (!evTileInputs) HIP_TRY(hipEventCreateWithFlags(&evTileInputs, hipEventDisableTiming));
+			HIP_TRY(hipMemcpyAsync(h_tileStage, d_blkrow.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(h_tileStage + nblk, d_colind.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(h_tileStage + 2 * (size_t)nblk, d_prodPtr.data(), sizeof(int) * ((size_t)nblk + 1), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipEventRecord(evTileInputs, stream));
+		}
 		// 6. blocks with products, longest list first
 		const size_t n32 = std::max((size_t)std::max(nblk, E), (size_t)2 * nblk);
 		d_k32a.resize(n32); d_k32b.resize(n32); d_v32a.resize(n32); d_v32b.resize(n32);
@@ -1544,6 +1567,15 @@ struct cuba_hip_solver
 		allocSystem(nblk, cc);
 		// ---- synchronisation 3: widest adjacency row, numbers of product blocks and of coarse blocks -----------------------------
 		HIP_TRY(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, stream));
+		std::vector<int> earlyOd;
+		if (earlyTiles)
+		{
+			HIP_TRY(hipEventSynchronize(evTileInputs));
+			const int* pp = h_tileStage + 2 * (size_t)nblk;
+			std::vector<int> len(nblk);
+			for (int k = 0; k < nblk; k++) len[k] = pp[k + 1] - pp[k];
+			earlyOd = rowGroupedOrder(h_tileStage, h_tileStage + nblk, len.data(), nblk);
+		}
 		sync();
 		lap("structure (device): adjacency, coarse lists, allocations");
 		const int maxRow = hc[topo::CNT_MAXROW];
@@ -1559,9 +1591,15 @@ struct cuba_hip_solver
 		reorderTried = false;
 		diagProdBlocks = hc[topo::CNT_DIAGPROD]; heavyBlocks = hc[topo::CNT_NHEAVY];
 		int nOdList = hc[topo::CNT_NOD];
-		if (rowGroupedBlocks(npairs) && nblk > 0)
+		if (earlyTiles)
 		{
-			// (the grouping itself is a few sorts of nblk numbers: done on the host from two small downloads)
+			d_odBlocks.upload(earlyOd, stream);
+			sync();          // `earlyOd` is a local
+			nOdList = (int)earlyOd.size(); heavyBlocks = 0;
+		}
+		else if (rowGroupedBlocks(npairs) && nblk > 0)
+		{
+			// (landmark partitions: the list lengths are those of the rank's sub-ranges, known only after step 6)
 			std::vector<int> hRow(nblk), hBeg(nblk), hEnd(nblk), hCol;
 			hCol.resize(nblk); HIP_TRY(hipMemcpyAsync(hCol.data(), d_colind.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(hRow.data(), d_blkrow.data(), sizeof(int) * nblk, hipMemcpyDeviceToHost, stream));
@@ -2452,6 +2490,7 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
 		else if (k == "pcg_unconverged_solves") *value = s->cntPcgUnconverged;
 		else if (k == "pcg_graph_instantiations") *value = s->gb.builds.load();
 		else if (k == "precond_fp32_fallbacks") *value = s->cntFp32Fallbacks;
+		else if (k == "graph_uploads") *value = s->cntUploads;
 		else throw ArgError{ "unknown counter: " + k };
 	});
 }

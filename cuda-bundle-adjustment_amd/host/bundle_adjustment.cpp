@@ -330,6 +330,11 @@ public:
 		if (graphDirty_)
 		{
 			// what initialize() learned while it re-read the graph: the index arrays / the edge values are those of the last upload
+			// (the promise refers to ONE upload: the handle counts its uploads, and a count that is not the one recorded with the flags
+			// -- a handle that was recreated, an upload this object does not know of -- voids it: round-3 advisor)
+			int64_t uploadsNow = -1;
+			(void)cuba_hip_get_counter(solver_, "graph_uploads", &uploadsNow);
+			if (uploadsNow != uploadGeneration_) uploadedOnce_ = false;
 			const bool sameEdges = uploadedOnce_ && !edgesChangedSinceUpload_;
 			check(cuba_hip_hint_unchanged(solver_, sameEdges ? 1 : 0, sameEdges && !valuesChangedSinceUpload_ ? 1 : 0), "cuba_hip_hint_unchanged");
 			// two-step upload: the measurements / information (32 of the 41 bytes per edge; page-locked staging arrays of this object,
@@ -342,6 +347,7 @@ public:
 			check(cuba_hip_set_graph_end(solver_), "cuba_hip_set_graph_end");
 			graphDirty_ = false;
 			uploadedOnce_ = true; edgesChangedSinceUpload_ = valuesChangedSinceUpload_ = false;       // from here on the device holds exactly these edges and values
+			(void)cuba_hip_get_counter(solver_, "graph_uploads", &uploadGeneration_);
 		}
 		lap("create + set_graph");
 		std::vector<double> chi2(std::max(niterations, 1), 0.0);
@@ -526,6 +532,7 @@ private:
 
 	cuba_hip_solver* solver_ = nullptr;
 	bool uploadedOnce_ = false, edgesChangedSinceUpload_ = true, valuesChangedSinceUpload_ = true;    // what cuba_hip_hint_unchanged may promise
+	int64_t uploadGeneration_ = -1;          // "graph_uploads" of the handle right after the upload those flags describe
 	BatchStatistics stats_;
 	TimeProfile timeProfile_;
 	PinnedVector<double> perEdgeChi_;

@@ -253,7 +253,9 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
    "pcg_host_looks", "pcg_iterations_enqueued", plus "coarse_inline_inversions" (coarse inversions that ran on the work stream in front
    of a solve -- the others ran on the second stream under an earlier trial's PCG), "pcg_unconverged_solves",
    "pcg_graph_instantiations" (hipGraphs of PCG iteration batches built), "precond_fp32_fallbacks" (solves repeated with the fp64
-   coarse inverse after the fp32-stored one broke the PCG down).  Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
+   coarse inverse after the fp32-stored one broke the PCG down), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
+   life of the handle, never reset: a caller that keeps state about "what the device holds" -- the promises of cuba_hip_hint_unchanged --
+   stores this number with it and distrusts its state when the two differ).  Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
 int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);
 
 /* PCG iteration count of every reduced solve since cuba_hip_set_graph, oldest first (at most `capacity` are written,

@@ -1,4 +1,4 @@
-"""round 4 experiment: forcing term of the inexact LM step (option pcg_forcing) against the stated estimate tolerances.
+"""(needs the option pcg_forcing, which existed in commit c79419a only)  round 4 experiment: forcing term of the inexact LM step (option pcg_forcing) against the stated estimate tolerances.
 For every BASELINE shape: the oracle once (exact solves), then the HIP path for (pcg_tol, pcg_forcing) pairs: chi2 max-rel-diff per
 iteration, RMSE of the final estimates (as tests/test_gpu_configs.py takes it), PCG iterations per run, wall of a 10-iteration run."""
 import os, sys, time
