@@ -71,14 +71,6 @@ struct DeviceStructure
 	const int *prod_beg = nullptr, *prod_end = nullptr, *pe_beg = nullptr, *pe_end = nullptr;
 	int* prod_lm = nullptr;            // landmark of each product (= e_lm[prod_ea]): the block pass then fetches inv(Hll + lambda) beside the
 	                                   // two edge records instead of after them (one memory round trip per product instead of two)
-	// LDS-staged block pass (ba_linearize.hip: block_pass_tiles_body): per workgroup of 16 blocks its stages, per stage the ranges of the
-	// workgroup's unique a-edges / b-edges / landmarks it copies into LDS, per (stage, group) the end of the group's products in it, and
-	// per product one packed word {slot a: 11 bits, slot b: 11 bits, slot landmark: 10 bits} into the stage's LDS arrays.  nullptr = off.
-	const int *tile_stage_ptr = nullptr, *tile_a_beg = nullptr, *tile_b_beg = nullptr, *tile_l_beg = nullptr, *tile_p_end = nullptr;
-	const int *tile_a = nullptr, *tile_b = nullptr, *tile_l = nullptr;
-	const unsigned* tile_slots = nullptr;
-	const int* od_blocks_padded = nullptr;    // od_blocks, readable up to the next multiple of 16 entries (-1 beyond nOd)
-	int tile_merged = 1;               // pose pass + staged block pass in one launch
 	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
 	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
 	int nCb = 0;                       // non-empty coarse blocks

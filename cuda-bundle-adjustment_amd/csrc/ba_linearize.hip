@@ -484,319 +484,6 @@ __device__ __forceinline__ void block_pass_group(const DeviceGraph& g, const Dev
 	}
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Block pass with the operands of a workgroup's 16 blocks staged in LDS (round 4; the north star's "Jacobian tiles and Hpl blocks
-// staged in LDS", in the form this design has them: per-edge records and landmark inverses).  The 16 blocks of a workgroup come from
-// one 4 x 4 tile of the block matrix (st.od_blocks), so the a-side records of a tile row are shared by its 4 blocks, the b-side records
-// of a tile column likewise, and a landmark inverse by every product of that landmark: the default pass gathers 3 lines per product
-// (3.67 M at KITTI-00), the tile's UNIQUE operands are 1.70 M lines.  The structure lists every workgroup's unique a-edges, b-edges
-// and landmarks in landmark order (an edge belongs to one landmark, so all three lists cut at the same landmark boundaries into
-// STAGES of at most TILE_LDS_BYTES), and for every product one packed word of three slots into the stage's LDS arrays.  Per stage:
-// all 256 threads copy the operands (first 32 bytes of a record: Xc, w'; 6 numbers of an inverse) into LDS with full-line requests,
-// one barrier, then every 16-lane group walks its block's products of that stage with LDS reads only.  Summation order per block is
-// unchanged (landmark order, lane = product index mod 16, same lane reduction): results are bit-identical to block_pass_group's.
-// ---------------------------------------------------------------------------------------------------
-constexpr int TILE_LDS_BYTES = 48 * 1024;
-
-template <typename ET>
-__device__ __forceinline__ void block_pass_tiles_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int wg, unsigned char* lds)
-{
-	const int t = threadIdx.x, gl = t & (BP_GROUP - 1);
-	const int grp = wg * 16 + (t >> 4);
-	const int blk0 = grp < st.nOd ? st.od_blocks[grp] : -1;
-	const bool on = blk0 >= 0;
-	const int blk = on ? blk0 : 0;
-	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
-	ET qa[4], cama[5], qb[4], camb[5];
-	load_pose_as<ET>(g, a, qa, cama);
-	load_pose_as<ET>(g, b, qb, camb);
-	const Rot3T<ET> Ra = quat_to_rot(qa[0], qa[1], qa[2], qa[3]);
-	const Rot3T<ET> Rb = quat_to_rot(qb[0], qb[1], qb[2], qb[3]);
-	ET T[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++) T[r][c] = 0;
-	const ET* recs = reinterpret_cast<const ET*>(st.e_rec);
-	typedef ET RecVec __attribute__((ext_vector_type(4)));
-	const int pbeg = on ? st.prod_beg[blk] : 0;
-	int p = pbeg;
-	const bool skipCompute = (st.tile_merged & 2) != 0, skipStaging = (st.tile_merged & 4) != 0;      // (timing experiments only)
-	const int s1 = st.tile_stage_ptr[wg + 1];
-	for (int s = st.tile_stage_ptr[wg]; s < s1; s++)
-	{
-		const int a0 = st.tile_a_beg[s], na = st.tile_a_beg[s + 1] - a0;
-		const int b0 = st.tile_b_beg[s], nb = st.tile_b_beg[s + 1] - b0;
-		const int l0 = st.tile_l_beg[s], nl = st.tile_l_beg[s + 1] - l0;
-		RecVec* ldsA = reinterpret_cast<RecVec*>(lds);
-		RecVec* ldsB = ldsA + na;
-		Scalar* ldsL = reinterpret_cast<Scalar*>(ldsB + nb);
-		__syncthreads();                                   // the previous stage's readers are through
-		if (!skipStaging)
-		for (int i = t; i < na + nb; i += 256)
-		{
-			const int e = i < na ? st.tile_a[a0 + i] : st.tile_b[b0 + i - na];
-			ldsA[i] = *reinterpret_cast<const RecVec*>(recs + REC * (size_t)e);       // Xc[3], w' (sign = stereo)
-		}
-		if (!skipStaging)
-		for (int i = t; i < 6 * nl; i += 256)
-		{
-			const int item = i / 6, k = i - 6 * item;
-			const int lm = st.tile_l[l0 + item];
-			ldsL[i] = st.inv_rows8 ? sys.lm_inv[8 * (size_t)lm + k] : sys.lm_sys[9 * (size_t)lm + k];
-		}
-		__syncthreads();
-		const int pe = on && !skipCompute ? st.tile_p_end[(size_t)s * 16 + (t >> 4)] : 0;
-		// (lane = product index mod 16 counted from the block's first product, as in block_pass_group: same partial sums per lane)
-		for (int pp = p + ((gl - (p - pbeg)) & (BP_GROUP - 1)); pp < pe; pp += BP_GROUP)
-		{
-			const unsigned w = st.tile_slots[pp];
-			const RecVec va = ldsA[w & 2047u], vb = ldsB[(w >> 11) & 2047u];
-			const Scalar* li = ldsL + 6 * (w >> 22);
-			const ET ra[4] = { va.x, va.y, va.z, va.w }, rb[4] = { vb.x, vb.y, vb.z, vb.w };
-			ET inv[6];
-#pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = (ET)li[k];
-			ProductOperand<ET> A, B;
-			product_operand<ET>(ra, Ra, cama, A);
-			product_operand<ET>(rb, Rb, camb, B);
-			product_accumulate<ET>(A, B, inv, T);
-		}
-		p = max(p, pe);
-	}
-	Scalar Ts[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-		{
-			Scalar v = (Scalar)T[r][c];
-			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-			Ts[r][c] = v;
-		}
-	if (!on) return;
-	Scalar* dst = sys.hsc + 36 * (size_t)blk;
-	if (a != b)
-	{
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r < 6; r++)
-				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
-	}
-	else if (gl == 0)
-	{
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= Ts[r][c] + Ts[c][r];
-	}
-}
-
-// ---- pipelined variant: two LDS buffers, the operands of stage s + 1 travel global -> LDS (global_load_lds, no registers) while the
-// groups multiply stage s out of the other buffer; the slot words of a stage's products are staged too, so the product loop touches
-// LDS only and nothing waits for the copies before the barrier that ends the stage.  Per stage at most TP_NA / TP_NB records per
-// side, TP_NL landmark inverses (whole 8-number rows of lm_inv) and TP_NP products.
-constexpr int TP_NA = 320, TP_NB = 320, TP_NL = 128, TP_NP = 1024;
-
-template <typename ET>
-struct TileBuf
-{
-	static constexpr int REC_B = 4 * (int)sizeof(ET);          // Xc[3], w'
-	static constexpr int INV_B = 8 * (int)sizeof(Scalar);      // one row of lm_inv
-	static constexpr int A_OFF = 0, B_OFF = TP_NA * REC_B, L_OFF = B_OFF + TP_NB * REC_B, S_OFF = L_OFF + TP_NL * INV_B, SIZE = S_OFF + TP_NP * 4;
-};
-
-__device__ __forceinline__ void glds16(const void* src, void* ldsWaveBase)
-{
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const void* src, void* ldsWaveBase)
-{
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)ldsWaveBase, 4, 0, 0);
-}
-
-// copies of stage s into buffer `buf`; returns this thread's {first product, end, word offset of its group's slots} through the references
-template <typename ET>
-__device__ __forceinline__ void tile_stage_issue(const DeviceStructure& st, const DeviceSystem& sys, int wg, int s, bool firstStage, unsigned char* buf,
-	int& myPb, int& myPe, int& myOfs)
-{
-	typedef TileBuf<ET> TB;
-	const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), g = t >> 4;
-	const int a0 = st.tile_a_beg[s], na = st.tile_a_beg[s + 1] - a0;
-	const int b0 = st.tile_b_beg[s], nb = st.tile_b_beg[s + 1] - b0;
-	const int l0 = st.tile_l_beg[s], nl = st.tile_l_beg[s + 1] - l0;
-	// product ranges of the 16 groups in this stage (uniform loads), their prefix sums = where each group's slot words go
-	int pb[16], pe[16];
-#pragma unroll
-	for (int k = 0; k < 16; k++)
-	{
-		pe[k] = st.tile_p_end[(size_t)s * 16 + k];
-		if (firstStage) { const int blk = st.od_blocks_padded[wg * 16 + k]; pb[k] = blk >= 0 ? st.prod_beg[blk] : 0; }
-		else pb[k] = st.tile_p_end[(size_t)(s - 1) * 16 + k];
-		pe[k] = max(pe[k], pb[k]);
-	}
-	int run = 0, mPb = 0, mPe = 0, mOfs = 0, ofs[16];
-#pragma unroll
-	for (int k = 0; k < 16; k++) { ofs[k] = run; run += pe[k] - pb[k]; if (g == k) { mPb = pb[k]; mPe = pe[k]; mOfs = ofs[k]; } }
-	myPb = mPb; myPe = mPe; myOfs = mOfs;
-	// source indices first (ordinary loads, waited for together), then every copy of the stage
-	constexpr int RP = TB::REC_B / 16, RPW = 64 / RP;          // pieces per record, records per wave instruction
-	constexpr int IP = TB::INV_B / 16, IPW = 64 / IP;
-	constexpr int RC = (TP_NA + 4 * RPW - 1) / (4 * RPW), LC = (TP_NL + 4 * IPW - 1) / (4 * IPW);      // instructions per wave
-	int ida[RC], idb[RC], idl[LC];
-#pragma unroll
-	for (int c = 0; c < RC; c++)
-	{
-		const int item = (wv + 4 * c) * RPW + lane / RP;
-		ida[c] = item < na ? st.tile_a[a0 + item] : -1;
-		idb[c] = item < nb ? st.tile_b[b0 + item] : -1;
-	}
-#pragma unroll
-	for (int c = 0; c < LC; c++)
-	{
-		const int item = (wv + 4 * c) * IPW + lane / IP;
-		idl[c] = item < nl ? st.tile_l[l0 + item] : -1;
-	}
-	const char* recs = reinterpret_cast<const char*>(st.e_rec);
-#pragma unroll
-	for (int c = 0; c < RC; c++)
-	{
-		const int chunk = wv + 4 * c;
-		if (ida[c] >= 0) glds16(recs + (size_t)ida[c] * (REC * sizeof(ET)) + 16 * (lane % RP), buf + TB::A_OFF + chunk * RPW * TB::REC_B);
-		if (idb[c] >= 0) glds16(recs + (size_t)idb[c] * (REC * sizeof(ET)) + 16 * (lane % RP), buf + TB::B_OFF + chunk * RPW * TB::REC_B);
-	}
-#pragma unroll
-	for (int c = 0; c < LC; c++)
-	{
-		const int chunk = wv + 4 * c;
-		if (idl[c] >= 0) glds16(reinterpret_cast<const char*>(sys.lm_inv) + (size_t)idl[c] * TB::INV_B + 16 * (lane % IP), buf + TB::L_OFF + chunk * IPW * TB::INV_B);
-	}
-	// slot words: group k's run of (pe - pb) words, 64 per instruction, groups dealt to the waves
-#pragma unroll
-	for (int k = 0; k < 16; k++)
-	{
-		if ((k & 3) != wv) continue;
-		const int cnt = pe[k] - pb[k];
-		for (int w0 = 0; w0 < cnt; w0 += 64)
-			if (w0 + lane < cnt) glds4(st.tile_slots + pb[k] + w0 + lane, buf + TB::S_OFF + 4 * (ofs[k] + w0));
-	}
-}
-
-template <typename ET>
-__device__ __forceinline__ void block_pass_tiles2_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int wg, unsigned char* lds)
-{
-	typedef TileBuf<ET> TB;
-	typedef ET RecVec __attribute__((ext_vector_type(4)));
-	const int t = threadIdx.x, gl = t & (BP_GROUP - 1);
-	const int grp = wg * 16 + (t >> 4);
-	const int blk0 = grp < st.nOd ? st.od_blocks[grp] : -1;
-	const bool on = blk0 >= 0;
-	const int blk = on ? blk0 : 0;
-	const int a = on ? st.hsc_blkrow[blk] : 0, b = on ? st.hsc_colind[blk] : 0;
-	ET qa[4], cama[5], qb[4], camb[5];
-	load_pose_as<ET>(g, a, qa, cama);
-	load_pose_as<ET>(g, b, qb, camb);
-	const Rot3T<ET> Ra = quat_to_rot(qa[0], qa[1], qa[2], qa[3]);
-	const Rot3T<ET> Rb = quat_to_rot(qb[0], qb[1], qb[2], qb[3]);
-	ET T[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++) T[r][c] = 0;
-	const int pbeg = on ? st.prod_beg[blk] : 0;
-	const int s0 = st.tile_stage_ptr[wg], s1 = st.tile_stage_ptr[wg + 1];
-	int curPb = 0, curPe = 0, curOfs = 0;
-	if (s0 < s1) tile_stage_issue<ET>(st, sys, wg, s0, true, lds, curPb, curPe, curOfs);
-	__syncthreads();
-	for (int s = s0; s < s1; s++)
-	{
-		unsigned char* cur = lds + ((s - s0) & 1) * TB::SIZE;
-		unsigned char* nxt = lds + (((s - s0) & 1) ^ 1) * TB::SIZE;
-		int nPb = 0, nPe = 0, nOfs = 0;
-		if (s + 1 < s1) tile_stage_issue<ET>(st, sys, wg, s + 1, false, nxt, nPb, nPe, nOfs);
-		const RecVec* ldsA = reinterpret_cast<const RecVec*>(cur + TB::A_OFF);
-		const RecVec* ldsB = reinterpret_cast<const RecVec*>(cur + TB::B_OFF);
-		const Scalar* ldsL = reinterpret_cast<const Scalar*>(cur + TB::L_OFF);
-		const unsigned* ldsS = reinterpret_cast<const unsigned*>(cur + TB::S_OFF);
-		const int pe = on ? curPe : 0;
-		for (int pp = curPb + ((gl - (curPb - pbeg)) & (BP_GROUP - 1)); pp < pe; pp += BP_GROUP)
-		{
-			const unsigned w = ldsS[curOfs + (pp - curPb)];
-			const RecVec va = ldsA[w & 2047u], vb = ldsB[(w >> 11) & 2047u];
-			const Scalar* li = ldsL + 8 * (w >> 22);
-			const ET ra[4] = { va.x, va.y, va.z, va.w }, rb[4] = { vb.x, vb.y, vb.z, vb.w };
-			ET inv[6];
-#pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = (ET)li[k];
-			ProductOperand<ET> A, B;
-			product_operand<ET>(ra, Ra, cama, A);
-			product_operand<ET>(rb, Rb, camb, B);
-			product_accumulate<ET>(A, B, inv, T);
-		}
-		__syncthreads();                                   // the copies of stage s + 1 have landed, every reader of stage s is through
-		curPb = nPb; curPe = nPe; curOfs = nOfs;
-	}
-	Scalar Ts[6][6];
-#pragma unroll
-	for (int r = 0; r < 6; r++)
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-		{
-			Scalar v = (Scalar)T[r][c];
-			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-			Ts[r][c] = v;
-		}
-	if (!on) return;
-	Scalar* dst = sys.hsc + 36 * (size_t)blk;
-	if (a != b)
-	{
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r < 6; r++)
-				if ((c * 6 + r) % BP_GROUP == gl) dst[c * 6 + r] = -Ts[r][c];
-	}
-	else if (gl == 0)
-	{
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r <= c; r++) dst[c * 6 + r] -= Ts[r][c] + Ts[c][r];
-	}
-}
-
-template <typename ET>
-__global__ __launch_bounds__(256) void block_pass_tiles2_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
-{
-	__shared__ __align__(16) unsigned char lds[2 * TileBuf<ET>::SIZE];
-	block_pass_tiles2_body<ET>(g, st, sys, blockIdx.x, lds);
-}
-
-template <typename ET>
-__global__ __launch_bounds__(256) void schur_pass_tiles2_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
-{
-	__shared__ __align__(16) unsigned char lds[2 * TileBuf<ET>::SIZE];
-	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
-	else block_pass_tiles2_body<ET>(g, st, sys, blockIdx.x - nPoseGroups, lds);
-}
-
-template <typename ET>
-__global__ __launch_bounds__(256) void block_pass_tiles_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys)
-{
-	__shared__ __align__(16) unsigned char lds[TILE_LDS_BYTES];
-	block_pass_tiles_body<ET>(g, st, sys, blockIdx.x, lds);
-}
-
-// pose pass + LDS-staged block pass in one launch (the pose workgroups do not touch the LDS array)
-template <typename ET>
-__global__ __launch_bounds__(256) void schur_pass_tiles_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
-{
-	__shared__ __align__(16) unsigned char lds[TILE_LDS_BYTES];
-	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
-	else block_pass_tiles_body<ET>(g, st, sys, blockIdx.x - nPoseGroups, lds);
-}
-
 // workgroup bid of the block pass: the heavy blocks first (one per wave), then 16 light blocks per workgroup
 __host__ __device__ __forceinline__ int block_pass_heavy_groups(int nHeavy) { return (nHeavy + 3) / 4; }
 __host__ __device__ __forceinline__ int block_pass_groups(int nOd, int nHeavy) { return block_pass_heavy_groups(nHeavy) + ((nOd - nHeavy) * BP_GROUP + 255) / 256; }
@@ -852,23 +539,10 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 	}
 	const int nbp = block_pass_groups(st.nOd, st.nHeavy);
-	const bool tiles = st.tile_stage_ptr != nullptr && st.nHeavy == 0;      // LDS-staged block pass: the structure carries the tile lists
 	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)
 	{
 		const int np = (g.Pf + 3) / 4;
-		if (tiles && (st.tile_merged & 8) && (st.tile_merged & 1)) hipLaunchKernelGGL((schur_pass_tiles2_kernel<ET>), dim3(np + nbp), dim3(256), 0, s, g, st, sys, np);
-		else if (tiles && (st.tile_merged & 8))
-		{
-			hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3(np), dim3(256), 0, s, g, st, sys);
-			hipLaunchKernelGGL((block_pass_tiles2_kernel<ET>), dim3(nbp), dim3(256), 0, s, g, st, sys);
-		}
-		else if (tiles && (st.tile_merged & 1)) hipLaunchKernelGGL((schur_pass_tiles_kernel<ET>), dim3(np + nbp), dim3(256), 0, s, g, st, sys, np);
-		else if (tiles)
-		{
-			hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3(np), dim3(256), 0, s, g, st, sys);
-			hipLaunchKernelGGL((block_pass_tiles_kernel<ET>), dim3(nbp), dim3(256), 0, s, g, st, sys);
-		}
-		else hipLaunchKernelGGL((schur_pass_kernel<ET>), dim3(np + nbp), dim3(256), 0, s, g, st, sys, np);
+		hipLaunchKernelGGL((schur_pass_kernel<ET>), dim3(np + nbp), dim3(256), 0, s, g, st, sys, np);
 		return;
 	}
 	if (g.Pf > 0)
@@ -877,10 +551,7 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 		else hipLaunchKernelGGL((pose_pass_kernel<1, ET>), dim3((g.Pf + 3) / 4), dim3(256), 0, s, g, st, sys);
 	}
 	if (mode == 1 && st.nOd > 0)
-	{
-		if (tiles) hipLaunchKernelGGL((block_pass_tiles_kernel<ET>), dim3(nbp), dim3(256), 0, s, g, st, sys);
-		else hipLaunchKernelGGL((block_pass_kernel<ET>), dim3(nbp), dim3(256), 0, s, g, st, sys);
-	}
+		hipLaunchKernelGGL((block_pass_kernel<ET>), dim3(nbp), dim3(256), 0, s, g, st, sys);
 }
 
 void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,

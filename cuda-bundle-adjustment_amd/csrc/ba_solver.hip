@@ -165,8 +165,6 @@ struct cuba_hip_solver
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
 	DevBuf<int> d_blkrow, d_odBlocks, d_prodPtr, d_prodEa, d_prodEb, d_prodLm, d_pePtr, d_peEdge;
-	DevBuf<int> d_tileStagePtr, d_tileABeg, d_tileBBeg, d_tileLBeg, d_tilePEnd, d_tileA, d_tileB, d_tileL;     // LDS-staged block pass: tile lists
-	DevBuf<unsigned> d_tileSlots;
 	DevBuf<int> d_prodBeg, d_prodEnd, d_peBeg, d_peEnd;     // landmark partition built on the device: the sub-ranges of the global lists it walks
 	bool localRanges = false;
 	DevBuf<Scalar> d_erec;
@@ -2652,44 +2650,6 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 		return CUBA_HIP_OK;
 	}
 	catch (const HipError&) { return CUBA_HIP_ERR_RUNTIME; }
-}
-
-// ---- experiment hooks (round 4, LDS-staged block pass): the tile lists are built outside and handed in ------------------------------------
-int cuba_hip_debug_get_ints(cuba_hip_solver* s, const char* name, int32_t* out, size_t* count)
-{
-	return guarded(s, [&] {
-		s->need();
-		const std::string k(name ? name : "");
-		const int* src = nullptr; size_t n = 0;
-		if (k == "od_blocks") { src = s->st.od_blocks; n = (size_t)s->st.nOd; }
-		else if (k == "prod_beg") { src = s->st.prod_beg; n = (size_t)s->st.nblk; }
-		else if (k == "prod_end") { src = s->st.prod_end; n = (size_t)s->st.nblk; }
-		else if (k == "prod_ea") { src = s->st.prod_ea; n = s->d_prodEa.size(); }
-		else if (k == "prod_eb") { src = s->st.prod_eb; n = s->d_prodEb.size(); }
-		else if (k == "prod_lm") { src = s->st.prod_lm; n = s->d_prodLm.size(); }
-		else throw ArgError{ "unknown array" };
-		if (count) *count = n;
-		if (out && n) { HIP_TRY(hipMemcpyAsync(out, src, sizeof(int) * n, hipMemcpyDeviceToHost, s->stream)); s->sync(); }
-	});
-}
-
-int cuba_hip_debug_set_tiles(cuba_hip_solver* s, int nWG, int nStages, const int32_t* stage_ptr, const int32_t* a_beg, const int32_t* b_beg, const int32_t* l_beg,
-	const int32_t* p_end, const int32_t* ta, size_t nta, const int32_t* tb, size_t ntb, const int32_t* tl, size_t ntl, const uint32_t* slots, size_t nslots, int merged, int inv_rows8)
-{
-	return guarded(s, [&] {
-		s->need();
-		if (nWG <= 0) { s->st.tile_stage_ptr = nullptr; return; }
-		s->d_tileStagePtr.uploadRaw(stage_ptr, (size_t)nWG + 1, s->stream);
-		s->d_tileABeg.uploadRaw(a_beg, (size_t)nStages + 1, s->stream); s->d_tileBBeg.uploadRaw(b_beg, (size_t)nStages + 1, s->stream); s->d_tileLBeg.uploadRaw(l_beg, (size_t)nStages + 1, s->stream);
-		s->d_tilePEnd.uploadRaw(p_end, (size_t)nStages * 16, s->stream);
-		s->d_tileA.uploadRaw(ta, nta, s->stream); s->d_tileB.uploadRaw(tb, ntb, s->stream); s->d_tileL.uploadRaw(tl, ntl, s->stream);
-		s->d_tileSlots.uploadRaw(slots, nslots, s->stream);
-		s->sync();
-		s->st.tile_stage_ptr = s->d_tileStagePtr.data(); s->st.tile_a_beg = s->d_tileABeg.data(); s->st.tile_b_beg = s->d_tileBBeg.data(); s->st.tile_l_beg = s->d_tileLBeg.data();
-		s->st.tile_p_end = s->d_tilePEnd.data(); s->st.tile_a = s->d_tileA.data(); s->st.tile_b = s->d_tileB.data(); s->st.tile_l = s->d_tileL.data();
-		s->st.tile_slots = s->d_tileSlots.data(); s->st.tile_merged = merged; s->st.inv_rows8 = inv_rows8;
-		s->st.od_blocks_padded = s->st.od_blocks;       // (the tile order pads its list to whole workgroups)
-	});
 }
 
 int cuba_hip_begin_run(cuba_hip_solver* s)

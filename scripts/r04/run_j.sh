@@ -1,4 +1,5 @@
 #!/bin/bash
 out=gpurun_out; mkdir -p $out
-( for cap in 64 128; do TILES_TRUNCATE=$cap timeout 600 python scripts/experiments/r04_block_pass_tiles.py kitti00; done ) > $out/r04j_truncate.txt 2>&1
-grep -v amdgpu $out/r04j_truncate.txt | cut -c1-250
+
+( time timeout 1200 python scripts/experiments/r04_block_pass_tiles.py kitti00 ) > $out/r04j_block_pass_tiles.txt 2>&1
+cat $out/r04j_block_pass_tiles.txt | cut -c1-330
