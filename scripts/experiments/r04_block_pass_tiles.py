@@ -1,9 +1,7 @@
 """Round-4 experiment: Schur block pass with the operands of a workgroup's 16 blocks staged in LDS (block_pass_tiles_body).
 The tile lists -- per workgroup: stages; per stage: unique a-edges / b-edges / landmarks; per product: packed LDS slots -- are built HERE
 with numpy from the library's own block order and product lists (debug hooks) and handed in; the reduced matrix must come out
-bit-identical, and linearise + Schur is timed with cuba_hip_time_kernels before and after.
-NOTE: the kernel and the two debug hooks this script drives (cuba_hip_debug_get_ints / _set_tiles) exist in commit c43c0bc only; they were
-removed after the measurement (profiles/r04j_block_pass_lds_tiles_experiment.txt): check that commit out to re-run it."""
+bit-identical, and linearise + Schur is timed with cuba_hip_time_kernels before and after."""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -22,7 +20,7 @@ def get_ints(h, name):
     assert h.lib.cuba_hip_debug_get_ints(h.h, name.encode(), out.ctypes.data_as(_ip), C.byref(n)) == 0
     return out
 
-def build_tiles(od, pbeg, pend, ea, eb, lm):
+def build_tiles(od, pbeg, pend, ea, eb, lm, lim_a=2047, lim_b=2047, lim_l=1023, lim_p=1 << 30, lds=LDS):
     nWG = (len(od) + 15) // 16
     odp = np.full(nWG * 16, -1, np.int64); odp[:len(od)] = od
     stage_ptr = [0]; a_beg = [0]; b_beg = [0]; l_beg = [0]; p_end = []
@@ -41,12 +39,13 @@ def build_tiles(od, pbeg, pend, ea, eb, lm):
         oa = np.argsort(pea, kind="stable"); la = plm[oa][np.searchsorted(pea[oa], ua)]
         ob = np.argsort(peb, kind="stable"); lb = plm[ob][np.searchsorted(peb[ob], ub)]
         ca = np.searchsorted(la, ul, side="right"); cb = np.searchsorted(lb, ul, side="right")     # unique a / b edges with landmark <= ul[i]
+        cp = np.searchsorted(np.sort(plm), ul, side="right")                                       # products of the workgroup with landmark <= ul[i]
         # greedy stage cuts over the landmarks
         cuts = []; i0 = 0
         while i0 < len(ul):
-            a0 = ca[i0 - 1] if i0 else 0; b0 = cb[i0 - 1] if i0 else 0
-            na = ca[i0:] - a0; nb = cb[i0:] - b0; nl = np.arange(1, len(ul) - i0 + 1)
-            ok = (32 * (na + nb) + 48 * nl <= LDS) & (na <= 2047) & (nb <= 2047) & (nl <= 1023)
+            a0 = ca[i0 - 1] if i0 else 0; b0 = cb[i0 - 1] if i0 else 0; p0 = cp[i0 - 1] if i0 else 0
+            na = ca[i0:] - a0; nb = cb[i0:] - b0; nl = np.arange(1, len(ul) - i0 + 1); npr = cp[i0:] - p0
+            ok = (32 * (na + nb) + 48 * nl <= lds) & (na <= lim_a) & (nb <= lim_b) & (nl <= lim_l) & (npr <= lim_p)
             k = int(np.argmin(ok)) if not ok.all() else len(ok)
             assert k >= 1, "one landmark does not fit a stage"
             i0 += k; cuts.append(i0)
@@ -115,8 +114,21 @@ for shape in sys.argv[1:] or ["kitti00"]:
         print(f"{shape}: list integrity check: {bad} bad (stage, group) entries", flush=True)
     rp, ci = h.hsc_structure()
     offd = np.ones(len(ci), bool); offd[rp[:-1]] = False          # (the lower triangles of the diagonal blocks are never written: compare the rest)
-    for merged, inv8 in ((1, 0), (0, 0), (1, 1), (0 | 2, 0), (0 | 4, 0), (1 | 2, 0), (1 | 4, 0)):
-        set_tiles(h, tiles, merged, inv8)
+    tiles2 = build_tiles(od, pbeg, pend, ea.astype(np.int64), eb.astype(np.int64), lm.astype(np.int64), 320, 320, 128, 1024, 1 << 30)
+    print(f"{shape}: pipelined variant: {tiles2['nStages']} stages (at most 320 + 320 records, 128 inverses, 1024 products each)", flush=True)
+    if os.environ.get("TILES_TRUNCATE"):
+        # timing-only hypothesis test: is the pass bound by its LONGEST product list (27 dependent trips of 16 lanes at KITTI-00)?  Every
+        # group stops after `cap` products of its block (wrong reduced system, same launch shape)
+        cap = int(os.environ["TILES_TRUNCATE"])
+        odp = np.full(tiles["nWG"] * 16, -1, np.int64); odp[:len(od)] = od
+        for t_ in (tiles, tiles2):
+            lim = np.where(odp >= 0, pbeg[np.maximum(odp, 0)] + cap, 0)
+            pe = t_["p_end"].reshape(-1, 16)
+            wg_of_stage = np.repeat(np.arange(t_["nWG"]), np.diff(t_["stage_ptr"]))
+            t_["p_end"] = np.ascontiguousarray(np.minimum(pe, lim.reshape(-1, 16)[wg_of_stage]).reshape(-1).astype(np.int32))
+        print(f"{shape}: TIMING ONLY: every block truncated to its first {cap} products", flush=True)
+    for merged, inv8 in ((1, 0), (0, 0), (8 | 1, 1), (8, 1)):
+        set_tiles(h, tiles2 if merged & 8 else tiles, merged, inv8)
         h.schur(); got = h.array("hsc"); got_bsc = h.array("bsc")
         same = np.array_equal(got.reshape(-1, 36)[offd], ref.reshape(-1, 36)[offd]) and np.array_equal(got_bsc, ref_bsc)
         if merged & 6: same = "n/a (timing variant: " + ("staging only" if merged & 2 else "compute only") + ")"
@@ -126,7 +138,7 @@ for shape in sys.argv[1:] or ["kitti00"]:
             wrong = np.nonzero(d > 0)[0]
             pos = {int(b): i for i, b in enumerate(od) if b >= 0}
             print(f"   {nbad} of {len(d)} blocks differ; first wrong blocks {wrong[:8].tolist()} at list positions {[pos.get(int(b), -1) for b in wrong[:8]]}, products {[(int(pbeg[b]), int(pend[b])) for b in wrong[:4]]}", flush=True)
-        print(f"{shape}: LDS-staged block pass ({'one launch with the pose pass' if merged & 1 else 'own launch'}, inverses from {'64-byte rows' if inv8 else 'the landmark systems'}): "
+        print(f"{shape}: LDS-staged block pass ({'PIPELINED, ' if merged & 8 else ''}{'one launch with the pose pass' if merged & 1 else 'own launch'}, inverses from {'64-byte rows' if inv8 else 'the landmark systems'}): "
               f"linearise + Schur {t1 * 1e3:7.2f} us, reduced system bit-identical: {same}" + ("" if same is not False else f" (max abs diff {(np.abs(got - ref).reshape(-1, 36)[offd]).max():.3e})"), flush=True)
     set_tiles(h, None, 1, 0)
     h.close()
