@@ -1053,12 +1053,14 @@ struct cuba_hip_solver
 		const int cl = coarseLinear ? 2 : 1;
 		// automatic size: coarse dimension <= ~700-960 (scripts/experiments/agg_sweep.py: iterations vs the O(Nc^3) inversion)
 		// (small graphs want smaller aggregates: KITTI-07, 247 free poses: 24 / 16 / 12 / 8 / 6 / 4 poses -> 8.6 / 7.0 / 6.4 / 6.3 / 6.5 / 7.9 ms)
+		// (round 4, fp32-stored inverse + unrolled pivot chain: KITTI-07 10 / 8 / 6 / 4 poses -> 4.00 / 3.65 / 3.39 / 4.30 ms, 250 / 212 / 195 / 238 iterations:
+		// the floor of the small-graph rule went from 8 to 6, profiles/r04m_sweeps.txt)
 		// (large graphs, inversion hidden under the PCG of earlier trials: S2M 44 / 40 / 36 / 32 poses -> 27.1 / 26.35 / 26.7 / 26.4 ms,
 		// G4M 88 / 72 / 64 / 56 / 48 -> 65.1 / 59.6 / 54.8 / 54.0 / 58.3 ms: the aggregate count may grow from 115 to 180 with the graph)
 		// (round 3, coarse inverse stored in fp32 -- its apply costs half: KITTI-00 24 / 20 / 16 poses -> 8.16 / 8.00 / 7.81 ms, S2M 44 / 40 / 36 /
 		// 32 / 28 -> 25.8 / 25.0 / 24.8 / 24.6 / 26.0 ms, G4M 64 / 56 / 48 / 40 -> 51.7 / 50.5 / 52.8 / 58.2 ms: profiles/r03i_agg_sweep.txt)
 		const int ncMax = std::min(180, std::max(115, (Pf + 31) / 32));
-		if (agg < 0) agg = cl == 2 ? (Pf >= 1320 ? std::max(16, (Pf + ncMax - 1) / ncMax) : std::max(8, (Pf + 27) / 55)) : std::max(12, (Pf + 159) / 160);
+		if (agg < 0) agg = cl == 2 ? (Pf >= 1320 ? std::max(16, (Pf + ncMax - 1) / ncMax) : std::max(6, (Pf + 27) / 55)) : std::max(12, (Pf + 159) / 160);
 		const int spmvRows = spmv_rows_for(Pf);
 		if (agg > 0) agg = (agg + spmvRows - 1) / spmvRows * spmvRows;   // aggregates = whole SpMV workgroups (sys.qpart)
 		int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;

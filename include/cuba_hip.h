@@ -88,7 +88,7 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
 /* Options (16).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
-   "pcg_aggregate" (poses per coarse aggregate of the two-level preconditioner; -1 = automatic: max(8, Pf/55) below 1320 free poses,
+   "pcg_aggregate" (poses per coarse aggregate of the two-level preconditioner; -1 = automatic: max(6, Pf/55) below 1320 free poses,
    max(16, Pf/min(180, max(115, Pf/32))) above; 0 = block-Jacobi only), "coarse_linear" (default 1: constant + linear-in-pose-index
    coarse functions per aggregate, 12 unknowns each; 0 = constant only, 6 unknowns), "precond_fp32" (fp64 library only, default 1: the
    explicit coarse inverse is STORED in fp32 -- symmetrised, applied with fp64 accumulation; a solve whose PCG breaks down with it is
