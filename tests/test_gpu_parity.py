@@ -434,12 +434,15 @@ def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small
     import copy
     HipSolver, _ = solvers
     fp = small_fp
-    h = HipSolver(fp, RK_HUBER)
+    # (pcg_tol 1e-10: the runs below start their first solve with different preconditioners -- a fresh handle inverts in line, a
+    # re-uploaded one carries the previous run's inverse over --, so they agree to the solver tolerance, which is tightened here
+    # to keep the 1e-9 comparisons about the uploads, not about the PCG)
+    h = HipSolver(fp, RK_HUBER, pcg_tol=1e-10)
     base = h.optimize(4)["chi2"]
     h.hint_unchanged(True, True); h.set_graph(fp)
     assert rel(h.optimize(4)["chi2"], base) < 1e-9
     fp2 = copy.copy(fp); fp2.meas = fp.meas.copy(); fp2.meas[:, 0] += 0.5
-    moved = HipSolver(fp2, RK_HUBER).optimize(4)["chi2"]
+    moved = HipSolver(fp2, RK_HUBER, pcg_tol=1e-10).optimize(4)["chi2"]
     assert rel(moved, base) > 1e-6                                   # (the modification is visible in the objective)
     h.set_graph(fp2)                                                 # no promise: the new values go up
     assert rel(h.optimize(4)["chi2"], moved) < 1e-9
