@@ -401,7 +401,7 @@ def main():
                     "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials,
                     "coarse_setup": c1["coarse_refreshes"] - c0["coarse_refreshes"]}
         kt = {k: v for k, v in kt.items() if v > 0}
-        # the coarse inverse is rebuilt on a second stream under the PCG of an earlier trial (option coarse_overlap, default on): the
+        # the coarse inverse is rebuilt on a second stream under the PCG of an earlier trial: the
         # per-kernel table charges the work stream with the inversions the library COUNTED there (cuba_hip_get_counter
         # "coarse_inline_inversions"), the rest is off the timed path
         refreshes = launches["coarse_setup"]
