@@ -27,11 +27,6 @@ static __device__ unsigned long long cuba_trace_buf[3][8192 * 8];
 // ---------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void atomic_add(Scalar* p, Scalar v)
-{
-	__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __device__ __forceinline__ void atomic_max_nonneg(unsigned long long* p, Scalar v)
 {
 	// IEEE-754 ordering of non-negative doubles equals the ordering of their bit patterns
@@ -130,12 +125,6 @@ __device__ __forceinline__ void wave_lds_sync()
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ Scalar sum_slots(const Scalar* s, int lane)
-{
-	Scalar v = lane < NSLOT ? s[lane] : Scalar(0);
-	return wave_sum(v);
 }
 
 // lane-strided partial sum of n per-workgroup partials (finish with wave_sum)

@@ -284,31 +284,7 @@ void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar
 // ---------------------------------------------------------------------------------------------------
 // manifold update.  Ref: updatePosesKernel / updateLandmarksKernel :1045-1068.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void update_poses_kernel(DeviceGraph g, DeviceSystem sys)
-{
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= g.Pf) return;
-	Scalar upd[6], q[4], t[3];
-#pragma unroll
-	for (int k = 0; k < 6; k++) upd[k] = sys.xp[6 * (size_t)i + k];
-#pragma unroll
-	for (int k = 0; k < 4; k++) q[k] = g.q[4 * (size_t)i + k];
-#pragma unroll
-	for (int k = 0; k < 3; k++) t[k] = g.t[3 * (size_t)i + k];
-	pose_exp_update(upd, q, t);
-#pragma unroll
-	for (int k = 0; k < 4; k++) g.q[4 * (size_t)i + k] = q[k];
-#pragma unroll
-	for (int k = 0; k < 3; k++) g.t[3 * (size_t)i + k] = t[k];
-}
-
-__global__ __launch_bounds__(256) void update_landmarks_kernel(DeviceGraph g, DeviceSystem sys)
-{
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < g.Lf * 3) g.Xw[i] += sys.xl[i];
-}
-
-// both updates in one launch: the first workgroups take the poses, the rest the landmark coordinates
+// one launch: the first workgroups take the poses, the rest the landmark coordinates
 __global__ __launch_bounds__(256) void update_state_kernel(DeviceGraph g, DeviceSystem sys, int poseBlocks)
 {
 	if ((int)blockIdx.x < poseBlocks)
@@ -619,16 +595,6 @@ void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const De
 	const int nScale = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
 	if (nRes + nScale > 0) hipLaunchKernelGGL(eval_trial_kernel, dim3(nRes + nScale), dim3(256), 0, s, g, sys, lambda, resParts, nRes, scaleParts, nScale);
 	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, sys.parts, nA, sys.slots + NSLOT, resParts, nRes, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT);
-}
-
-void launch_update_poses(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s)
-{
-	if (g.Pf > 0) hipLaunchKernelGGL(update_poses_kernel, dim3((g.Pf + 255) / 256), dim3(256), 0, s, g, sys);
-}
-
-void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s)
-{
-	if (g.Lf > 0) hipLaunchKernelGGL(update_landmarks_kernel, dim3((g.Lf * 3 + 255) / 256), dim3(256), 0, s, g, sys);
 }
 
 }  // namespace cubahip

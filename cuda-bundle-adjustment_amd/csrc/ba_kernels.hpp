@@ -45,11 +45,8 @@ struct DeviceStructure
 	int* wave_lm = nullptr;            // [2*nWaves] first / one-past-last landmark of each wave
 	int nBig = 0;
 	int* big_lm = nullptr;             // landmarks with more than 64 edges (own workgroup each)
-	long long* big_scratch_ofs = nullptr;  // [nBig] offset (in edges) into big_hpl
-	Scalar* big_hpl = nullptr;         // 18 doubles per edge of a big landmark
 	int nblk = 0;
 	int *hsc_rowptr = nullptr, *hsc_colind = nullptr;
-	int* lm_nfree = nullptr;           // [Lf] number of edges of the landmark whose pose is free
 	int *adj_ptr = nullptr, *adj_blk = nullptr, *adj_col = nullptr;  // adj_blk bit 31 = use transposed
 	// the first 20*ell_m entries of every adjacency row again, padded to a fixed width and interleaved so that lane
 	// (slot, m) finds its (block, column) pair at ((row*ell_m + m)*20 + slot) without reading adj_ptr first;
@@ -64,14 +61,14 @@ struct DeviceStructure
 	int inv_rows8 = 1;                 // 1 = the landmark pass also writes inv(Hll + lambda I) as 64-byte rows (lm_inv) and the block pass gathers those;
 	                                   // 0 = 48-byte gathers from the 72-byte rows of lm_sys (small graphs: the extra stores cost the landmark pass more than the block pass gains)
 	int nHeavy = 0;                    // the first nHeavy of them have more than BP_HEAVY products: a whole wave each in the block pass
-	int* prod_ptr = nullptr;           // [nblk+1] product range of each block
 	int *prod_ea = nullptr, *prod_eb = nullptr;   // sorted edge ids of each product (ea: row pose, eb: column pose)
-	// the ranges of the two lists above that THIS handle walks: prod_ptr / prod_ptr + 1 and pe_ptr / pe_ptr + 1 for a whole graph,
-	// sub-ranges (the lists are in landmark order) for a landmark partition built on the device
+	// the ranges of the product list (per block) and of the pose edge list (per free pose) that THIS handle walks: consecutive
+	// entries of the [n + 1] range arrays for a whole graph, sub-ranges (the lists are in landmark order) for a landmark
+	// partition built on the device
 	const int *prod_beg = nullptr, *prod_end = nullptr, *pe_beg = nullptr, *pe_end = nullptr;
 	int* prod_lm = nullptr;            // landmark of each product (= e_lm[prod_ea]): the block pass then fetches inv(Hll + lambda) beside the
 	                                   // two edge records instead of after them (one memory round trip per product instead of two)
-	int *pe_ptr = nullptr, *pe_edge = nullptr;    // per free pose: its sorted edge ids
+	int* pe_edge = nullptr;            // per free pose: its sorted edge ids (ranges: pe_beg / pe_end)
 	// coarse-matrix assembly lists: for every non-empty coarse block (I,J) the fine blocks that fall into it
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
@@ -161,9 +158,7 @@ size_t trial_tail_parts(const DeviceGraph& g, const DeviceStructure& st);
 // landmark-side part recomputed from xl and the stored bl (stage API; the fused path gets it from back_substitute)
 void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
 
-void launch_update_poses(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
 void launch_update_state(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);   // poses + landmarks in one launch
-void launch_update_landmarks(const DeviceGraph& g, const DeviceSystem& sys, hipStream_t s);
 
 // block-Jacobi PCG on the upper-BSR reduced system
 void launch_pcg_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);

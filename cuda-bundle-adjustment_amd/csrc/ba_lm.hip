@@ -544,15 +544,6 @@ void cuba_hip_solver::evaluateTrial(double lam, bool withScale, double* Fhat, do
 	readEvaluate(withScale, Fhat, scale);
 }
 
-double cuba_hip_solver::scaleOfLastSolve(double lam)
-{
-	launch_pose_scale(g, sys, lam, slotsDev + 3 * NSLOT, stream);
-	sync();
-	double v = 0;
-	for (int i = 0; i < NSLOT; i++) v += slot(NSLOT + i) + slot(3 * NSLOT + i);
-	return v;
-}
-
 void cuba_hip_solver::timeKernels(int reps, double* msOut)
 {
 	need();

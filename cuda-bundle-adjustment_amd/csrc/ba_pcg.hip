@@ -541,19 +541,6 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 // doUpdate = 0 (once per solve: z_0 = M^-1 r_0) still restricts r directly.
 constexpr int PCG2_T = 512;
 
-__device__ __forceinline__ Scalar block_strided_sum(const Scalar* p, int n)
-{
-	Scalar v0 = 0, v1 = 0;
-	int t = threadIdx.x;
-	for (; t + PCG2_T < n; t += 2 * PCG2_T)
-	{
-		const Scalar a = p[t], b = p[t + PCG2_T];
-		v0 += a; v1 += b;
-	}
-	const Scalar e = t < n ? p[t] : Scalar(0);
-	return (v0 + e) + v1;
-}
-
 // CL = coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose index.  Coarse
 // unknown (aggregate J, function a, component c) has index (6 CL) J + 6 a + c.
 // AC2: further column pairs per lane and row, fetched in a second batch once the restricted sums have freed their registers

@@ -447,8 +447,6 @@ void cuba_hip_solver::buildStructure()
 	lap("structure: pose edge lists");
 	// wave work list: whole landmarks, at most 64 edges per wave; larger landmarks get a workgroup each
 	std::vector<int> waveLm, bigLm;
-	std::vector<long long> bigOfs;
-	long long bigEdges = 0;
 	{
 		int start = -1, cnt = 0;
 		auto flush = [&](int end) { if (start >= 0 && cnt > 0) { waveLm.push_back(start); waveLm.push_back(end); } start = -1; cnt = 0; };
@@ -461,7 +459,7 @@ void cuba_hip_solver::buildStructure()
 			if (n > WAVE)
 			{
 				flush(l);
-				bigLm.push_back(l); bigOfs.push_back(bigEdges); bigEdges += n;
+				bigLm.push_back(l);
 				continue;
 			}
 			if (n == 0) continue;   // empty landmarks inside a run are harmless (no lanes)
@@ -473,10 +471,8 @@ void cuba_hip_solver::buildStructure()
 	}
 
 	lap("structure: wave list");
-	d_waveLm.upload(waveLm, stream); d_bigLm.upload(bigLm, stream); d_bigOfs.upload(bigOfs, stream);
-	d_bigHpl.resize((size_t)bigEdges * 18);
+	d_waveLm.upload(waveLm, stream); d_bigLm.upload(bigLm, stream);
 	d_rowptr.upload(h_rowptr, stream); d_colind.upload(h_colind, stream);
-	d_lmNfree.upload(nfree, stream);
 	d_adjPtr.upload(adjPtr, stream); d_adjBlk.upload(adjBlk, stream); d_adjCol.upload(adjCol, stream);
 	int ellM = 0, ellOver = 0;
 	{
@@ -668,9 +664,8 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	const int gridSetup = (Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES, gridUpd = (Pf + 39) / 40, gridSpmv = (Pf + spmvRows - 1) / spmvRows;
 	st = DeviceStructure();
 	st.nWaves = nWaves; st.wave_lm = d_waveLm.data();
-	st.nBig = nBig; st.big_lm = d_bigLm.data(); st.big_scratch_ofs = d_bigOfs.data(); st.big_hpl = d_bigHpl.data();
+	st.nBig = nBig; st.big_lm = d_bigLm.data();
 	st.nblk = nblk; st.hsc_rowptr = d_rowptr.data(); st.hsc_colind = d_colind.data();
-	st.lm_nfree = d_lmNfree.data();
 	st.adj_ptr = d_adjPtr.data(); st.adj_blk = d_adjBlk.data(); st.adj_col = d_adjCol.data();
 	st.ell = d_ell.data(); st.ell_m = ellM; st.ell_over = ellOver;
 	st.hsc_blkrow = d_blkrow.data(); st.nOd = nOd; st.nDiagProd = diagProdBlocks; st.od_blocks = d_odBlocks.data(); st.nHeavy = std::min(heavyBlocks, nOd);
@@ -679,12 +674,12 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	if (d_prodEa.size() > ((size_t)1 << 19)) st.nHeavy = 0;
 	// (64-byte rows of the landmark inverses: block pass -3 us / landmark pass +5 us at KITTI-00, -16 / +3 us at S2M)
 	st.inv_rows8 = Lf >= 250000;
-	st.prod_ptr = d_prodPtr.data(); st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
+	st.prod_ea = d_prodEa.data(); st.prod_eb = d_prodEb.data();
 	if (!localRanges) fillProdLm();          // (a device-built partition needed it earlier)
 	st.prod_lm = d_prodLm.data();
 	st.prod_beg = localRanges ? d_prodBeg.data() : d_prodPtr.data(); st.prod_end = localRanges ? d_prodEnd.data() : d_prodPtr.data() + 1;
 	st.pe_beg = localRanges ? d_peBeg.data() : d_pePtr.data(); st.pe_end = localRanges ? d_peEnd.data() : d_pePtr.data() + 1;
-	st.pe_ptr = d_pePtr.data(); st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
+	st.pe_edge = d_peEdge.data(); st.e_rec = d_erec.data();
 	st.nCb = nCb; st.cb_I = d_cbI.data(); st.cb_J = d_cbJ.data(); st.cb_ptr = d_cbPtr.data(); st.cb_blk = d_cbBlk.data(); st.cb_wi = d_cbWi.data(); st.cb_wj = d_cbWj.data();
 	sys = DeviceSystem();
 	sys.hsc = d_red.data(); sys.bsc = d_red.data() + (size_t)36 * nblk; sys.bp = sys.bsc + (size_t)6 * Pf;
@@ -891,7 +886,7 @@ void cuba_hip_solver::buildStructureDevice()
 	const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
 	localRanges = partHi >= 0;
 	const int nChunks = (hi - lo + topo::WAVE_CHUNK - 1) / topo::WAVE_CHUNK;
-	d_chunk.resize((size_t)3 * std::max(1, nChunks));
+	d_chunk.resize((size_t)2 * std::max(1, nChunks));
 	if (nChunks == 0) d_chunk.zero(stream);
 	topo::launch_wave_count(d_lmptr.data(), lo, hi, d_chunk.data(), stream);
 	topo::launch_wave_scan(d_chunk.data(), nChunks, cnt, stream);
@@ -913,9 +908,8 @@ void cuba_hip_solver::buildStructureDevice()
 	if (npairs >= (1LL << 31) - Pf) throw ArgError{ "graph too dense: more than 2^31 Schur block products" };
 	nmul = npairs + nFreeEdges;
 	const int nWaves = hc[topo::CNT_NWAVES], nBig = hc[topo::CNT_NBIG];
-	const long long bigEdges = (long long)hc[topo::CNT_BIGEDGES_LO] | ((long long)hc[topo::CNT_BIGEDGES_HI] << 31);
-	d_waveLm.resize((size_t)2 * nWaves); d_bigLm.resize(nBig); d_bigOfs.resize(nBig); d_bigHpl.resize((size_t)bigEdges * 18);
-	topo::launch_wave_write(d_lmptr.data(), lo, hi, d_chunk.data(), d_waveLm.data(), d_bigLm.data(), d_bigOfs.data(), stream);
+	d_waveLm.resize((size_t)2 * nWaves); d_bigLm.resize(nBig);
+	topo::launch_wave_write(d_lmptr.data(), lo, hi, d_chunk.data(), d_waveLm.data(), d_bigLm.data(), stream);
 	g.e_begin = eRange[0]; g.e_end = eRange[1];
 	if (localRanges)
 	{

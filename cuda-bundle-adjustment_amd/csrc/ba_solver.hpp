@@ -154,8 +154,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
 	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
 	DevBuf<int2> d_ell;
-	DevBuf<long long> d_bigOfs, d_lmPairBase;
-	DevBuf<Scalar> d_bigHpl;
+	DevBuf<long long> d_lmPairBase;
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
 	DevBuf<Scalar> d_parts, d_lmSys, d_lmInv, d_xp, d_xl, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
@@ -260,7 +259,7 @@ struct cuba_hip_solver
 	}
 	hipStream_t gjStream = nullptr;
 	hipEvent_t evSetup = nullptr, evAssembled = nullptr, evInverse = nullptr, evFirstInv = nullptr;
-	int liveInv = 0, pendingInv = -1;   // buffer with the inverse in use / buffer the running inversion will leave its result in
+	int pendingInv = -1;                // >= 0 while a coarse inversion runs on the second stream (evInverse marks its end)
 	bool assemblePending = false;       // the other stream may still be reading hsc
 	void ensureOverlapObjects();
 	// the work stream must not touch what a running inversion still uses
@@ -555,7 +554,6 @@ struct cuba_hip_solver
 
 	// Fused version used by optimize(): the landmark part was accumulated by back_substitute (same lambda),
 	// only the 6*Pf pose part is added here.
-	double scaleOfLastSolve(double lam);
 
 	// Average device time per launch of the five hot kernels, measured with HIP events on this solver's
 	// stream (bench.py's roofline leg).  Leaves the increments / reduced system in an undefined state.

@@ -321,18 +321,18 @@ __global__ __launch_bounds__(T) void coarse_lists_kernel(const uint32_t* keys, c
 }
 
 // ---- wave list ---------------------------------------------------------------------------------------------------------
-// one thread per chunk of WAVE_CHUNK landmarks; WRITE = false: count waves / big landmarks / their edges, true: emit
+// one thread per chunk of WAVE_CHUNK landmarks; WRITE = false: count waves / big landmarks, true: emit
 template <bool WRITE>
 __global__ __launch_bounds__(64) void wave_list_kernel(const int* lm_ptr, int lo, int hi, const int* chunkOfs, int* chunkCounts,
-	int* wave_lm, int* big_lm, long long* big_ofs)
+	int* wave_lm, int* big_lm)
 {
 	const int c = blockIdx.x * 64 + threadIdx.x;
 	const int l0 = lo + c * WAVE_CHUNK;
 	if (l0 >= hi) return;
 	const int l1 = min(hi, l0 + WAVE_CHUNK);
-	int nW = 0, nB = 0; long long bigE = 0;
-	int w = 0, bI = 0; long long bE = 0;
-	if (WRITE) { w = chunkOfs[3 * c]; bI = chunkOfs[3 * c + 1]; bE = chunkOfs[3 * c + 2]; }
+	int nW = 0, nB = 0;
+	int w = 0, bI = 0;
+	if (WRITE) { w = chunkOfs[2 * c]; bI = chunkOfs[2 * c + 1]; }
 	int start = -1, cnt = 0;
 	int prev = lm_ptr[l0];
 	for (int l = l0; l < l1; l++)
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(64) void wave_list_kernel(const int* lm_ptr, int lo
 		{
 			if (start >= 0 && cnt > 0) { if (WRITE) { wave_lm[2 * (w + nW)] = start; wave_lm[2 * (w + nW) + 1] = l; } nW++; }
 			start = -1; cnt = 0;
-			if (WRITE) { big_lm[bI + nB] = l; big_ofs[bI + nB] = bE + bigE; }
-			nB++; bigE += n;
+			if (WRITE) big_lm[bI + nB] = l;
+			nB++;
 			continue;
 		}
 		if (n == 0) continue;
@@ -358,45 +358,41 @@ __global__ __launch_bounds__(64) void wave_list_kernel(const int* lm_ptr, int lo
 		cnt += n;
 	}
 	if (start >= 0 && cnt > 0) { if (WRITE) { wave_lm[2 * (w + nW)] = start; wave_lm[2 * (w + nW) + 1] = l1; } nW++; }
-	if (!WRITE) { chunkCounts[3 * c] = nW; chunkCounts[3 * c + 1] = nB; chunkCounts[3 * c + 2] = (int)bigE; }
+	if (!WRITE) { chunkCounts[2 * c] = nW; chunkCounts[2 * c + 1] = nB; }
 }
 
-// exclusive scan of the 3 counts per chunk by one workgroup (in place), totals -> counters
+// exclusive scan of the 2 counts per chunk by one workgroup (in place), totals -> counters
 __global__ __launch_bounds__(1024) void wave_scan_kernel(int* chunkCounts, int nChunks, int* counters)
 {
-	__shared__ long long sh[3][1024];
+	__shared__ long long sh[2][1024];
 	const int t = threadIdx.x;
 	const int per = (nChunks + 1023) / 1024;
 	const int c0 = min(nChunks, t * per), c1 = min(nChunks, c0 + per);
-	long long s[3] = { 0, 0, 0 };
+	long long s[2] = { 0, 0 };
 	for (int c = c0; c < c1; c++)
 #pragma unroll
-		for (int k = 0; k < 3; k++) s[k] += chunkCounts[3 * c + k];
+		for (int k = 0; k < 2; k++) s[k] += chunkCounts[2 * c + k];
 #pragma unroll
-	for (int k = 0; k < 3; k++) sh[k][t] = s[k];
+	for (int k = 0; k < 2; k++) sh[k][t] = s[k];
 	__syncthreads();
 	for (int off = 1; off < 1024; off <<= 1)
 	{
-		long long v[3] = { 0, 0, 0 };
+		long long v[2] = { 0, 0 };
 		if (t >= off)
 #pragma unroll
-			for (int k = 0; k < 3; k++) v[k] = sh[k][t - off];
+			for (int k = 0; k < 2; k++) v[k] = sh[k][t - off];
 		__syncthreads();
 #pragma unroll
-		for (int k = 0; k < 3; k++) sh[k][t] += v[k];
+		for (int k = 0; k < 2; k++) sh[k][t] += v[k];
 		__syncthreads();
 	}
-	long long run[3];
+	long long run[2];
 #pragma unroll
-	for (int k = 0; k < 3; k++) run[k] = sh[k][t] - s[k];          // exclusive prefix of this thread's segment
+	for (int k = 0; k < 2; k++) run[k] = sh[k][t] - s[k];          // exclusive prefix of this thread's segment
 	for (int c = c0; c < c1; c++)
 #pragma unroll
-		for (int k = 0; k < 3; k++) { const int v = chunkCounts[3 * c + k]; chunkCounts[3 * c + k] = (int)run[k]; run[k] += v; }
-	if (t == 1023)
-	{
-		counters[CNT_NWAVES] = (int)sh[0][1023]; counters[CNT_NBIG] = (int)sh[1][1023];
-		counters[CNT_BIGEDGES_LO] = (int)(sh[2][1023] & 0x7fffffff); counters[CNT_BIGEDGES_HI] = (int)(sh[2][1023] >> 31);
-	}
+		for (int k = 0; k < 2; k++) { const int v = chunkCounts[2 * c + k]; chunkCounts[2 * c + k] = (int)run[k]; run[k] += v; }
+	if (t == 1023) { counters[CNT_NWAVES] = (int)sh[0][1023]; counters[CNT_NBIG] = (int)sh[1][1023]; }
 }
 
 __global__ __launch_bounds__(T) void unsort_kernel(const uint32_t* perm, const Scalar* sorted, int E, double* callerOrder)
@@ -521,7 +517,7 @@ void launch_wave_count(const int* lm_ptr, int lo, int hi, int* chunkCounts, hipS
 {
 	const int nChunks = (hi - lo + WAVE_CHUNK - 1) / WAVE_CHUNK;
 	if (nChunks > 0) hipLaunchKernelGGL(wave_list_kernel<false>, dim3((nChunks + 63) / 64), dim3(64), 0, s, lm_ptr, lo, hi, (const int*)nullptr, chunkCounts,
-		(int*)nullptr, (int*)nullptr, (long long*)nullptr);
+		(int*)nullptr, (int*)nullptr);
 }
 
 void launch_wave_scan(int* chunkCounts, int nChunks, int* counters, hipStream_t s)
@@ -529,10 +525,10 @@ void launch_wave_scan(int* chunkCounts, int nChunks, int* counters, hipStream_t 
 	hipLaunchKernelGGL(wave_scan_kernel, dim3(1), dim3(1024), 0, s, chunkCounts, nChunks, counters);
 }
 
-void launch_wave_write(const int* lm_ptr, int lo, int hi, const int* chunkOfs, int* wave_lm, int* big_lm, long long* big_ofs, hipStream_t s)
+void launch_wave_write(const int* lm_ptr, int lo, int hi, const int* chunkOfs, int* wave_lm, int* big_lm, hipStream_t s)
 {
 	const int nChunks = (hi - lo + WAVE_CHUNK - 1) / WAVE_CHUNK;
-	if (nChunks > 0) hipLaunchKernelGGL(wave_list_kernel<true>, dim3((nChunks + 63) / 64), dim3(64), 0, s, lm_ptr, lo, hi, chunkOfs, (int*)nullptr, wave_lm, big_lm, big_ofs);
+	if (nChunks > 0) hipLaunchKernelGGL(wave_list_kernel<true>, dim3((nChunks + 63) / 64), dim3(64), 0, s, lm_ptr, lo, hi, chunkOfs, (int*)nullptr, wave_lm, big_lm);
 }
 
 void launch_unsort(const uint32_t* perm, const Scalar* sorted, int E, double* callerOrder, hipStream_t s)

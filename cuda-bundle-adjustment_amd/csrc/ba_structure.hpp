@@ -30,7 +30,7 @@ hipError_t exclusive_scan_i64(void* temp, size_t tempBytes, const long long* in,
 hipError_t inclusive_scan_i32(void* temp, size_t tempBytes, const int* in, int* out, size_t n, hipStream_t s);
 
 // counters the kernels fill (one device int each), read back by the host at its synchronisation points
-enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_BIGEDGES_LO, CNT_BIGEDGES_HI, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_NHEAVY, CNT_COUNT = 16 };
+enum { CNT_BAD = 0, CNT_FREE_EDGES, CNT_NOD, CNT_MAXROW, CNT_NCB, CNT_NWAVES, CNT_NBIG, CNT_FARBLOCKS, CNT_DIAGPROD, CNT_NHEAVY, CNT_COUNT = 16 };
 
 // ---- A. edges ------------------------------------------------------------------------------------------------------
 // keys[e] = landmark << 32 | pose, vals[e] = e; counters[CNT_BAD] = 1 / 2 / 3 for an index out of range / a bad dimension /
@@ -85,11 +85,11 @@ void launch_coarse_lists(const uint32_t* keys, const uint32_t* order, const int*
 	int nAdj, int agg, int nc, int Pf, int cl, int* cbI, int* cbJ, int* cbPtr, int* cbBlk, Scalar* cbWi, Scalar* cbWj, int* counters, hipStream_t s);
 // wave work list of the landmark-major kernels: whole landmarks, at most 64 edges per wave; larger landmarks apart.
 // Two passes over chunks of WAVE_CHUNK landmarks (each chunk starts a new wave): count, then (after a scan by one
-// workgroup) write.  chunkCounts has 3 ints per chunk.
+// workgroup) write.  chunkCounts has 2 ints per chunk.
 constexpr int WAVE_CHUNK = 256;
 void launch_wave_count(const int* lm_ptr, int lo, int hi, int* chunkCounts, hipStream_t s);
 void launch_wave_scan(int* chunkCounts, int nChunks, int* counters, hipStream_t s);
-void launch_wave_write(const int* lm_ptr, int lo, int hi, const int* chunkCounts, int* wave_lm, int* big_lm, long long* big_ofs, hipStream_t s);
+void launch_wave_write(const int* lm_ptr, int lo, int hi, const int* chunkCounts, int* wave_lm, int* big_lm, hipStream_t s);
 // per-edge values from sorted order back to the caller's order
 void launch_unsort(const uint32_t* perm, const Scalar* sorted, int E, double* callerOrder, hipStream_t s);
 
