@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar*
 //   * the inverse of the pivot block comes in ready-made (pivIn): the workgroup that produced the NEXT pivot block in the
 //     previous step -- tile (p0/32 + 1, p0/32 + 1) is final for this purpose once step p0 has updated it -- inverted it right
 //     away (look-ahead).  One workgroup runs the 16-step chain per launch instead of all of them (twice as slow when two
-//     workgroups share a CU), and it has its CU nearly to itself by then: 15.9 -> ~10 us per step;
+//     workgroups share a CU), and it has its CU nearly to itself by then: 15.9 -> ~10 us per step.  That workgroup is an
+//     extra one (blockIdx.y = 0) with this single tile: it neither waits for a dispatch slot nor walks over other tiles first;
 //   * the two 32x32x32 products run on the matrix cores.
 __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk, int colsPerGroup,
 	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
@@ -179,13 +180,16 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	TRACE_DECL
 	TRACE_MARK();
 	const int tiles = (n + GJ_B - 1) / GJ_B;
-	const int jt0 = blockIdx.x * colsPerGroup, jt1 = min(tiles, jt0 + colsPerGroup);
-	const int i0 = blockIdx.y * GJ_B;
+	const int pNext = p0 + GJ_B;                            // look-ahead: the tile (pNext, pNext) is the next pivot block
+	// blockIdx.y = 0 is the look-ahead workgroup (dispatched first): it recomputes the one tile (pNext, pNext) -- stored by the
+	// workgroup that owns it -- and goes straight into the pivot chain; rows 1.. are the tile rows
+	const bool aheadRow = blockIdx.y == 0;
+	if (aheadRow && (blockIdx.x != 0 || pNext >= n)) return;
+	const int jt0 = aheadRow ? pNext / GJ_B : blockIdx.x * colsPerGroup, jt1 = aheadRow ? jt0 + 1 : min(tiles, jt0 + colsPerGroup);
+	const int i0 = aheadRow ? pNext : (blockIdx.y - 1) * GJ_B;
 	int j0 = jt0 * GJ_B;
 	const int r = tid & 31, cb = tid >> 5;
 	const bool rowTile = i0 == p0;                          // this workgroup's tiles lie in the pivot rows
-	const int pNext = p0 + GJ_B;                            // look-ahead: the tile (pNext, pNext) is the next pivot block
-	const bool aheadRow = i0 == pNext && pNext < n;
 	Scalar dv[4], av[4], fv[4], sv[4], keep[4] = { 0, 0, 0, 0 };
 #pragma unroll
 	for (int u = 0; u < 4; u++)
@@ -277,9 +281,9 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 		for (int u = 0; u < 4; u++)
 		{
 			const int gi = i0 + r, gj = j0 + cb + 8 * u;
-			if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
+			if (!aheadRow && gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
 		}
-		if (aheadRow && j0 == pNext)                        // (uniform over the workgroup)
+		if (aheadRow)                                       // (uniform over the workgroup)
 		{
 #pragma unroll
 			for (int u = 0; u < 4; u++) keep[u] = out[u];
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	}
 	TRACE_MARK();
 	// look-ahead: this workgroup produced the next pivot block -> invert it for the next launch
-	if (aheadRow && jt0 * GJ_B <= pNext && pNext < jt1 * GJ_B)
+	if (aheadRow)
 	{
 		const int bkN = min(GJ_B, n - pNext);
 		__syncthreads();                                       // D (the current inverse) is no longer an operand
@@ -337,7 +341,7 @@ Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots
 	hipLaunchKernelGGL(dense_gj_first_pivot_kernel, dim3(1), dim3(256), 0, s, src, n, min(GJ_B, n), pivIn);
 	for (int p0 = 0; p0 < n; p0 += GJ_B)
 	{
-		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols, pivIn, pivOut);
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles + 1), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols, pivIn, pivOut);
 		Scalar* tmp = src; src = dst; dst = tmp;
 		tmp = pivIn; pivIn = pivOut; pivOut = tmp;
 	}
