@@ -158,39 +158,35 @@ __global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar*
 }
 
 // One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B: dst = GJ_step(src). After the
-// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile (or per colsPerGroup tiles of one tile row); thread
-// (r, cb) owns the elements (r, cb + 8u), u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32
-// dependent launches), so:
+// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile; thread (r, cb) owns the elements (r, cb + 8u),
+// u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32 dependent launches), so:
 //   * every global load of the kernel is issued before the first use (clamped addresses, selected afterwards);
-//   * the inverse of the pivot block comes in ready-made (pivIn): the workgroup that produced the NEXT pivot block in the
-//     previous step -- tile (p0/32 + 1, p0/32 + 1) is final for this purpose once step p0 has updated it -- inverted it right
-//     away (look-ahead).  One workgroup runs the 16-step chain per launch instead of all of them (twice as slow when two
-//     workgroups share a CU), and it has its CU nearly to itself by then: 15.9 -> ~10 us per step.  That workgroup is an
-//     extra one (blockIdx.y = 0) with this single tile: it neither waits for a dispatch slot nor walks over other tiles first;
+//   * the inverse of the pivot block comes in ready-made (pivIn): the NEXT pivot block -- tile (p0/32 + 1, p0/32 + 1) is
+//     final for this purpose once step p0 has updated it -- is inverted inside this launch (look-ahead) by ONE extra
+//     workgroup (blockIdx.y = 0, dispatched first) that recomputes just that tile and goes straight into the 16-step
+//     chain: 15.9 us per step when every workgroup inverted the pivot block itself, 11.4 now;
+//   * four LDS arrays (the chain's second array reuses an operand array): four workgroups per CU, so that the n/32 x n/32
+//     tiles of a coarse matrix of ~1000 unknowns are resident at once with one tile each (several tiles per workgroup were
+//     faster only while the LDS footprint allowed three per CU);
 //   * the two 32x32x32 products run on the matrix cores.
-__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk, int colsPerGroup,
+__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk,
 	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
 {
 	__shared__ Scalar D[GJ_B][GJ_B + 1];
-	__shared__ Scalar D2[GJ_B][GJ_B + 1];
 	__shared__ Scalar Apj[GJ_B][GJ_B + 1];
 	__shared__ Scalar R[GJ_B][GJ_B + 1];
 	__shared__ Scalar F[GJ_B][GJ_B + 1];
 	const int tid = threadIdx.x;
 	TRACE_DECL
 	TRACE_MARK();
-	const int tiles = (n + GJ_B - 1) / GJ_B;
 	const int pNext = p0 + GJ_B;                            // look-ahead: the tile (pNext, pNext) is the next pivot block
-	// blockIdx.y = 0 is the look-ahead workgroup (dispatched first): it recomputes the one tile (pNext, pNext) -- stored by the
-	// workgroup that owns it -- and goes straight into the pivot chain; rows 1.. are the tile rows
-	const bool aheadRow = blockIdx.y == 0;
-	if (aheadRow && (blockIdx.x != 0 || pNext >= n)) return;
-	const int jt0 = aheadRow ? pNext / GJ_B : blockIdx.x * colsPerGroup, jt1 = aheadRow ? jt0 + 1 : min(tiles, jt0 + colsPerGroup);
-	const int i0 = aheadRow ? pNext : (blockIdx.y - 1) * GJ_B;
-	int j0 = jt0 * GJ_B;
+	const bool ahead = blockIdx.y == 0;                     // the look-ahead workgroup; rows 1.. of the grid are the tile rows
+	if (ahead && (blockIdx.x != 0 || pNext >= n)) return;
+	const int i0 = ahead ? pNext : (blockIdx.y - 1) * GJ_B;
+	const int j0 = ahead ? pNext : blockIdx.x * GJ_B;
 	const int r = tid & 31, cb = tid >> 5;
-	const bool rowTile = i0 == p0;                          // this workgroup's tiles lie in the pivot rows
-	Scalar dv[4], av[4], fv[4], sv[4], keep[4] = { 0, 0, 0, 0 };
+	const bool rowTile = i0 == p0, colTile = j0 == p0;      // this tile lies in the pivot rows / pivot columns
+	Scalar dv[4], av[4], fv[4], sv[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 	{
@@ -212,118 +208,82 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	}
 	__syncthreads();
 	TRACE_MARK();
-	Scalar (*Dcur)[GJ_B + 1] = D;
 	// The two 32 x 32 x 32 tile products on the matrix cores: wave w owns the 16 x 16 output tile (w >> 1, w & 1), eight
 	// v_mfma_f64_16x16x4_f64 k-steps each (operands straight from LDS, one number per lane: A[i = lane & 15][k = lane >> 4],
 	// B[k = lane >> 4][j = lane & 15]).  This is the one GEMM-shaped piece of the whole path.
 	const int wv = tid >> 6, lane = tid & 63;
 	const int ti = wv >> 1, tj = wv & 1;
-	// A workgroup walks over colsPerGroup column tiles (1 up to n = 768: the sweep is latency there and the grid small;
-	// more beyond).
-	for (int jt = jt0; jt < jt1; jt++)
+	// R = Dinv * Apj (not needed by the tiles of the pivot columns)
+	if (!colTile)
 	{
-		j0 = jt * GJ_B;
-		const bool colTile = j0 == p0;                      // this tile lies in the pivot columns
-		// next column tile of this workgroup: loads in flight under the products of the current one
-		Scalar avN[4], svN[4];
-		if (jt + 1 < jt1)
+		MfmaAcc acc = mfma_zero();
+#pragma unroll
+		for (int s4 = 0; s4 < GJ_B; s4 += 4)
+			acc = mfma_16x16x4(D[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+#pragma unroll
+		for (int q = 0; q < 4; q++)
 		{
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-			{
-				const size_t pr = (size_t)min(p0 + r, n - 1), gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + GJ_B + cb + 8 * u, n - 1);
-				avN[u] = src[gj * n + pr];
-				svN[u] = src[gj * n + gi];
-			}
+			const int rr = 16 * ti + mfma_row(lane, q);
+			R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
 		}
-		// R = Dinv * Apj (not needed by the tiles of the pivot columns)
-		if (!colTile)
-		{
-			MfmaAcc acc = mfma_zero();
+	}
+	__syncthreads();
+	Scalar out[4];
+	if (rowTile && colTile)
+	{
 #pragma unroll
-			for (int s4 = 0; s4 < GJ_B; s4 += 4)
-				acc = mfma_16x16x4(Dcur[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+		for (int u = 0; u < 4; u++) out[u] = dv[u];
+	}
+	else if (rowTile)
+	{
 #pragma unroll
-			for (int q = 0; q < 4; q++)
-			{
-				const int rr = 16 * ti + mfma_row(lane, q);
-				R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
-			}
-		}
+		for (int u = 0; u < 4; u++) out[u] = R[r][cb + 8 * u];
+	}
+	else
+	{
+		Scalar (*B)[GJ_B + 1] = colTile ? D : R;               // pivot columns: -F Dinv; elsewhere: S - F R
+		MfmaAcc acc = mfma_zero();
+#pragma unroll
+		for (int s4 = 0; s4 < GJ_B; s4 += 4)
+			acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+		// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
 		__syncthreads();
-		Scalar out[4];
-		if (rowTile && colTile)
-		{
 #pragma unroll
-			for (int u = 0; u < 4; u++) out[u] = dv[u];
-		}
-		else if (rowTile)
-		{
+		for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
+		__syncthreads();
 #pragma unroll
-			for (int u = 0; u < 4; u++) out[u] = R[r][cb + 8 * u];
-		}
-		else
-		{
-			Scalar (*B)[GJ_B + 1] = colTile ? Dcur : R;            // pivot columns: -F Dinv; elsewhere: S - F R
-			MfmaAcc acc = mfma_zero();
-#pragma unroll
-			for (int s4 = 0; s4 < GJ_B; s4 += 4)
-				acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
-			// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
-			__syncthreads();
-#pragma unroll
-			for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
-			__syncthreads();
-#pragma unroll
-			for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
-		}
+		for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
+	}
+	TRACE_MARK();
+	if (!ahead)
+	{
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 		{
 			const int gi = i0 + r, gj = j0 + cb + 8 * u;
-			if (!aheadRow && gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
+			if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
 		}
-		if (aheadRow)                                       // (uniform over the workgroup)
-		{
-#pragma unroll
-			for (int u = 0; u < 4; u++) keep[u] = out[u];
-		}
-		if (jt + 1 < jt1)
-		{
-			__syncthreads();                                   // every reader of Apj / R of this tile is through
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-			{
-				sv[u] = svN[u];
-				Apj[r][cb + 8 * u] = (r < bk && j0 + GJ_B + cb + 8 * u < n) ? avN[u] : Scalar(0);
-			}
-			__syncthreads();
-		}
-	}
-	TRACE_MARK();
-	// look-ahead: this workgroup produced the next pivot block -> invert it for the next launch
-	if (aheadRow)
-	{
-		const int bkN = min(GJ_B, n - pNext);
-		__syncthreads();                                       // D (the current inverse) is no longer an operand
-#pragma unroll
-		for (int u = 0; u < 4; u++)
-		{
-			const int c = cb + 8 * u;
-			keep[u] = (r < bkN && c < bkN) ? keep[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short last block
-			D[r][c] = keep[u];
-			D2[r][c] = r == c ? Scalar(1) : Scalar(0);
-		}
-		__syncthreads();
-		Scalar (*res)[GJ_B + 1] = gj_pivot_inverse(D, D2, tid, bkN);
-#pragma unroll
-		for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
 		TRACE_MARK();
-		TRACE_FLUSH(2, 8000 + (threadIdx.x >> 6));          // (kept apart: the last launch of a sweep has no look-ahead workgroup)
+		TRACE_FLUSH(2, ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) % 8000);
 		return;
 	}
+	// look-ahead: invert the next pivot block for the next launch (the chain's second array: Apj -- the operands are through)
+	const int bkN = min(GJ_B, n - pNext);
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u;
+		out[u] = (r < bkN && c < bkN) ? out[u] : (r == c ? Scalar(1) : Scalar(0));     // identity padding of a short last block
+		D[r][c] = out[u];
+		Apj[r][c] = r == c ? Scalar(1) : Scalar(0);
+	}
+	__syncthreads();
+	Scalar (*res)[GJ_B + 1] = gj_pivot_inverse(D, Apj, tid, bkN);
+#pragma unroll
+	for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
 	TRACE_MARK();
-	TRACE_FLUSH(2, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+	TRACE_FLUSH(2, 8000 + (threadIdx.x >> 6));              // (kept apart: the last launch of a sweep has no look-ahead workgroup)
 }
 
 // blocked Gauss-Jordan sweep: work0 holds the matrix on entry; returns the buffer (work0 or work1) holding the inverse.
@@ -332,16 +292,11 @@ Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots
 {
 	Scalar* src = work0; Scalar* dst = work1;
 	const int tiles = (n + GJ_B - 1) / GJ_B;
-	// column tiles per workgroup: enough workgroups to fill 256 CUs once (3 fit a CU by their LDS), no second round
-	int cols = 1;
-	if (const char* e = std::getenv("CUBA_HIP_GJ_COLS")) cols = std::max(1, std::atoi(e));
-	else while (tiles * ((tiles + cols - 1) / cols) > 768) cols++;
-	const int groups = (tiles + cols - 1) / cols;
 	Scalar* pivIn = pivots; Scalar* pivOut = pivots + GJ_B * GJ_B;
 	hipLaunchKernelGGL(dense_gj_first_pivot_kernel, dim3(1), dim3(256), 0, s, src, n, min(GJ_B, n), pivIn);
 	for (int p0 = 0; p0 < n; p0 += GJ_B)
 	{
-		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(groups, tiles + 1), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), cols, pivIn, pivOut);
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles + 1), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), pivIn, pivOut);
 		Scalar* tmp = src; src = dst; dst = tmp;
 		tmp = pivIn; pivIn = pivOut; pivOut = tmp;
 	}
