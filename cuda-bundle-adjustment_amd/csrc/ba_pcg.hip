@@ -343,44 +343,36 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 // One wave per block row (large graphs).  With two waves per row S2M / G4M need 10 000 / 20 000 waves of ~5 KB each, i.e.
 // 2.5 / 5 rounds of resident waves whose life is two dependent round trips + a barrier: the launch is bound by
 // wave slots x latency, not by bytes.  Here lane (slot, r2) = (lane / 3, lane % 3) takes block rows 2 r2 and 2 r2 + 1 of one of
-// the 20 entry slots: half the waves, twice the bytes per wave, no cross-wave exchange.  Two levels of the fixed-width row are
-// in flight at once (96 VGPRs of operands: occupancy 3); the third level, which few rows have, follows.
-template <int N>
-__device__ __forceinline__ void spmv_batch2(const DeviceSystem& sys, const Scalar* pold, const int2* e, const Scalar* Arow, int r2,
+// the 20 entry slots: half the waves, twice the bytes per wave, no cross-wave exchange.  One level of the fixed-width row per
+// step at FIVE waves per SIMD (82 VGPRs; five workgroups per CU = 1280 resident: S2M's 1250 workgroups are one round) beats
+// two levels in flight at four (120 VGPRs): S2M 16.4 -> 14.7 us, G4M 25.1 -> 23.5 us (profiles/r04s_spmv_row_occupancy.txt).
+__device__ __forceinline__ void spmv_level(const DeviceSystem& sys, const Scalar* pold, int2 e, const Scalar* Arow, int r2,
 	Scalar& az0, Scalar& ap0, Scalar& az1, Scalar& ap1)
 {
-	Scalar2 a0v[N][3], a1v[N][3], zv[N][3], pv[N][3];
+	Scalar2 a0v[3], a1v[3], zv[3], pv[3];
+	const size_t j = e.y >= 0 ? e.y : 0;
+	const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + 12 * r2);
+	const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
+	const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
+	const bool on = e.y >= 0;          // padding slots: matrix entry not fetched
 #pragma unroll
-	for (int n = 0; n < N; n++)
+	for (int c = 0; c < 3; c++)
 	{
-		const size_t j = e[n].y >= 0 ? e[n].y : 0;
-		const Scalar2* A2 = reinterpret_cast<const Scalar2*>(Arow + (size_t)n * (20 * 36) + 12 * r2);
-		const Scalar2* z2 = reinterpret_cast<const Scalar2*>(sys.z + 6 * j);
-		const Scalar2* p2 = reinterpret_cast<const Scalar2*>(pold + 6 * j);
-		const bool on = e[n].y >= 0;       // padding slots: matrix entry not fetched
-#pragma unroll
-		for (int c = 0; c < 3; c++)
-		{
-			a0v[n][c] = on ? A2[c] : Scalar2{ 0, 0 }; a1v[n][c] = on ? A2[3 + c] : Scalar2{ 0, 0 };
-			zv[n][c] = z2[c]; pv[n][c] = p2[c];
-		}
+		a0v[c] = on ? A2[c] : Scalar2{ 0, 0 }; a1v[c] = on ? A2[3 + c] : Scalar2{ 0, 0 };
+		zv[c] = z2[c]; pv[c] = p2[c];
 	}
 #pragma unroll
-	for (int n = 0; n < N; n++)
+	for (int c = 0; c < 3; c++)
 	{
-#pragma unroll
-		for (int c = 0; c < 3; c++)
-		{
-			az0 += a0v[n][c].x * zv[n][c].x; ap0 += a0v[n][c].x * pv[n][c].x;
-			az0 += a0v[n][c].y * zv[n][c].y; ap0 += a0v[n][c].y * pv[n][c].y;
-			az1 += a1v[n][c].x * zv[n][c].x; ap1 += a1v[n][c].x * pv[n][c].x;
-			az1 += a1v[n][c].y * zv[n][c].y; ap1 += a1v[n][c].y * pv[n][c].y;
-		}
+		az0 += a0v[c].x * zv[c].x; ap0 += a0v[c].x * pv[c].x;
+		az0 += a0v[c].y * zv[c].y; ap0 += a0v[c].y * pv[c].y;
+		az1 += a1v[c].x * zv[c].x; ap1 += a1v[c].x * pv[c].x;
+		az1 += a1v[c].y * zv[c].y; ap1 += a1v[c].y * pv[c].y;
 	}
 }
 
 template <int ROWS>
-__global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+__global__ __launch_bounds__(64 * ROWS, 5) void pcg_spmv_row_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, lr = threadIdx.x >> 6;
 	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
@@ -421,9 +413,9 @@ __global__ __launch_bounds__(64 * ROWS) void pcg_spmv_row_kernel(DeviceGraph g, 
 #pragma unroll
 		for (int m = 0; m < 3; m++) cnt += __any(e[m].y >= 0) ? 1 : 0;
 		const Scalar* Arow = sys.hrow + 36 * ((size_t)row * st.ell_m * 20 + slot);     // entry (row, m, slot) at + m * 20 * 36
-		if (cnt >= 2) spmv_batch2<2>(sys, pold, e, Arow, r2, az0, ap0, az1, ap1);
-		else if (cnt == 1) spmv_batch2<1>(sys, pold, e, Arow, r2, az0, ap0, az1, ap1);
-		if (cnt == 3) spmv_batch2<1>(sys, pold, e + 2, Arow + 2 * (20 * 36), r2, az0, ap0, az1, ap1);
+		if (cnt >= 1) spmv_level(sys, pold, e[0], Arow, r2, az0, ap0, az1, ap1);
+		if (cnt >= 2) spmv_level(sys, pold, e[1], Arow + 20 * 36, r2, az0, ap0, az1, ap1);
+		if (cnt == 3) spmv_level(sys, pold, e[2], Arow + 2 * (20 * 36), r2, az0, ap0, az1, ap1);
 		for (int a = a0; a < a1; a += 20)          // rows wider than the fixed part: from the upper-triangular storage
 		{
 			const int bi = st.adj_blk[a];
