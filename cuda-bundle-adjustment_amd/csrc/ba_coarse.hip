@@ -157,17 +157,20 @@ __global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar*
 	for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
 }
 
-// One blocked Gauss-Jordan step with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B: dst = GJ_step(src). After the
-// last step dst = A^-1.  One 256-thread workgroup per 32x32 output tile; thread (r, cb) owns the elements (r, cb + 8u),
-// u = 0..3, of every 32x32 array.  The step time is latency, not flops (n/32 dependent launches), so:
+// One blocked step of the symmetric sweep with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B:  with D = A_pp^-1,
+//     A_ij <- A_ij - A_ip D A_pj,   A_ip <- A_ip D,   A_pj <- D A_pj,   A_pp <- -D          (i, j != p)
+// applied to EVERY block row / column, swept before or not.  A symmetric matrix stays symmetric under it, so only the tiles
+// on and above the diagonal are computed and stored (tile (i, j), i <= j; a tile below the diagonal is read as the transpose
+// of its mirror image): half the tiles, half the bytes of the plain Gauss-Jordan sweep this replaced.  After the last step
+// the upper tiles hold -A^-1.  One 256-thread workgroup per 32x32 output tile; thread (r, cb) owns the elements
+// (r, cb + 8u), u = 0..3, of every 32x32 array.  For coarse matrices of ~1000 unknowns the step time is latency, not flops
+// (n/32 dependent launches), so:
 //   * every global load of the kernel is issued before the first use (clamped addresses, selected afterwards);
 //   * the inverse of the pivot block comes in ready-made (pivIn): the NEXT pivot block -- tile (p0/32 + 1, p0/32 + 1) is
 //     final for this purpose once step p0 has updated it -- is inverted inside this launch (look-ahead) by ONE extra
-//     workgroup (blockIdx.y = 0, dispatched first) that recomputes just that tile and goes straight into the 16-step
-//     chain: 15.9 us per step when every workgroup inverted the pivot block itself, 11.4 now;
-//   * four LDS arrays (the chain's second array reuses an operand array): four workgroups per CU, so that the n/32 x n/32
-//     tiles of a coarse matrix of ~1000 unknowns are resident at once with one tile each (several tiles per workgroup were
-//     faster only while the LDS footprint allowed three per CU);
+//     workgroup (blockIdx.x = 0, dispatched first) that recomputes just that tile and goes straight into the 16-step
+//     chain: 15.9 us per step when every workgroup inverted the pivot block itself, ~11 now;
+//   * four LDS arrays (the chain's second array reuses an operand array): four workgroups per CU;
 //   * the two 32x32x32 products run on the matrix cores.
 __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk,
 	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
@@ -180,22 +183,35 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	TRACE_DECL
 	TRACE_MARK();
 	const int pNext = p0 + GJ_B;                            // look-ahead: the tile (pNext, pNext) is the next pivot block
-	const bool ahead = blockIdx.y == 0;                     // the look-ahead workgroup; rows 1.. of the grid are the tile rows
-	if (ahead && (blockIdx.x != 0 || pNext >= n)) return;
-	const int i0 = ahead ? pNext : (blockIdx.y - 1) * GJ_B;
-	const int j0 = ahead ? pNext : blockIdx.x * GJ_B;
+	const bool ahead = blockIdx.x == 0;                     // the look-ahead workgroup; workgroups 1.. are the upper tiles, column by column
+	if (ahead && pNext >= n) return;
+	int ti, tj;
+	if (ahead) ti = tj = pNext / GJ_B;
+	else
+	{
+		const int t = blockIdx.x - 1;                       // t = tj (tj + 1) / 2 + ti, ti <= tj
+		tj = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+		while ((tj + 1) * (tj + 2) / 2 <= t) tj++;
+		while (tj * (tj + 1) / 2 > t) tj--;
+		ti = t - tj * (tj + 1) / 2;
+	}
+	const int i0 = ti * GJ_B, j0 = tj * GJ_B;
 	const int r = tid & 31, cb = tid >> 5;
 	const bool rowTile = i0 == p0, colTile = j0 == p0;      // this tile lies in the pivot rows / pivot columns
+	const bool fT = i0 > p0, gT = j0 < p0;                  // A[i, p] / A[p, j] lies below the diagonal: read the mirror tile, transposed
 	Scalar dv[4], av[4], fv[4], sv[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 	{
 		const int c = cb + 8 * u;
-		const size_t pr = (size_t)min(p0 + r, n - 1), pc = (size_t)min(p0 + c, n - 1);
+		// element (r, c) of a tile stored as is: A[row0 + r, col0 + c] = src[(col0 + c) n + row0 + r]; of the mirror tile the same
+		// expression with the two offsets swapped, landing in LDS as element (c, r)
+		const size_t gRow = (size_t)min((gT ? j0 : p0) + r, n - 1), gCol = (size_t)min((gT ? p0 : j0) + c, n - 1);
+		const size_t fRow = (size_t)min((fT ? p0 : i0) + r, n - 1), fCol = (size_t)min((fT ? i0 : p0) + c, n - 1);
 		const size_t gi = (size_t)min(i0 + r, n - 1), gj = (size_t)min(j0 + c, n - 1);
-		dv[u] = pivIn[c * GJ_B + r];   // D[r][c]   = inverse of the pivot block A[p0.., p0..]
-		av[u] = src[gj * n + pr];      // Apj[r][c] = A[p0+r, j0+c]
-		fv[u] = src[pc * n + gi];      // F[r][c]   = A[i0+r, p0+c]
+		dv[u] = pivIn[c * GJ_B + r];   // D[r][c] = inverse of the pivot block A[p0.., p0..]
+		av[u] = src[gCol * n + gRow];  // Apj = A[p0.., j0..]
+		fv[u] = src[fCol * n + fRow];  // F   = A[i0.., p0..]
 		sv[u] = src[gj * n + gi];      // own tile
 	}
 #pragma unroll
@@ -203,8 +219,11 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	{
 		const int c = cb + 8 * u;
 		D[r][c] = dv[u];
-		Apj[r][c] = (r < bk && j0 + c < n) ? av[u] : Scalar(0);
-		F[r][c] = (c < bk && i0 + r < n) ? fv[u] : Scalar(0);
+		// Apj[k][m] is live for k < bk, j0 + m < n;  F[m][k] for k < bk, i0 + m < n
+		if (gT) Apj[c][r] = (c < bk && j0 + r < n) ? av[u] : Scalar(0);
+		else Apj[r][c] = (r < bk && j0 + c < n) ? av[u] : Scalar(0);
+		if (fT) F[c][r] = (r < bk && i0 + c < n) ? fv[u] : Scalar(0);
+		else F[r][c] = (c < bk && i0 + r < n) ? fv[u] : Scalar(0);
 	}
 	__syncthreads();
 	TRACE_MARK();
@@ -212,19 +231,19 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	// v_mfma_f64_16x16x4_f64 k-steps each (operands straight from LDS, one number per lane: A[i = lane & 15][k = lane >> 4],
 	// B[k = lane >> 4][j = lane & 15]).  This is the one GEMM-shaped piece of the whole path.
 	const int wv = tid >> 6, lane = tid & 63;
-	const int ti = wv >> 1, tj = wv & 1;
+	const int wi = wv >> 1, wj = wv & 1;
 	// R = Dinv * Apj (not needed by the tiles of the pivot columns)
 	if (!colTile)
 	{
 		MfmaAcc acc = mfma_zero();
 #pragma unroll
 		for (int s4 = 0; s4 < GJ_B; s4 += 4)
-			acc = mfma_16x16x4(D[16 * ti + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+			acc = mfma_16x16x4(D[16 * wi + (lane & 15)][s4 + (lane >> 4)], Apj[s4 + (lane >> 4)][16 * wj + (lane & 15)], acc);
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 		{
-			const int rr = 16 * ti + mfma_row(lane, q);
-			R[rr][16 * tj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
+			const int rr = 16 * wi + mfma_row(lane, q);
+			R[rr][16 * wj + (lane & 15)] = rr < bk ? mfma_get(acc, q) : Scalar(0);
 		}
 	}
 	__syncthreads();
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	if (rowTile && colTile)
 	{
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = dv[u];
+		for (int u = 0; u < 4; u++) out[u] = -dv[u];
 	}
 	else if (rowTile)
 	{
@@ -241,18 +260,18 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	}
 	else
 	{
-		Scalar (*B)[GJ_B + 1] = colTile ? D : R;               // pivot columns: -F Dinv; elsewhere: S - F R
+		Scalar (*B)[GJ_B + 1] = colTile ? D : R;               // pivot columns: F Dinv; elsewhere: S - F R
 		MfmaAcc acc = mfma_zero();
 #pragma unroll
 		for (int s4 = 0; s4 < GJ_B; s4 += 4)
-			acc = mfma_16x16x4(F[16 * ti + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * tj + (lane & 15)], acc);
+			acc = mfma_16x16x4(F[16 * wi + (lane & 15)][s4 + (lane >> 4)], B[s4 + (lane >> 4)][16 * wj + (lane & 15)], acc);
 		// back to the thread -> element map of the loads / stores through LDS (Apj is free by now)
 		__syncthreads();
 #pragma unroll
-		for (int q = 0; q < 4; q++) Apj[16 * ti + mfma_row(lane, q)][16 * tj + (lane & 15)] = mfma_get(acc, q);
+		for (int q = 0; q < 4; q++) Apj[16 * wi + mfma_row(lane, q)][16 * wj + (lane & 15)] = mfma_get(acc, q);
 		__syncthreads();
 #pragma unroll
-		for (int u = 0; u < 4; u++) out[u] = colTile ? -Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
+		for (int u = 0; u < 4; u++) out[u] = colTile ? Apj[r][cb + 8 * u] : sv[u] - Apj[r][cb + 8 * u];
 	}
 	TRACE_MARK();
 	if (!ahead)
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 			if (gi < n && gj < n) dst[(size_t)gj * n + gi] = out[u];
 		}
 		TRACE_MARK();
-		TRACE_FLUSH(2, ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) % 8000);
+		TRACE_FLUSH(2, (blockIdx.x * 4 + (threadIdx.x >> 6)) % 8000);
 		return;
 	}
 	// look-ahead: invert the next pivot block for the next launch (the chain's second array: Apj -- the operands are through)
@@ -286,8 +305,9 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	TRACE_FLUSH(2, 8000 + (threadIdx.x >> 6));              // (kept apart: the last launch of a sweep has no look-ahead workgroup)
 }
 
-// blocked Gauss-Jordan sweep: work0 holds the matrix on entry; returns the buffer (work0 or work1) holding the inverse.
-// pivots: 2 x 32 x 32 numbers of scratch (the inverse of the current / of the next pivot block)
+// symmetric sweep: work0 holds the matrix on entry (its upper triangle is what is read); returns the buffer (work0 or work1)
+// whose tiles on and above the diagonal hold -A^-1 -- launch_coarse_finish / launch_coarse_to_fp32 turn that into what the
+// iteration kernels read.  pivots: 2 x 32 x 32 numbers of scratch (the inverse of the current / of the next pivot block)
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s)
 {
 	Scalar* src = work0; Scalar* dst = work1;
@@ -296,14 +316,47 @@ Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots
 	hipLaunchKernelGGL(dense_gj_first_pivot_kernel, dim3(1), dim3(256), 0, s, src, n, min(GJ_B, n), pivIn);
 	for (int p0 = 0; p0 < n; p0 += GJ_B)
 	{
-		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(tiles, tiles + 1), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), pivIn, pivOut);
+		hipLaunchKernelGGL(dense_gj_step_kernel, dim3(1 + tiles * (tiles + 1) / 2), dim3(256), 0, s, src, dst, n, p0, min(GJ_B, n - p0), pivIn, pivOut);
 		Scalar* tmp = src; src = dst; dst = tmp;
 		tmp = pivIn; pivIn = pivOut; pivOut = tmp;
 	}
 	return src;
 }
 
-// Assemble P^T A P from the (already damped) reduced matrix and invert it; returns the buffer (work0 or work1) holding the inverse.
+// swept buffer (upper triangle = -A^-1) -> full symmetric +A^-1 in dst (dst = swept: in place)
+__global__ __launch_bounds__(256) void coarse_finish_kernel(const Scalar* __restrict__ swept, Scalar* __restrict__ dst, int n)
+{
+	__shared__ Scalar tile[32][33];
+	// one workgroup per 32 x 32 tile on or above the diagonal (2D grid, the tiles below return at once): coalesced reads of
+	// the tile, coalesced writes of the tile and of its mirror image
+	if (blockIdx.x > blockIdx.y) return;
+	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32, r = threadIdx.x & 31, cb = threadIdx.x >> 5;
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u, gi = i0 + r, gj = j0 + c;
+		Scalar v = (gi < n && gj < n) ? -swept[(size_t)gj * n + gi] : Scalar(0);
+		if (blockIdx.x == blockIdx.y && r > c) v = (gi < n && gj < n) ? -swept[(size_t)gi * n + gj] : Scalar(0);   // diagonal tile: its upper half on both sides
+		tile[r][c] = v;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		const int c = cb + 8 * u;
+		if (i0 + r < n && j0 + c < n) dst[(size_t)(j0 + c) * n + i0 + r] = tile[r][c];
+		if (blockIdx.x != blockIdx.y && j0 + r < n && i0 + c < n) dst[(size_t)(i0 + c) * n + j0 + r] = tile[c][r];
+	}
+}
+
+void launch_coarse_finish(const Scalar* swept, Scalar* dst, int n, hipStream_t s)
+{
+	const int tiles = (n + 31) / 32;
+	if (n > 0) hipLaunchKernelGGL(coarse_finish_kernel, dim3(tiles, tiles), dim3(256), 0, s, swept, dst, n);
+}
+
+// Assemble P^T A P from the (already damped) reduced matrix and sweep it; returns the buffer (work0 or work1) whose upper
+// triangle holds -(P^T A P)^-1 (launch_dense_inverse).
 Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled)
 {
 	const int Nc = 6 * sys.cl * sys.nc;
@@ -313,13 +366,13 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 	return launch_dense_inverse(work0, work1, Nc, sys.gj_pivots, s);
 }
 
-// fp64 coarse inverse (n x n, column-major, symmetric up to rounding) -> fp32, symmetrised exactly, rows padded with zeros to ld
+// swept buffer (upper triangle = -A^-1, column-major) -> +A^-1 in fp32, exactly symmetric, rows padded with zeros to ld
 __global__ __launch_bounds__(256) void coarse_to_fp32_kernel(const Scalar* __restrict__ src, float* __restrict__ dst, int n, int ld)
 {
 	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (t >= (size_t)n * ld) return;
 	const int row = (int)(t / ld), j = (int)(t - (size_t)row * ld);
-	dst[t] = j < n ? (float)(Scalar(0.5) * (src[(size_t)row * n + j] + src[(size_t)j * n + row])) : 0.0f;
+	dst[t] = j < n ? -(float)src[(size_t)max(row, j) * n + min(row, j)] : 0.0f;
 }
 
 void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s)

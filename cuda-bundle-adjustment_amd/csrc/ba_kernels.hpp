@@ -168,12 +168,13 @@ void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const De
 Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, Scalar* work1, hipStream_t s, hipEvent_t assembled = nullptr);
 // blocked Gauss-Jordan inversion of a dense SPD n x n matrix (column-major in work0; work1 = scratch of the same size);
 // returns whichever of the two buffers holds the inverse
-Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // pivots: 2 x 32 x 32 numbers of scratch
+Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // symmetric sweep: the result's upper triangle holds -A^-1; pivots: 2 x 32 x 32 numbers of scratch
+void launch_coarse_finish(const Scalar* swept, Scalar* dst, int n, hipStream_t s);    // swept buffer -> full symmetric +A^-1 (dst may be the swept buffer)
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 // what the last node of an iteration graph does, as a launch: advance the iteration offset by n, run the stop test on the residual the
 // chunk left (tol2 >= 0), report to the host
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s, Scalar tol2 = Scalar(-1));
-void launch_coarse_to_fp32(const Scalar* src, float* dst, int n, hipStream_t s);   // n x n inverse -> sys.acinv32 layout
+void launch_coarse_to_fp32(const Scalar* swept, float* dst, int n, hipStream_t s);   // swept buffer -> +A^-1 in the sys.acinv32 layout
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
 
 // Adds `chunk` PCG iterations (chunk-local k = 0..chunk-1) and the kbase advance to `graph` as a chain of kernel nodes.

@@ -275,7 +275,7 @@ bool cuba_hip_solver::solveReducedOnce()
 				drainInversion();
 				(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), stream);
 				if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
-				else HIP_TRY(hipMemcpyAsync(d_coarse[2].data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, stream));
+				else launch_coarse_finish(d_coarse[0].data(), d_coarse[2].data(), 6 * sys.cl * sys.nc, stream);
 				coarseValid = true; cntCoarseRefresh++; cntCoarseInline++; sideAge = 0;
 				if (coarseFirstReuse)
 				{
@@ -302,6 +302,7 @@ bool cuba_hip_solver::solveReducedOnce()
 				HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
 				(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
 				if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[1].data(), 6 * sys.cl * sys.nc, gjStream);   // (staging: the iteration graphs read [0])
+				else launch_coarse_finish(d_coarse[0].data(), d_coarse[0].data(), 6 * sys.cl * sys.nc, gjStream);                     // (the sweep leaves -inverse in the upper triangle)
 				if (firstInvPending)
 				{
 					if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, gjStream));
@@ -589,6 +590,7 @@ void cuba_hip_solver::timeKernels(int reps, double* msOut)
 		drainInversion();
 		sys.acinv = launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream);
 		if (fp32Inverse()) launch_coarse_to_fp32(sys.acinv, d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
+		else launch_coarse_finish(sys.acinv, sys.acinv, 6 * sys.cl * sys.nc, stream);
 		coarseValid = false;
 		launch_pcg2_fused(g, sys, 0, 0, 1 << 30, -1.0, 0, stream);
 	}

@@ -468,6 +468,7 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 		w0.upload(h, nullptr); w1.resize(nn);
 		DevBuf<Scalar> piv; piv.resize(2 * 32 * 32);
 		Scalar* res = launch_dense_inverse(w0.data(), w1.data(), n, piv.data(), nullptr);
+		launch_coarse_finish(res, res, n, nullptr);
 		HIP_TRY(hipMemcpy(h.data(), res, sizeof(Scalar) * nn, hipMemcpyDeviceToHost));
 		for (size_t i = 0; i < nn; i++) Ainv[i] = (double)h[i];
 		return CUBA_HIP_OK;
