@@ -126,6 +126,8 @@ def load_library(precision="f64"):
     lib.cuba_hip_host_free.restype = None
     lib.cuba_hip_debug_dense_inverse.argtypes = [C.c_int, C.c_int, _dp, _dp]
     lib.cuba_hip_debug_dense_inverse.restype = C.c_int
+    lib.cuba_hip_debug_dense_solve.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int)]
+    lib.cuba_hip_debug_dense_solve.restype = C.c_int
     lib.cuba_hip_last_error.argtypes = [H]
     lib.cuba_hip_last_error.restype = C.c_char_p
     lib.cuba_hip_version.restype = C.c_char_p
@@ -157,6 +159,19 @@ def _close_all():
     # survive until interpreter teardown would be destroyed after the runtime's own static destructors
     for s in list(_live):
         s.close()
+
+
+def dense_solve(A, b, precision="f64", device=0):
+    """The library's exact reduced solve (dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip) applied to a symmetric
+    matrix whose order is a multiple of 6: test hook.  Returns (x, not_positive_definite)."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    flag = C.c_int()
+    rc = load_library(precision).cuba_hip_debug_dense_solve(int(device), A.shape[0], _d(A), _d(b), _d(x), C.byref(flag))
+    if rc != 0:
+        raise CubaHipError(f"cuba_hip_debug_dense_solve failed with status {rc}")
+    return x, bool(flag.value)
 
 
 class HipSolver:

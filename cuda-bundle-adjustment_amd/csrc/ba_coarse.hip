@@ -3,7 +3,7 @@
 // plus the fp32 copy the iteration kernels read.  Stands where the reference calls cuSOLVER's csrcholFactor
 // (/root/reference/src/cuda_linear_solver.cpp:147-232); runs on a second stream under the PCG of an earlier trial.
 
-#include "ba_device.hpp"
+#include "ba_mfma.hpp"
 
 namespace cubahip
 {
@@ -61,21 +61,6 @@ __global__ __launch_bounds__(256) void coarse_assemble_kernel(DeviceStructure st
 }
 
 constexpr int GJ_B = 32;      // pivot block width of the Gauss-Jordan sweep = output tile edge
-
-// 16 x 16 x 4 matrix-core step in the library's Scalar: v_mfma_f64_16x16x4_f64 (fp64 build) / v_mfma_f32_16x16x4_f32 (fp32 build).
-// Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives 4 results of column l & 15, in rows (l >> 4) + 4 q (f64)
-// or 4 (l >> 4) + q (f32), q = 0..3.
-#ifdef CUBA_HIP_FLOAT32
-typedef float MfmaAcc __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ MfmaAcc mfma_16x16x4(float a, float b, MfmaAcc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ int mfma_row(int lane, int q) { return 4 * (lane >> 4) + q; }
-#else
-typedef double MfmaAcc __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ MfmaAcc mfma_16x16x4(double a, double b, MfmaAcc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ int mfma_row(int lane, int q) { return (lane >> 4) + 4 * q; }
-#endif
-__device__ __forceinline__ MfmaAcc mfma_zero() { return MfmaAcc{ 0, 0, 0, 0 }; }
-__device__ __forceinline__ Scalar mfma_get(const MfmaAcc& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
 // Inverse of the 32 x 32 block a 256-thread workgroup holds as Dcur[r][c] in LDS (Dnext: identity outside [0, bk)^2): 2x2 block
 // pivots -- 16 dependent steps instead of 32, one reciprocal (v_rcp_f64 + two Newton steps: the pivots of an SPD matrix are
@@ -324,7 +309,9 @@ Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots
 }
 
 // swept buffer (upper triangle = -A^-1) -> full symmetric +A^-1 in dst (dst = swept: in place)
-__global__ __launch_bounds__(256) void coarse_finish_kernel(const Scalar* __restrict__ swept, Scalar* __restrict__ dst, int n)
+// (no __restrict__: the overlapped schedule runs it in place, dst == swept -- every load of a tile reaches LDS before the barrier and
+// workgroups own disjoint tile pairs, so the in-place use is well defined only WITHOUT a no-alias promise)
+__global__ __launch_bounds__(256) void coarse_finish_kernel(const Scalar* swept, Scalar* dst, int n)
 {
 	__shared__ Scalar tile[32][33];
 	// one workgroup per 32 x 32 tile on or above the diagonal (2D grid, the tiles below return at once): coalesced reads of

@@ -189,6 +189,21 @@ void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const De
 void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s,
 	const Scalar* copySrc = nullptr, Scalar* copyDst = nullptr, size_t copyCount = 0);
 
+// ---- exact reduced solve (ba_direct.hip): dense blocked Cholesky of the damped reduced matrix + triangular solves --------------
+struct DenseCholesky
+{
+	Scalar* A = nullptr;       // [(N + 160) x N] column-major: lower triangle of the matrix, the right-hand side in row N
+	Scalar* invL = nullptr;    // [N / 32][32 x 32] inverses of the diagonal tiles' Cholesky factors (row-major)
+	Scalar* y = nullptr;       // [N] work vector of the backward substitution
+	int* fail = nullptr;       // != 0 after the solve: a non-positive pivot was met (the matrix is not positive definite)
+	int n = 0, N = 0, ld = 0;  // unknowns, unknowns rounded up to 128, column stride
+};
+size_t dense_cholesky_elems(int n, int* N, int* ld);       // numbers in DenseCholesky::A for n unknowns
+// hsc (damped by launch_pcg_setup: full diagonal blocks) and bsc -> d.A; clears d.fail
+void launch_dense_fill(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const DenseCholesky& d, hipStream_t s);
+// factorise d.A in place and solve: x[0 .. n) = A^-1 b
+void launch_dense_cholesky_solve(const DenseCholesky& d, Scalar* x, hipStream_t s);
+
 // out3 = {chi2 total, landmark scale part, pose scale part} gathered from the result slots of the kernels enqueued before
 void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s);
 

@@ -217,13 +217,91 @@ void cuba_hip_solver::schur(bool withBackup)
 bool cuba_hip_solver::solveReduced()
 {
 	const bool ok = solveReducedOnce();
-	if (ok || !lastSolveBrokeDown || !fp32Inverse() || sys.agg <= 0) return ok;
+	// (only a loss of positive definiteness ALONG THE ITERATION, code 2, can come from the fp32 rounding of the coarse inverse: a NaN or a
+	// diagonal block that is not positive definite would fail with fp64 storage just the same -- round-4 advisor)
+	if (ok || !lastSolveBrokeDown || lastFailCode != 2 || !fp32Inverse() || sys.agg <= 0) return ok;
 	precondFp32 = false; sys.acinv32 = nullptr;
 	dropPcgGraph();
 	coarseValid = false; firstInvValid = false; firstInvPending = false;
 	cntFp32Fallbacks++;
 	if (std::getenv("CUBA_HIP_DEBUG")) std::fprintf(stderr, "[cuba_hip] PCG broke down with the fp32-stored coarse inverse: repeating the solve with fp64 storage\n");
-	return solveReducedOnce();
+	const int64_t directBefore = cntDirect;
+	const bool ok2 = solveReducedOnce();
+	if (!ok2 || cntDirect != directBefore)
+	{
+		// the fp64-stored inverse did not make the PCG converge either: storage precision was not the cause, the handle keeps its fp32 copy
+		precondFp32 = true; sys.acinv32 = d_coarse32[0].data();
+		dropPcgGraph();
+		coarseValid = false; firstInvValid = false; firstInvPending = false;
+	}
+	return ok2;
+}
+
+bool cuba_hip_solver::directUsable()
+{
+	return directFallback && !directRefused && Pf > 0 && 6LL * Pf <= (long long)directMaxUnknowns;
+}
+
+// PCG iterations a solve may use before it is handed to the exact solver: a THIRD of what one exact solve costs (measured on this
+// handle, or estimated: ~30 us of dependent launches per 32-column tile + n^3 / 3 flops at ~40 TFLOP/s -- KITTI-07 shape 1.5 ms,
+// KITTI-00 shape 11.7 ms).  A third, not the whole: within a run the damping shrinks and the iteration count grows from solve to solve
+// (x 1.3-2), so a solve at a third of the exact solver's cost announces solves beyond it; and the iteration count is the one measure of
+// the system's conditioning the PCG has -- pcg_tol bounds the residual, the error of the increment is up to cond(M^-1 Hsc) times larger,
+// and on the KITTI-00-size Tukey start of tests/test_ref_lm.py the solves of 370 and 800 iterations at the default tolerance are what
+// takes the run off the reference's (2.6e-5 on chi2 with them, 3e-9 when they go to the exact solver).
+int cuba_hip_solver::pcgBudget(int maxIter) const
+{
+	if (directAfter > 0) return std::min(maxIter, std::max(4, directAfter / 4 * 4));
+	const double n = 6.0 * Pf;
+	const double tDirect = directSeconds > 0 ? directSeconds : (n / 32) * 30e-6 + n * n * n / 3 / 40e12;
+	const double tIter = 10e-6 + 288.0 * (2.0 * st.nblk - Pf) / 3.5e12;
+	const double it = std::min((double)maxIter, std::max(128.0, tDirect / tIter / 3));
+	return std::max(4, (int)it / 4 * 4);
+}
+
+bool cuba_hip_solver::solveDirect()
+{
+	int N = 0, ld = 0;
+	const size_t elems = dense_cholesky_elems(6 * Pf, &N, &ld);
+	if (d_dense.size() < elems)
+	{
+		size_t freeB = 0, totalB = 0;
+		const bool fits = hipMemGetInfo(&freeB, &totalB) == hipSuccess && elems * sizeof(Scalar) + ((size_t)1 << 30) <= freeB;
+		bool got = false;
+		if (fits) { try { d_dense.resize(elems); got = true; } catch (const HipError&) { (void)hipGetLastError(); } }
+		if (!got)
+		{
+			directRefused = true;
+			char buf[200];
+			std::snprintf(buf, sizeof buf, "exact reduced solve unavailable: %.1f GB for the dense matrix of %d unknowns do not fit the free device memory", elems * sizeof(Scalar) / 1e9, 6 * Pf);
+			lastError = buf;
+			return false;
+		}
+	}
+	d_denseInvL.resize((size_t)(N / 32) * 1024); d_denseY.resize(N); d_denseFail.resize(1);
+	const auto t0 = Clock::now();
+	DenseCholesky d;
+	d.A = d_dense.data(); d.invL = d_denseInvL.data(); d.y = d_denseY.data(); d.fail = d_denseFail.data();
+	d.n = 6 * Pf; d.N = N; d.ld = ld;
+	launch_dense_fill(g, st, sys, d, stream);
+	launch_dense_cholesky_solve(d, sys.xp, stream);
+	int* hflag = (int*)hostStage();
+	HIP_TRY(hipMemcpyAsync(hflag, d.fail, sizeof(int), hipMemcpyDeviceToHost, stream));
+	sync();
+	directSeconds = std::chrono::duration<double>(Clock::now() - t0).count();
+	cntDirect++;
+	directSticky = true;
+	coarseValid = false;
+	if (std::getenv("CUBA_HIP_DEBUG"))
+		std::fprintf(stderr, "[cuba_hip] exact reduced solve: %d unknowns, %.3f ms, lambda %.3e%s\n", 6 * Pf, 1e3 * directSeconds, lambda, *hflag ? " -- NON-POSITIVE PIVOT" : "");
+	if (*hflag)
+	{
+		// the reference's failed factorisation (src/cuda_linear_solver.cpp:406-410): the LM loop rejects the trial and raises lambda
+		cntDirectFailed++;
+		lastError = "exact reduced solve: non-positive pivot (the damped reduced matrix is not positive definite)";
+		return false;
+	}
+	return true;
 }
 
 bool cuba_hip_solver::solveReducedOnce()
@@ -236,6 +314,17 @@ bool cuba_hip_solver::solveReducedOnce()
 	const Scalar tol2 = pcgTol * pcgTol;
 	if (failDirty) { d_fail.zero(stream); failDirty = false; }      // (the device flag only changes when a solve fails, and every solve reports it)
 	const bool twoLevel = sys.agg > 0;
+	const bool direct = directUsable();
+	if (direct && directSticky)
+	{
+		// an earlier solve of this run needed the exact solver: this one goes there at once (the set-up launch damps the diagonal blocks)
+		launch_pcg_setup(g, st, sys, lambda, stream);
+		coarseValid = false;
+		if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);
+		pcgHistory.push_back(0);
+		return solveDirect();
+	}
+	const int budget = direct ? pcgBudget(maxIter) : maxIter;     // iterations before the solve is handed to the exact solver
 	// an inversion that ran on the second stream under the previous trial's PCG: its result moves into the buffer the iteration
 	// graphs read within the next launch
 	const size_t invCount = (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
@@ -355,9 +444,9 @@ bool cuba_hip_solver::solveReducedOnce()
 	// (the last node of every iteration graph runs the stop test on the residual its chunk left: a batch of exactly the needed
 	// length is recognised as converged)
 	int target = (predicted + 3) / 4 * 4;
-	while (k0 < maxIter && !converged)
+	while (k0 < budget && !converged)
 	{
-		int todo = std::max(4, std::min(target, maxIter) - k0);
+		int todo = std::max(4, std::min(target, budget) - k0);
 		while (todo > 0)
 		{
 			int c = 256;
@@ -384,7 +473,21 @@ bool cuba_hip_solver::solveReducedOnce()
 		}
 		if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (graphs and chunks of plain launches end with this report)
 		waitReport();
-		if (hInts[0] != 0) { lastSolveBrokeDown = true; cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; failDirty = true; return false; }
+		if (hInts[0] != 0)
+		{
+			lastSolveBrokeDown = true; lastFailCode = hInts[0];
+			cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; failDirty = true;
+			// (code 1, a diagonal block that is not positive definite, fails a Cholesky factorisation just the same; code 2 with the
+			// fp32-stored inverse is first repeated with fp64 storage by solveReduced)
+			if (direct && lastFailCode != 1 && !(lastFailCode == 2 && fp32Inverse() && twoLevel))
+			{
+				if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);
+				pcgHistory.push_back(-hInts[1]);
+				d_fail.zero(stream); failDirty = false;
+				return solveDirect();
+			}
+			return false;
+		}
 		if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 		target = k0 + ((looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
 		looks++; cntPcgLooks++;
@@ -413,10 +516,11 @@ bool cuba_hip_solver::solveReducedOnce()
 		// the LM loop rejects the trial and raises lambda, which also makes the next system easier), unless the
 		// caller asked for the best iterate ("pcg_accept_unconverged").
 		cntPcgUnconverged++;
+		coarseValid = false;
+		if (direct && !acceptUnconverged) return solveDirect();      // exact solve instead of a failure report (ba_direct.hip)
 		char buf[160];
 		std::snprintf(buf, sizeof buf, "PCG stopped at max_iter = %d without reaching pcg_tol = %g", maxIter, pcgTol);
 		lastError = buf;
-		coarseValid = false;
 		return acceptUnconverged;
 	}
 	return true;

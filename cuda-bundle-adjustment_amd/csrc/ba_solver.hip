@@ -126,6 +126,9 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }
 		else if (k == "mixed_precision") s->mixedPrecision = value != 0 && sizeof(Scalar) == 8;
 		else if (k == "pcg_accept_unconverged") s->acceptUnconverged = value != 0;
+		else if (k == "direct_fallback") { s->directFallback = value != 0; s->directSticky = false; }
+		else if (k == "direct_after") s->directAfter = (int)value;
+		else if (k == "direct_max_unknowns") { s->directMaxUnknowns = (int)value; s->directRefused = false; }
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
@@ -313,6 +316,8 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
 		else if (k == "pcg_unconverged_solves") *value = s->cntPcgUnconverged;
 		else if (k == "pcg_graph_instantiations") *value = s->gb.builds.load();
 		else if (k == "precond_fp32_fallbacks") *value = s->cntFp32Fallbacks;
+		else if (k == "exact_solve_fallbacks") *value = s->cntDirect;
+		else if (k == "exact_solve_failures") *value = s->cntDirectFailed;
 		else if (k == "graph_uploads") *value = s->cntUploads;
 		else throw ArgError{ "unknown counter: " + k };
 	});
@@ -471,6 +476,42 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 		launch_coarse_finish(res, res, n, nullptr);
 		HIP_TRY(hipMemcpy(h.data(), res, sizeof(Scalar) * nn, hipMemcpyDeviceToHost));
 		for (size_t i = 0; i < nn; i++) Ainv[i] = (double)h[i];
+		return CUBA_HIP_OK;
+	}
+	catch (const HipError&) { return CUBA_HIP_ERR_RUNTIME; }
+}
+
+int cuba_hip_debug_dense_solve(int device, int n, const double* A, const double* b, double* x, int* not_positive_definite)
+{
+	if (n <= 0 || n % 6 != 0 || !A || !b || !x) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	if (hipSetDevice(device) != hipSuccess) return CUBA_HIP_ERR_NO_DEVICE;
+	try
+	{
+		// the matrix as the reduced system would hold it: every 6 x 6 block on or above the diagonal, one block per (row, column)
+		const int P = n / 6;
+		std::vector<Scalar> blocks; std::vector<int> blkrow, colind;
+		for (int bi = 0; bi < P; bi++)
+			for (int bj = bi; bj < P; bj++)
+			{
+				blkrow.push_back(bi); colind.push_back(bj);
+				for (int c = 0; c < 6; c++) for (int r = 0; r < 6; r++) blocks.push_back((Scalar)A[(size_t)(6 * bj + c) * n + 6 * bi + r]);
+			}
+		std::vector<Scalar> hb(b, b + n);
+		DevBuf<Scalar> dBlocks, dB, dA, dInvL, dY, dX; DevBuf<int> dRow, dCol, dFail;
+		dBlocks.upload(blocks, nullptr); dB.upload(hb, nullptr); dRow.upload(blkrow, nullptr); dCol.upload(colind, nullptr);
+		DenseCholesky d;
+		dA.resize(dense_cholesky_elems(n, &d.N, &d.ld)); dInvL.resize((size_t)(d.N / 32) * 1024); dY.resize(d.N); dFail.resize(1); dX.resize(n);
+		d.A = dA.data(); d.invL = dInvL.data(); d.y = dY.data(); d.fail = dFail.data(); d.n = n;
+		DeviceGraph g; DeviceStructure st; DeviceSystem sys;
+		st.nblk = (int)blkrow.size(); st.hsc_blkrow = dRow.data(); st.hsc_colind = dCol.data();
+		sys.hsc = dBlocks.data(); sys.bsc = dB.data();
+		launch_dense_fill(g, st, sys, d, nullptr);
+		launch_dense_cholesky_solve(d, dX.data(), nullptr);
+		std::vector<Scalar> hx(n); int flag = 0;
+		HIP_TRY(hipMemcpy(hx.data(), dX.data(), sizeof(Scalar) * n, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&flag, dFail.data(), sizeof(int), hipMemcpyDeviceToHost));
+		for (int i = 0; i < n; i++) x[i] = (double)hx[i];
+		if (not_positive_definite) *not_positive_definite = flag;
 		return CUBA_HIP_OK;
 	}
 	catch (const HipError&) { return CUBA_HIP_ERR_RUNTIME; }

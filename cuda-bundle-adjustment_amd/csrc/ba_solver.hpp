@@ -278,7 +278,7 @@ struct cuba_hip_solver
 	int topoSlot = 0;
 	std::vector<int> runIters;   // PCG iterations of the solves of the current LM run (sizes the next batch of launches)
 	std::vector<int> prevRunIters;   // ... and of the previous run on this structure: a run that repeats it solve for solve is sized from it
-	void startRunHistory() { if (!runIters.empty()) prevRunIters.swap(runIters); runIters.clear(); }
+	void startRunHistory() { if (!runIters.empty()) prevRunIters.swap(runIters); runIters.clear(); directSticky = false; }
 	int firstSolveIters = 0;     // ... and of the first solve of the previous run
 
 	double lambda = 0;
@@ -528,7 +528,28 @@ struct cuba_hip_solver
 	// ~6e-8 ||Ac^-1||, which can cost positive definiteness once lambda_max(block) / lambda_min(Ac) approaches 1e7 (weakly constrained
 	// graphs at very small damping; round-3 advisor).  Counted in "precond_fp32_fallbacks".
 	bool lastSolveBrokeDown = false;
+	int lastFailCode = 0;        // device failure code of the last PCG (1: a diagonal block is not positive definite, 2: p.Ap <= 0, 3: NaN)
 	bool solveReduced();
+
+	// Exact reduced solve (ba_direct.hip: dense blocked Cholesky on the matrix cores), the counterpart of the reference's
+	// SparseLinearSolver::solve (src/cuda_linear_solver.cpp:386-415: exact, false only on a non-positive pivot).  A solve goes there when
+	// the PCG has used its iteration budget without meeting pcg_tol, when it broke down, and -- for the rest of the LM run -- once one
+	// solve of the run had to: such systems (nearly singular Hsc: most observations of many poses at zero robust weight) are the ones an
+	// iterative solve is the wrong tool for.  Dense, hence limited in size: "direct_max_unknowns" (default 65536 = 34 GB) and the free
+	// device memory at the time of the first use; beyond, the old failure report stands (the trial is rejected like a failed
+	// factorisation of the reference).
+	bool directFallback = true;         // option "direct_fallback"
+	int directAfter = 0;                // option "direct_after": PCG iterations a solve may use before it is handed over; 0 = automatic
+	int directMaxUnknowns = 65536;      // option "direct_max_unknowns"
+	bool directSticky = false;          // a solve of the current run went to the exact solver: the run's remaining solves go there at once
+	bool directRefused = false;         // the dense matrix did not fit into the free device memory (asked once per structure)
+	double directSeconds = 0;           // host-side wall time of the last exact solve (sizes the automatic budget)
+	DevBuf<Scalar> d_dense, d_denseInvL, d_denseY;
+	DevBuf<int> d_denseFail;
+	int64_t cntDirect = 0, cntDirectFailed = 0;
+	bool directUsable();
+	int pcgBudget(int maxIter) const;
+	bool solveDirect();
 
 	bool solveReducedOnce();
 

@@ -86,8 +86,15 @@ void cuba_hip_host_free(void* p);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Options (16).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
+/* Options (19).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
+   "direct_fallback" (default 1: a reduced solve whose PCG uses up its iteration budget, breaks down, or follows such a solve in the
+   same Levenberg-Marquardt run is solved EXACTLY on the device -- dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip, the
+   role of SparseLinearSolver::solve, /root/reference/src/cuda_linear_solver.cpp:386-415 -- and fails only on a non-positive pivot
+   like the reference, :406-410; 0 = the solve is reported as failed instead), "direct_after" (PCG iterations before the hand-over;
+   default 0 = automatic: as many as one exact solve costs, at most pcg_max_iter), "direct_max_unknowns" (default 65536: the exact
+   solver is dense -- 8 (6 Pf)^2 bytes, allocated at its first use -- and is not used beyond this size or when the matrix does not fit
+   the free device memory; the failure report then stands),
    "pcg_aggregate" (poses per coarse aggregate of the two-level preconditioner; -1 = automatic: max(6, Pf/55) below 1320 free poses,
    max(16, Pf/min(180, max(115, Pf/32))) above; 0 = block-Jacobi only), "coarse_linear" (default 1: constant + linear-in-pose-index
    coarse functions per aggregate, 12 unknowns each; 0 = constant only, 6 unknowns), "precond_fp32" (fp64 library only, default 1: the
@@ -253,7 +260,8 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
    "pcg_host_looks", "pcg_iterations_enqueued", plus "coarse_inline_inversions" (coarse inversions that ran on the work stream in front
    of a solve -- the others ran on the second stream under an earlier trial's PCG), "pcg_unconverged_solves",
    "pcg_graph_instantiations" (hipGraphs of PCG iteration batches built), "precond_fp32_fallbacks" (solves repeated with the fp64
-   coarse inverse after the fp32-stored one broke the PCG down), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
+   coarse inverse after the fp32-stored one broke the PCG down), "exact_solve_fallbacks" (reduced solves that went to the exact
+   solver, see "direct_fallback"; 0 on well-conditioned graphs), "exact_solve_failures" (of these, the ones that met a non-positive pivot), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
    life of the handle, never reset: a caller that keeps state about "what the device holds" -- the promises of cuba_hip_hint_unchanged --
    stores this number with it and distrusts its state when the two differ).  Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
 int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);
@@ -263,7 +271,9 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);
    unsatisfied, *n_unconverged counts those.  Such a solve is reported as a failure (*ok = 0 from
    cuba_hip_solve_reduced / cuba_hip_solve; cuba_hip_optimize rejects the trial and raises lambda) -- the role of
    the reference's "factorize failed" path, src/cuda_linear_solver.cpp:406-410 -- unless the option
-   "pcg_accept_unconverged" = 1 asks for the best iterate to be used as an inexact step. */
+   "pcg_accept_unconverged" = 1 asks for the best iterate to be used as an inexact step, or -- the default, "direct_fallback" = 1 --
+   the exact solver takes the solve over (the entry then records the iterations the PCG had used; solves that went to the exact solver
+   straight away are recorded as 0). */
 int cuba_hip_get_pcg_history(cuba_hip_solver* s, int32_t* iterations, int capacity, int* n_solves, int64_t* n_unconverged);
 
 /* ---- introspection (parity tests) and multi-GPU plumbing ------------------------------------------ */
@@ -307,6 +317,12 @@ int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5]);
 /* Test hook for the one dense kernel of the path: the blocked Gauss-Jordan inversion (matrix-core tile products) that builds the
    coarse inverse of the two-level preconditioner.  A, Ainv: n x n, column-major, SPD input.  No solver handle involved. */
 int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ainv);
+
+/* Test hook for the exact reduced solve (csrc/ba_direct.hip: dense blocked Cholesky on the matrix cores + triangular solves), the
+   counterpart of SparseLinearSolver::solve (/root/reference/src/cuda_linear_solver.cpp:386-415).  A: n x n column-major, symmetric
+   (n a multiple of 6: it is cut into the 6 x 6 blocks of a reduced system); x = A^-1 b.  *not_positive_definite != 0 reports a
+   non-positive pivot (ref :406-410).  No solver handle involved. */
+int cuba_hip_debug_dense_solve(int device, int n, const double* A, const double* b, double* x, int* not_positive_definite);
 
 /* A driver that runs the Levenberg-Marquardt loop itself through the stage calls announces the start of a run (a new lambda_0):
    the coarse inverse of the two-level preconditioner and the iteration-count predictions of the previous run are dropped, as

@@ -223,19 +223,32 @@ def test_pcg_max_iter_is_reported(solvers):
     fp = flatten(synth_ba(200, 8000, 32000, seed=13))
     o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
     lam = 1e-7 * o.max_diagonal()
-    h = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_tol=1e-12, pcg_aggregate=0)
+    # (with the exact fallback switched off: the failure report of a handle whose reduced system is too large for the dense solver)
+    h = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_tol=1e-12, pcg_aggregate=0, direct_fallback=0)
     h.set_lambda(lam)
     assert h.solve() is False                                       # reported as a failed solve
     it, bad = h.pcg_history()
-    assert bad == 1 and it[-1] == -8
+    assert bad == 1 and it[-1] == -8 and h.counter("exact_solve_fallbacks") == 0
     h2 = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_tol=1e-12, pcg_aggregate=0, pcg_accept_unconverged=1)
     h2.set_lambda(lam)
     assert h2.solve() is True and h2.pcg_history()[1] == 1          # opt-in: best iterate, still counted
     # inside optimize() the trial is rejected and lambda raised until the system is easy enough (or the run stops)
-    h3 = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_tol=1e-9, pcg_aggregate=0)
+    h3 = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_tol=1e-9, pcg_aggregate=0, direct_fallback=0)
     chi2 = h3.optimize(3)["chi2"]
     it3, bad3 = h3.pcg_history()
     assert bad3 >= 1 and (len(chi2) == 0 or np.all(np.diff(chi2) <= 0))
+    # the default: the solve that ran out of iterations is finished EXACTLY on the device (csrc/ba_direct.hip; the reference's solve is
+    # exact, src/cuda_linear_solver.cpp:386-415) -- same increment as the exact-solve oracle, and the run follows the oracle's
+    h5 = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_tol=1e-12, pcg_aggregate=0)
+    h5.set_lambda(lam)
+    assert h5.solve() is True and h5.counter("exact_solve_fallbacks") == 1 and h5.pcg_history()[0][-1] == -8
+    o.set_lambda(lam); assert o.solve()
+    assert np.abs(h5.array("xp") - o.array("xp")).max() <= 1e-9 * np.abs(o.array("xp")).max()
+    h6 = HipSolver(fp, RK_HUBER, pcg_max_iter=8, pcg_aggregate=0)
+    got = h6.optimize(5)["chi2"]
+    want = OracleSolver(fp, RK_HUBER).optimize(5)["chi2"]
+    assert len(got) == len(want) and np.all(np.abs(got - want) <= 1e-9 * want)
+    assert h6.counter("exact_solve_fallbacks") == h6.counters()["lm_trials"] and h6.counter("exact_solve_failures") == 0
     # default settings on the same graph converge everywhere
     h4 = HipSolver(fp, RK_HUBER)
     h4.optimize(5)

@@ -184,10 +184,11 @@ def test_full_size_rejected_trials_follow_the_reference(name):
     start; the oracle must follow it to <= 1e-9 on every per-iteration chi2 with rejected trials in its record, the HIP path to
     <= 1e-8 at pcg_tol = 1e-11 and <= 1e-6 at the default tolerance, with exactly the oracle's number of trials; final estimates
     likewise.
-    The Tukey case pins the ORACLE only: with 10 m of landmark noise most observations of many poses get zero Tukey weight, the
-    reduced system is nearly singular from iteration 7 on, and the HIP path's PCG needs more than 3000 iterations per solve there
+    The Tukey case: with 10 m of landmark noise most observations of many poses get zero Tukey weight, the reduced system is nearly
+    singular from iteration 7 on, and a PCG needs more than 3000 iterations per solve there
     (profiles/r04b_tukey_rough_start_pcg_iterations.txt) -- an iterative reduced solve is the wrong tool for that system, a direct one
-    (the reference's, the oracle's) is not bothered.  The HIP path must still run it to the end without a failed call."""
+    (the reference's, the oracle's) is not bothered.  Round 5: the HIP path hands such solves to its own exact solver
+    (csrc/ba_direct.hip) and is pinned to the reference like the oracle, with the reference-vs-itself spread as the yardstick."""
     from cuba_amd.capi import HipSolver
     from oracle.oracle import OracleSolver
     make, rk, iters = rejected_trial_cases()[name]
@@ -208,15 +209,33 @@ def test_full_size_rejected_trials_follow_the_reference(name):
         ref2 = ref_lm.run(g, rk, iters)
         self_chi = float(np.abs(ref2["chi2"] / ref["chi2"] - 1).max()) if len(ref2["chi2"]) == len(ref["chi2"]) else np.inf
         self_est = {nm: float(np.abs(a - b).max()) for nm, a, b in zip("qtX", (ref2["q"], ref2["t"], ref2["Xw"]), (ref["q"], ref["t"], ref["Xw"]))}
-        h = HipSolver(fp, rk, pcg_max_iter=400); rh = h.optimize(iters)["chi2"]      # (bounded: the point is a clean run, not its speed)
+        # HIP path, default options: the solves whose PCG cannot finish within its budget are finished EXACTLY on the device
+        # (csrc/ba_direct.hip, counter "exact_solve_fallbacks"), so the trajectory is the reference's -- same trials, same chi2
+        # at the yardstick above -- and not a sequence of rejected "failed" solves (rounds 1-4)
+        hip = {}
+        for label, opts in (("hip tight", dict(pcg_tol=1e-11)), ("hip default", dict())):
+            h = HipSolver(fp, rk, **opts); rh = h.optimize(iters)["chi2"]
+            hip[label] = dict(chi=float(np.abs(rh / ref["chi2"] - 1).max()) if len(rh) == len(ref["chi2"]) else np.inf,
+                              trials=h.counters()["lm_trials"], direct=h.counter("exact_solve_fallbacks"), failed=h.counter("exact_solve_failures"),
+                              est={nm: float(np.abs(a - b).max()) for nm, a, b in zip("qtX", in_graph_order(fp, g, h.state()), (ref["q"], ref["t"], ref["Xw"]))})
+            h.close()
         print(f"\n[{name}] trials per iteration {ro['trials'].tolist()}: oracle vs the reference's own optimiser "
               + ", ".join(f"{k} {v:.2e}" for k, v in {**dev, **est}.items())
               + f"; the reference vs a second run of itself: chi2 {self_chi:.2e}, " + ", ".join(f"{k} {v:.2e}" for k, v in self_est.items())
-              + f"; HIP path: {len(rh)} iterations, {h.pcg_history()[1]} solves stopped at pcg_max_iter = 400 and were rejected")
+              + "; " + "; ".join(f"{k}: chi2 {v['chi']:.2e}, {v['trials']} trials, {v['direct']} exact solves ({v['failed']} failed), "
+                                 + ", ".join(f"{a} {b:.2e}" for a, b in v["est"].items()) for k, v in hip.items()))
         assert dev["oracle chi2"] <= max(1e-9, 10 * self_chi), (dev, self_chi)
         for nm in "qtX":
             assert est[f"oracle {nm}"] <= max(1e-7, 10 * self_est[nm]), (nm, est, self_est)
-        assert len(rh) >= 1 and np.all(np.isfinite(rh)) and np.all(np.diff(rh) <= 0)
+        for label, v in hip.items():
+            assert v["chi"] <= max(1e-8 if "tight" in label else 1e-6, 10 * self_chi), (label, v, self_chi)
+            assert v["trials"] == int(ro["trials"].sum()), (label, v["trials"], ro["trials"])
+            assert v["direct"] >= 1 and v["failed"] == 0, (label, v)
+            # (estimates: the landmarks whose observations all carry zero Tukey weight sit where the damping term alone leaves them, and ONE
+            # second run of the reference is a noisy sample of its own spread -- 2.2e-3 and 5.1e-3 m on two boxes; the default-tolerance
+            # run additionally carries the 1e-7 solves of its first four iterations through the same amplification)
+            for nm in "qtX":
+                assert v["est"][nm] <= max(1e-6 if "tight" in label else 1e-5, (10 if "tight" in label else 100) * self_est[nm]), (label, nm, v["est"], self_est)
         return
     for label, opts in (("hip tight", dict(pcg_tol=1e-11)), ("hip default", dict())):
         h = HipSolver(fp, rk, **opts); rh = h.optimize(iters)["chi2"]
