@@ -115,6 +115,78 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
+# bench-line kernel key -> kernel names in the rocprofv3 outputs (template instantiations carry their arguments in the name)
+PROFILE_NAMES = {"pcg_spmv": ["pcg_spmv_kernel", "pcg_spmv_row_kernel", "pcg_spmv_upper_kernel"], "pcg_update": ["pcg2_fused_kernel"],
+                 "residual_chi2": ["residual_chi2_kernel"], "back_substitute": ["back_substitute_kernel"],
+                 "linearize_schur": ["lm_pass_kernel<1", "schur_pass_kernel"]}
+
+
+def newest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def profile_evidence(shape, keys):
+    """What the committed rocprofv3 outputs of this shape say about the bench line's kernels: HBM-side traffic per launch (PMC
+    FETCH_SIZE / WRITE_SIZE, separate passes, profiles/*_<shape>_pmc_traffic.json: raw and fetch-doubled as MI355X_MICROARCH.md
+    prescribes for gfx950) and the kernel-trace average duration (profiles/*_<shape>_kernel_stats.csv) -- so that the line can be
+    recomputed without opening profiles/ (round-4 verdict).  A kernel key that stands for two kernels (linearise + Schur) gets sums;
+    of several instantiations of one name the most-launched one counts."""
+    import csv
+    import re
+    ev = {"pmc_file": None, "stats_file": None, "stale": None, "kernels": {}}
+    pmc_path, stats_path = newest_profile(f"*_{shape}_pmc_traffic.json"), newest_profile(f"*_{shape}_kernel_stats.csv")
+    pk, sk = {}, {}
+    if pmc_path:
+        pj = json.load(open(pmc_path))
+        pk = pj["kernels"]
+        ev["pmc_file"] = os.path.basename(pmc_path)
+        ev["stale"] = pj.get("kernel_source_sha16") != source_sha16()
+    if stats_path:
+        ev["stats_file"] = os.path.basename(stats_path)
+        for row in csv.DictReader(open(stats_path)):
+            nm = re.sub(r"\(.*", "", row["Name"]).replace("cubahip::", "").replace("void ", "").strip()
+            sk[nm] = {"launches": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
+
+    def find(table, name):
+        hits = [v for k, v in table.items() if k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name))]
+        return max(hits, key=lambda v: v["launches"]) if hits else None
+    for key in keys:
+        rec = {}
+        names = PROFILE_NAMES.get(key, [])
+        if key == "linearize_schur":
+            groups = [[n] for n in names]                 # two kernels, both counted
+        else:
+            groups = [names]                             # alternatives: the one that ran
+        pm = [next((f for f in (find(pk, n) for n in g) if f), None) for g in groups]
+        if pm and all(pm):
+            rec["traffic"] = sum(f["hbm_bytes_fetch_x2"] for f in pm)
+            rec["traffic_raw"] = sum(f["hbm_bytes_raw"] for f in pm)
+        stt = [next((f for f in (find(sk, n) for n in g) if f), None) for g in groups]
+        if stt and all(stt):
+            rec["rocprof_avg_ms"] = sum(f["avg_ns"] for f in stt) * 1e-6
+        if rec:
+            ev["kernels"][key] = rec
+    return ev
+
+
+def kernel_table(kt, alg, evidence):
+    """per-kernel records of a roofline leg: HIP-event time, algorithmic bytes, achieved GB/s + the profile evidence"""
+    table = {}
+    for k, ms in kt.items():
+        if ms <= 0 or k not in alg:
+            continue
+        rec = {"ms_per_launch": ms, "alg_bytes": alg[k], "achieved_GBs": alg[k] / (ms * 1e-3) / 1e9}
+        e = evidence["kernels"].get(k, {})
+        rec.update(e)
+        if "traffic" in e:
+            rec["traffic_over_alg"] = e["traffic"] / alg[k]
+            rec["traffic_raw_over_alg"] = e["traffic_raw"] / alg[k]
+        table[k] = rec
+    return table
+
+
 PERTURB = {"sigma_t_m": 0.01, "sigma_X_m": 0.01, "sigma_r_deg": 0.05}
 HEURISTICS = ("coarse_first_reuse", "pcg_repeat_prediction", "pcg_exact_batch_graphs")
 
@@ -189,7 +261,27 @@ def shapes_leg(rk, device_index, stream, names=("kitti07", "s2m", "g4m"), runs=3
                         "wall_ms_10iter_replay": float(np.median(replay)) * 1e3,
                         "runs": runs, "edge_iterations_per_s": fp.E * LM_RUN / med, "pcg_iterations_per_run": int(np.median(iters)),
                         "hsc_blocks": h.counters()["hsc_blocks"], "coarse_dim": h.counters()["coarse_dim"],
-                        "unconverged_solves": h.pcg_history()[1]})
+                        "unconverged_solves": h.pcg_history()[1], "exact_solve_fallbacks": h.counter("exact_solve_fallbacks")})
+            # roofline of this shape: HIP-event time of each hot kernel on the solver's stream, its algorithmic bytes, and what the
+            # committed rocprofv3 outputs of the shape say (traffic, kernel-trace average).  The kernel named is the SpMV -- the one
+            # bandwidth-bound kernel of the path on the large shapes -- whichever kernel has the largest share is given beside it.
+            try:
+                c = h.counters()
+                kt = {k: v for k, v in h.time_kernels(reps=10).items() if v > 0}
+                alg = algorithmic_bytes(fp, c["hsc_blocks"], c["coarse_dim"] / 6.0 if kt.get("coarse_setup", 0) > 0 else 0)
+                ev = profile_evidence(name, list(kt))
+                table = kernel_table(kt, alg, ev)
+                it_per_run = int(np.median(iters))
+                share = {"pcg_spmv": it_per_run, "pcg_update": it_per_run}
+                dom = max(share, key=lambda k: share[k] * kt.get(k, 0))
+                sp = table.get("pcg_spmv")
+                if sp:
+                    rec["roofline"] = {"bound": "hbm", "kernel": "pcg_spmv", "achieved": sp["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": sp["achieved_GBs"] / HBM_PEAK_GBS, "traffic": sp.get("traffic"), "alg_bytes_per_launch": sp["alg_bytes"],
+                                       "ms_per_launch": sp["ms_per_launch"], "largest_share": dom, "traffic_source": ev["pmc_file"],
+                                       "traffic_stale": ev["stale"], "rocprof_source": ev["stats_file"], "kernels": table}
+            except Exception as e:   # noqa: BLE001
+                rec["roofline"] = {"error": repr(e)[:200]}
             if name == "kitti07" and cpu:
                 cpu_jobs.append((name, fp, got, (q1, t1, X1)))
             h.close()
@@ -353,6 +445,7 @@ def main():
         c = solver.counters()
         c["coarse_inline_inversions"] = solver.counter("coarse_inline_inversions")
         c["pcg_graph_instantiations"] = solver.counter("pcg_graph_instantiations")
+        c["exact_solve_fallbacks"] = solver.counter("exact_solve_fallbacks")
         if native is not None:
             c["lm_trials"] = native.counters()["lm_trials"]      # the native driver runs the trial loop, not the solver handle
         return c
@@ -408,32 +501,20 @@ def main():
         launches["coarse_setup"] = c1["coarse_inline_inversions"] - c0["coarse_inline_inversions"]
         share = {k: kt[k] * launches[k] for k in kt}
         dom = max(share, key=share.get)
-        kernels = {k: {"ms_per_launch": kt[k], "launches": launches[k], "alg_bytes": alg[k],
-                       "achieved_GBs": alg[k] / (kt[k] * 1e-3) / 1e9} for k in kt}
+        # measured HBM-side traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md
+        # prescribes for gfx950, the raw sum beside it) and the kernel-trace average duration of EVERY kernel of the table, from the
+        # newest committed profiles of this shape (written by scripts/profile_round.sh).  They are profiles of an EARLIER run of this
+        # command, so the traffic file is checked against the running build: it records the hash of the kernel sources it was taken
+        # with (scripts/pmc_traffic.py); a file from other sources is still quoted but flagged `traffic_stale`.
+        ev = profile_evidence(args.shape, list(kt))
+        kernels = kernel_table(kt, alg, ev)
+        for k in kernels:
+            kernels[k]["launches"] = launches[k]
         if "coarse_setup" in kernels:
             kernels["coarse_setup"]["launches_on_second_stream"] = refreshes - launches["coarse_setup"]
-        # measured HBM-side traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, see
-        # the newest profiles/*_kitti00_pmc_traffic.json, written by scripts/profile_round.sh; FETCH_SIZE doubled as
-        # MI355X_MICROARCH.md prescribes for gfx950)
-        # The file is a profile of an EARLIER run of this command, so it is checked against the running build: it records the hash of
-        # the kernel sources it was taken with (scripts/pmc_traffic.py) and must name the dominant kernel's launches; a file from
-        # other sources is still quoted but flagged `traffic_stale` (round-2 verdict: it used to go stale silently).
-        import glob
-        traffic, traffic_stale = None, None
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kitti00_pmc_traffic.json")), key=os.path.getmtime)
-        pmc_path = pmc_files[-1] if pmc_files else ""
-        pmc_names = {"pcg_spmv": ["pcg_spmv_kernel"], "pcg_update": ["pcg2_fused_kernel"], "residual_chi2": ["residual_chi2_kernel"],
-                     "back_substitute": ["back_substitute_kernel"], "linearize_schur": ["lm_pass_kernel<1", "schur_pass_kernel"]}   # (exact names match first)
-        if args.shape == "kitti00" and os.path.exists(pmc_path) and dom in pmc_names:
-            pj = json.load(open(pmc_path))
-            pk = pj["kernels"]
-            def find(name):          # template instantiations carry their arguments in the name: match the exact name or "name<...>"
-                hits = [v for k, v in pk.items() if k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name))]
-                return max(hits, key=lambda v: v["launches"]) if hits else None
-            found = [find(n) for n in pmc_names[dom]]
-            if all(f is not None for f in found):
-                traffic = sum(f["hbm_bytes_fetch_x2"] for f in found)
-                traffic_stale = pj.get("kernel_source_sha16") != source_sha16()
+        traffic = kernels[dom].get("traffic")
+        traffic_stale = ev["stale"] if traffic is not None else None
+        pmc_path = ev["pmc_file"] or ""
         # whole hot path: B_alg(trial) = 120 E3 + 96 E2 + 288 L + 2 * 288 nblk, achieved = B_alg x trials / t_hot.
         # The PCG's re-reads of the (L2 / Infinity-Cache resident) reduced matrix are deliberately NOT counted as HBM bytes.
         b_trial = 120 * fp.E3 + 96 * fp.E2 + 288 * fp.Lt + 2 * 288 * nblk
@@ -445,7 +526,8 @@ def main():
                         % (round(2 * pcg_iters / max(trials, 1)) + 12, b_trial * trials / 6.3e12 * 1e3)}
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "traffic_source": os.path.basename(pmc_path) if traffic else None,
+                "alg_bytes_per_launch": alg[dom], "ms_per_launch": kt[dom], "rocprof_avg_ms": kernels[dom].get("rocprof_avg_ms"),
+                "traffic_source": os.path.basename(pmc_path) if traffic else None, "rocprof_source": ev["stats_file"],
                 "traffic_stale": traffic_stale, "kernel_source_sha16": source_sha16(),
                 "kernels": kernels, "path": path}
         out = {
@@ -466,6 +548,7 @@ def main():
             "pcg_host_looks": c1["pcg_host_looks"] - c0["pcg_host_looks"], "coarse_refreshes": c1["coarse_refreshes"] - c0["coarse_refreshes"],
             "lm_trials": trials, "hsc_blocks": nblk, "schur_products": c1["schur_products"],
             "coarse_inline_inversions": c1["coarse_inline_inversions"] - c0["coarse_inline_inversions"],
+            "exact_solve_fallbacks": c1["exact_solve_fallbacks"] - c0["exact_solve_fallbacks"],
             "pcg_graph_instantiations_in_timed_region": c1["pcg_graph_instantiations"] - c0["pcg_graph_instantiations"],
             "final_chi2": float(chi2[-1]),
             "protocol": {"timed_runs": "each optimize(%d) from its own seeded perturbation of the warm state" % LM_RUN, **PERTURB,

@@ -126,6 +126,11 @@ struct DeviceSystem
 	                           // indexed by the workgroup's position inside its aggregate (P^T q is summed from these:
 	                           // aggregates are whole multiples of spmv_rows rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
+	// upper-triangle iteration (large graphs; ba_pcg.hip): three launches per iteration straight from the upper-triangular BSR storage
+	int upper = 0;
+	Scalar* tq = nullptr;      // [6 * (nblk - Pf)] transposed products B^T p_i of the off-diagonal blocks, written by the SpMV in the order of the rows that
+	                           // own them: the lower neighbours of row j are one contiguous range
+	int* lowpos = nullptr;     // [nblk] position of every off-diagonal block in that order (launch_build_lowpos)
 };
 
 // residual / robust chi2 over all edges -> sys.slots[0..NSLOT) (must be zeroed by the caller).
@@ -171,6 +176,10 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // symmetric sweep: the result's upper triangle holds -A^-1; pivots: 2 x 32 x 32 numbers of scratch
 void launch_coarse_finish(const Scalar* swept, Scalar* dst, int n, hipStream_t s);    // swept buffer -> full symmetric +A^-1 (dst may be the swept buffer)
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
+// one iteration of the upper-triangle form (sys.upper): which = 1 SpMV | 2 row updates | 4 preconditioner (7 = all three, in this order)
+int spmv_upper_grid(int Pf);      // workgroups of the upper-triangle SpMV (= its p.Ap partials)
+void launch_build_lowpos(const DeviceGraph& g, const DeviceStructure& st, int* lowpos, hipStream_t s);
+void launch_pcg_upper_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s, int which = 7);
 // what the last node of an iteration graph does, as a launch: advance the iteration offset by n, run the stop test on the residual the
 // chunk left (tol2 >= 0), report to the host
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s, Scalar tol2 = Scalar(-1));

@@ -459,14 +459,17 @@ bool cuba_hip_solver::solveReducedOnce()
 			{
 				if ((pcgGraphs.count(std::make_pair(todo, (const Scalar*)sys.acinv)) || ++batchRequests[todo] >= 2) && pcgGraphIfReady(todo, maxIter, tol2)) c = todo;
 			}
+			// (another handle is being driven right now: plain launches -- see g_activeCalls; the graphs are still ordered, for later)
+			const bool alone = g_activeCalls.load(std::memory_order_relaxed) <= 1;
 			hipGraphExec_t exec = useGraph ? pcgGraphIfReady(c, maxIter, tol2) : nullptr;
+			if (!alone) exec = nullptr;
 			if (exec) { HIP_TRY(hipGraphLaunch(exec, stream)); noteReport(); }     // (every graph reports; the host waits for the last)
 			else if (useGraph)
 			{
 				// the same chunk as plain launches: chunk-local iteration numbers + the advance / stop test / report node
 				for (int k = 0; k < c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				launch_pcg_advance(sys, c, stream, tol2); noteReport();
-				eagerIters += c;
+				eagerIters += c; cntPcgPlain += c;
 			}
 			else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 			k0 += c; todo -= c;
@@ -688,7 +691,7 @@ void cuba_hip_solver::timeKernels(int reps, double* msOut)
 	d_fail.zero(stream);
 	d_kbase.zero(stream);
 	launch_pcg_setup(g, st, sys, lam, stream);
-	launch_hsc_expand(g, st, sys, stream);
+	if (!sys.upper) launch_hsc_expand(g, st, sys, stream);
 	if (sys.agg > 0)
 	{
 		drainInversion();
@@ -698,11 +701,21 @@ void cuba_hip_solver::timeKernels(int reps, double* msOut)
 		coarseValid = false;
 		launch_pcg2_fused(g, sys, 0, 0, 1 << 30, -1.0, 0, stream);
 	}
-	msOut[2] = timeit([&] { launch_pcg_spmv(g, st, sys, 0, 1 << 30, -1.0, stream); });
+	if (sys.upper) msOut[2] = timeit([&] { launch_pcg_upper_iteration(g, st, sys, 0, 1 << 30, -1.0, stream, 1); });
+	else msOut[2] = timeit([&] { launch_pcg_spmv(g, st, sys, 0, 1 << 30, -1.0, stream); });
 	if (sys.agg > 0)
 	{
-		msOut[3] = timeit([&] { launch_pcg2_fused(g, sys, 0, 1, 1 << 30, -1.0, 1, stream); });
-		msOut[5] = 0;
+		// (upper-triangle iteration: row updates + preconditioner, the two launches that stand where the fused kernel does)
+		if (sys.upper)
+		{
+			msOut[3] = timeit([&] { launch_pcg_upper_iteration(g, st, sys, 0, 1 << 30, -1.0, stream, 2); });
+			msOut[5] = timeit([&] { launch_pcg_upper_iteration(g, st, sys, 0, 1 << 30, -1.0, stream, 4); });
+		}
+		else
+		{
+			msOut[3] = timeit([&] { launch_pcg2_fused(g, sys, 0, 1, 1 << 30, -1.0, 1, stream); });
+			msOut[5] = 0;
+		}
 		msOut[6] = timeit([&] { launch_coarse_setup(g, st, sys, d_coarse[0].data(), d_coarse[1].data(), stream); });
 	}
 	else

@@ -41,7 +41,7 @@ __device__ __forceinline__ void pcg_setup_body(const DeviceGraph& g, const Devic
 			}
 #pragma unroll
 		for (int k = 0; k < 36; k++) blk[k] = A[k];   // full symmetric diagonal block, damping included
-		if (ROWCOPY)
+		if (ROWCOPY && !sys.upper)
 		{
 			// adjacency of a row = its lower neighbours, then its own blocks, the diagonal one first
 			const int pos = (st.adj_ptr[i + 1] - st.adj_ptr[i]) - (st.hsc_rowptr[i + 1] - st.hsc_rowptr[i]);
@@ -183,7 +183,7 @@ void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, co
 	const Scalar* copySrc, Scalar* copyDst, size_t copyCount)
 {
 	if (g.Pf <= 0) return;
-	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
+	const size_t total = sys.upper ? 0 : (size_t)g.Pf * st.ell_m * 20 * 36;      // (the upper-triangle iteration reads the BSR storage itself)
 	const int nSetup = (g.Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES;
 	const unsigned nExpand = (unsigned)((total + 255) / 256);
 	const size_t pairs = copySrc ? copyCount / 2 : 0;            // (coarse dimensions are even)
@@ -547,7 +547,10 @@ template <typename T, int W> struct InvVec;
 template <typename T> struct InvVec<T, 2> { typedef T type __attribute__((ext_vector_type(2))); };
 template <typename T> struct InvVec<T, 4> { typedef T type __attribute__((ext_vector_type(4))); };
 
-template <int CL, int AC, int AC2, int W>
+// PRE = true: the preconditioner alone -- third launch of the upper-triangle iteration (large graphs, below): the residual and P^T r
+// of iteration k + 1 are already in place (pcg_rows_kernel), so this instantiation only applies M^-1 to them and forms r.z
+// (doUpdate = 1 at run time; alpha = 0, no partial sums of P^T q, nothing of x / r / P^T r is stored).
+template <int CL, int AC, int AC2, int W, bool PRE = false>
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
@@ -569,9 +572,9 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;
 	// the residual is double-buffered: other workgroups still read r_k of this aggregate while its owner stores r_{k+1}
-	const Scalar* rin = (k & 1) ? sys.r2 : sys.r;
+	const Scalar* rin = ((k & 1) != 0) != PRE ? sys.r2 : sys.r;              // (PRE: what pcg_rows_kernel of this iteration stored)
 	Scalar* rout = (k & 1) ? sys.r : sys.r2;
-	const Scalar* rcin = sys.rc + ((k & 1) ? Nc : 0);
+	const Scalar* rcin = sys.rc + (((k & 1) != 0) != PRE ? Nc : 0);
 	Scalar* rcout = sys.rc + ((doUpdate != 0) == ((k & 1) != 0) ? 0 : Nc);    // doUpdate = 0 stores P^T r_0 where k = 0 reads it
 	const int I = blockIdx.x;
 	TRACE_DECL
@@ -600,14 +603,14 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	{
 		if (t < sys.nrz) e_k = rz_slot(sys, k)[t];
 		if (t < sys.nrz0) e_0 = sys.rz[t];
-		if (t < sys.npq) e_q0 = pq_slot(sys, k)[t];
-		if (t + PCG2_T < sys.npq) e_q1 = pq_slot(sys, k)[t + PCG2_T];
+		if (!PRE && t < sys.npq) e_q0 = pq_slot(sys, k)[t];
+		if (!PRE && t + PCG2_T < sys.npq) e_q1 = pq_slot(sys, k)[t + PCG2_T];
 	}
 	if (t < ownN)
 	{
 		const size_t gi = (size_t)own0 + t;
 		pre_r = rin[gi];
-		if (doUpdate) { pre_q = sys.ap[gi]; pre_p = p[gi]; pre_x = sys.xp[gi]; }
+		if (doUpdate && !PRE) { pre_q = sys.ap[gi]; pre_p = p[gi]; pre_x = sys.xp[gi]; }
 		const size_t pose = gi / 6; const int comp = (int)(gi - 6 * pose);
 #pragma unroll
 		for (int c = 0; c < 6; c++) pre_m[c] = sys.minv[36 * pose + c * 6 + comp];
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		sr = *reinterpret_cast<const Scalar2*>(rcin + 2 * t);
 #pragma unroll
 		for (int m = 0; m < QV; m++)      // (m < per is uniform over the grid; sets of workgroups that do not exist stay zero)
-			if (m < per) qv[m] = *reinterpret_cast<const Scalar2*>(sys.qpart + (size_t)m * Nc + 2 * t);
+			if (!PRE && m < per) qv[m] = *reinterpret_cast<const Scalar2*>(sys.qpart + (size_t)m * Nc + 2 * t);
 	}
 #pragma unroll
 	for (int a = 0; a < AR; a++)
@@ -638,13 +641,13 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	{
 		for (int u = t + PCG2_T; u < sys.nrz; u += PCG2_T) a_k += rz_slot(sys, k)[u];
 		for (int u = t + PCG2_T; u < sys.nrz0; u += PCG2_T) a_0 += sys.rz[u];
-		for (int u = t + 2 * PCG2_T; u < sys.npq; u += PCG2_T) a_q += pq_slot(sys, k)[u];
+		if (!PRE) for (int u = t + 2 * PCG2_T; u < sys.npq; u += PCG2_T) a_q += pq_slot(sys, k)[u];
 	}
 	if (t < ownN) { rown[t] = pre_r; qown[t] = pre_q; }
 	for (int w = t + PCG2_T; w < ownN; w += PCG2_T)
 	{
 		rown[w] = rin[own0 + w];
-		qown[w] = doUpdate ? sys.ap[own0 + w] : Scalar(0);
+		qown[w] = doUpdate && !PRE ? sys.ap[own0 + w] : Scalar(0);
 	}
 	// restricted sums P^T r_k and P^T q_k (fixed summation order => reproducible)
 	if (doUpdate)
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 				for (int m = 0; m < QV; m++) s2 += qv[m];
 			}
 			else s1 = *reinterpret_cast<const Scalar2*>(rcin + 2 * pj);
-			for (int m0 = pj == t ? QV : 0; m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
+			for (int m0 = pj == t ? QV : 0; !PRE && m0 < per; m0 += QV)      // further unknowns of this thread (large graphs): QV loads per trip
 			{
 				Scalar2 qx[QV];
 				const Scalar* src = sys.qpart + (size_t)m0 * Nc + 2 * pj;
@@ -721,12 +724,15 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }
 			return;
 		}
-		if (!(pqk > 0))
+		if (!PRE)
 		{
-			if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
-			return;
+			if (!(pqk > 0))
+			{
+				if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;
+				return;
+			}
+			alpha = rzk / pqk;
 		}
-		alpha = rzk / pqk;
 	}
 	TRACE_MARK();
 	// ---- own rows: r_{k+1}, x_{k+1} ---------------------------------------------------------------------------
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	{
 		const Scalar r = rown[w] - alpha * qown[w];      // rown[w] / qown[w] were written by this very thread
 		rown[w] = r;
-		if (doUpdate)
+		if (doUpdate && !PRE)
 		{
 			rout[own0 + w] = r;
 			sys.xp[own0 + w] = (w == ow ? pre_x : sys.xp[own0 + w]) + alpha * (w == ow ? pre_p : p[own0 + w]);
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 			if (j < Nc)
 			{
 #pragma unroll
-				for (int i = 0; i < W; i++) acc += (Scalar)ainv[a][m][i] * (sR[j + i] - alpha * sQ[j + i]);
+				for (int i = 0; i < W; i++) acc += (Scalar)ainv[a][m][i] * (PRE ? sR[j + i] : sR[j + i] - alpha * sQ[j + i]);
 			}
 		}
 		if (AC2 > 0 && Nc > 64 * W * AC)
@@ -766,12 +772,12 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 				if (j < Nc)
 				{
 #pragma unroll
-					for (int i = 0; i < W; i++) acc += (Scalar)ainv2[a][m][i] * (sR[j + i] - alpha * sQ[j + i]);
+					for (int i = 0; i < W; i++) acc += (Scalar)ainv2[a][m][i] * (PRE ? sR[j + i] : sR[j + i] - alpha * sQ[j + i]);
 				}
 			}
 		}
 		if (row < CD)
-			for (int j = lane + 64 * W * (AC + AC2); j < Nc; j += 64) acc += (Scalar)acinv[(size_t)(CD * I + row) * ld + j] * (sR[j] - alpha * sQ[j]);
+			for (int j = lane + 64 * W * (AC + AC2); j < Nc; j += 64) acc += (Scalar)acinv[(size_t)(CD * I + row) * ld + j] * (PRE ? sR[j] : sR[j] - alpha * sQ[j]);
 		acc = wave_sum(acc);
 		if (lane == 0 && row < CD) yc[row] = acc;
 	}
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	if (lane == 0) wsum[24 + wv] = dot;
 	// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves: 8 interleaved partial
 	// sums per coarse unknown here, folded after the barrier (a single thread per unknown would chain `agg` LDS reads)
-	if (t < 8 * CD)
+	if (!PRE && t < 8 * CD)
 	{
 		const int u = t % CD, h = t / CD, a = u / 6, c = u - 6 * a;
 		Scalar s3 = 0;
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 		part[t] = s3;
 	}
 	__syncthreads();
-	if (t >= 64 && t < 64 + CD)
+	if (!PRE && t >= 64 && t < 64 + CD)
 	{
 		const int u = t - 64;
 		Scalar s3 = 0;
@@ -824,19 +830,21 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
 }
 
-static void* pcg2_kernel_for(const DeviceSystem& sys)
+template <bool PRE>
+static void* pcg2_kernel_sel(const DeviceSystem& sys)
 {
 	const int Nc = 6 * sys.cl * sys.nc;
 	if (sys.acinv32 && sizeof(Scalar) == 8)
 	{
 		// fp32 storage of the coarse inverse: a 16-byte load carries 4 columns, 3 / 6 / 6 + 3 loads per lane and row cover 768 / 1536 / 2304
-		if (sys.cl == 2) return Nc <= 768 ? (void*)pcg2_fused_kernel<2, 3, 0, 4> : Nc <= 1536 ? (void*)pcg2_fused_kernel<2, 6, 0, 4> : (void*)pcg2_fused_kernel<2, 6, 3, 4>;
-		return Nc <= 768 ? (void*)pcg2_fused_kernel<1, 3, 0, 4> : Nc <= 1536 ? (void*)pcg2_fused_kernel<1, 6, 0, 4> : (void*)pcg2_fused_kernel<1, 6, 3, 4>;
+		if (sys.cl == 2) return Nc <= 768 ? (void*)pcg2_fused_kernel<2, 3, 0, 4, PRE> : Nc <= 1536 ? (void*)pcg2_fused_kernel<2, 6, 0, 4, PRE> : (void*)pcg2_fused_kernel<2, 6, 3, 4, PRE>;
+		return Nc <= 768 ? (void*)pcg2_fused_kernel<1, 3, 0, 4, PRE> : Nc <= 1536 ? (void*)pcg2_fused_kernel<1, 6, 0, 4, PRE> : (void*)pcg2_fused_kernel<1, 6, 3, 4, PRE>;
 	}
 	const bool small = Nc <= 768;
-	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0, 2> : (void*)pcg2_fused_kernel<2, 12, 6, 2>;
-	return small ? (void*)pcg2_fused_kernel<1, 6, 0, 2> : (void*)pcg2_fused_kernel<1, 12, 6, 2>;
+	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0, 2, PRE> : (void*)pcg2_fused_kernel<2, 12, 6, 2, PRE>;
+	return small ? (void*)pcg2_fused_kernel<1, 6, 0, 2, PRE> : (void*)pcg2_fused_kernel<1, 12, 6, 2, PRE>;
 }
+static void* pcg2_kernel_for(const DeviceSystem& sys, bool precondOnly = false) { return precondOnly ? pcg2_kernel_sel<true>(sys) : pcg2_kernel_sel<false>(sys); }
 
 static size_t pcg2_lds_bytes(const DeviceSystem& sys)
 {
@@ -849,6 +857,302 @@ void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int
 {
 	const size_t lds = pcg2_lds_bytes(sys);
 	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Upper-triangle iteration (large graphs: sys.upper != 0).  There the two PCG kernels above are bound by bytes, and half of
+// them are redundant: the SpMV reads both triangles of the symmetric matrix from its row-ordered copy (G4M: 104 MB moved per launch for
+// 48 MB of matrix), and every workgroup of the two-level kernel adds up all row-sum partials of q = A p (43 MB) -- which it needs only
+// because a kernel that also updates r cannot know P^T r_{k+1} of the OTHER aggregates.  Three launches instead of two:
+//   pcg_spmv_upper_kernel   one wave per block row i, straight from the upper-triangular BSR storage (diagonal block first, blocks
+//                           contiguous): for every block (i, j) the product B p_j goes into q_i and the transposed product B^T p_i
+//                           -- which belongs to row j -- into tq[block] (48 bytes per block); p.Ap = sum_i p_i.(D p_i + 2 sum_j B p_j)
+//                           needs no completed row
+//   pcg_rows_kernel         one workgroup per aggregate: q_j = ap_j + sum of the tq of row j's lower neighbours (fixed order: the
+//                           adjacency list), x += alpha p, r -= alpha q, and P^T r_{k+1} of the aggregate from the updated rows
+//   pcg2_fused_kernel<PRE>  z = blockdiag^-1 r + P Ac^-1 P^T r, r.z
+// Every matrix byte is read once, no row-sum partials exist, the row-ordered copy (and its 9-us expand per solve) is gone.
+// ---------------------------------------------------------------------------------------------------
+// sums over the lanes 0..31 and over the lanes 32..63 of a wave, each handed to its own half (DPP row reductions; fixed order)
+__device__ __forceinline__ Scalar half_wave_sum(Scalar v, bool upperHalf)
+{
+	v += dpp_shift<0x111, 0xf>(v);   // row_shr:1
+	v += dpp_shift<0x112, 0xf>(v);   // row_shr:2
+	v += dpp_shift<0x114, 0xf>(v);   // row_shr:4
+	v += dpp_shift<0x118, 0xf>(v);   // row_shr:8
+	v += dpp_shift<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+	union { Scalar s; int w[sizeof(Scalar) / 4]; } u, lo, hi;
+	u.s = v;
+#pragma unroll
+	for (int i = 0; i < (int)(sizeof(Scalar) / 4); i++) { lo.w[i] = __builtin_amdgcn_readlane(u.w[i], 31); hi.w[i] = __builtin_amdgcn_readlane(u.w[i], 63); }
+	return upperHalf ? hi.s : lo.s;
+}
+
+// NS steps of five blocks each of one block row: lane (grp, c) of the row's half-wave takes column c of block s0 + 5 s + grp
+template <int NS>
+__device__ __forceinline__ void upper_steps(const DeviceStructure& st, const DeviceSystem& sys, const Scalar* pold, int s0, int b0, int b1, int grp, int c,
+	Scalar beta, const Scalar (&pi)[6], Scalar (&acc)[6], Scalar& dotT)
+{
+	int bb[NS], j[NS], lp[NS]; bool on[NS];               // (32-bit indices: 36 x nblk stays below 2^31 for every graph the handle accepts)
+	Scalar2 v[NS][3]; Scalar zj[NS], pjo[NS];
+#pragma unroll
+	for (int s = 0; s < NS; s++)
+	{
+		const int b = s0 + 5 * s + grp;
+		on[s] = grp < 5 && b < b1;
+		bb[s] = on[s] ? b : b0;
+	}
+#pragma unroll
+	for (int s = 0; s < NS; s++) { j[s] = st.hsc_colind[bb[s]]; lp[s] = sys.lowpos[bb[s]]; }
+#pragma unroll
+	for (int s = 0; s < NS; s++)
+	{
+		const Scalar2* B2 = reinterpret_cast<const Scalar2*>(sys.hsc + (36 * (size_t)bb[s] + 6 * c));      // column c of the block: B[0..5][c]
+		v[s][0] = B2[0]; v[s][1] = B2[1]; v[s][2] = B2[2];
+	}
+#pragma unroll
+	for (int s = 0; s < NS; s++) { zj[s] = sys.z[6 * (size_t)j[s] + c]; pjo[s] = pold[6 * (size_t)j[s] + c]; }
+#pragma unroll
+	for (int s = 0; s < NS; s++)
+	{
+		const Scalar pj = on[s] ? zj[s] + beta * pjo[s] : Scalar(0);
+		const Scalar Bc[6] = { v[s][0].x, v[s][0].y, v[s][1].x, v[s][1].y, v[s][2].x, v[s][2].y };
+		Scalar t = 0;
+#pragma unroll
+		for (int r = 0; r < 6; r++) { acc[r] += Bc[r] * pj; t += Bc[r] * pi[r]; }
+		if (on[s] && bb[s] != b0)                            // (the diagonal block is its own transpose: its product is the gather above)
+		{
+			sys.tq[6 * (size_t)lp[s] + c] = t;               // (where row j will look for it: position of this block among ITS lower neighbours)
+			dotT += pj * t;                                   // p_j . B^T p_i = p_i . B p_j: the mirrored block's share of p . A p
+		}
+	}
+}
+
+// TWO block rows per wave (lanes 0..31 / 32..63; five blocks of six lanes per step and row), UPPER_WAVES waves per workgroup: half the
+// waves of a row-per-wave kernel -- the launch is bound by wave dispatch (~1 wave per ns) and by the dependent round trips of a wave's
+// life (row pointers + reduction scalars, column indices, operands), not by the bytes per wave -- and one set of reduction scalars
+// serves two rows.  Twenty blocks per row in flight (rows of the large shapes hold ~17), the rest in further trips; four waves per SIMD (fifteen blocks in
+// flight at five waves per SIMD, every wave of G4M resident at once, is slower: 18.5 vs 17.2 us -- the operand phase is bound by the
+// memory-side cache's ~4.5 TB/s, not by latency: profiles/r05h_*).
+constexpr int UPPER_WAVES = 4;
+constexpr int UPPER_ROWS = 2 * UPPER_WAVES;       // block rows per workgroup (= number of p.Ap partials: sys.npq)
+__global__ __launch_bounds__(64 * UPPER_WAVES, 4) void pcg_spmv_upper_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const bool hi = lane >= 32;
+	const int hl = lane & 31;
+	const Scalar* pold = (k & 1) ? sys.p1 : sys.p0;
+	Scalar* pnew = (k & 1) ? sys.p0 : sys.p1;
+	const int lr = 2 * wv + (hi ? 1 : 0);
+	const int row = blockIdx.x * UPPER_ROWS + lr;
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	const Scalar s_k = load_parts(rz_slot(sys, k), sys.nrz, lane);
+	const Scalar s_0 = load_parts(sys.rz, sys.nrz0, lane);
+	const Scalar s_m = load_parts(rz_slot(sys, k - 1), sys.nrz, lane);
+	const bool rowOn = row < g.Pf;
+	const int grp = hl / 6, c = hl - 6 * grp;              // lanes 30, 31 of a half: grp 5 -> idle
+	TRACE_DECL
+	TRACE_MARK();
+	int b0 = 0, b1 = 0;
+	if (rowOn) { b0 = st.hsc_rowptr[row]; b1 = st.hsc_rowptr[row + 1]; }
+	Scalar zi[6], pio[6];
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+	{
+		zi[r] = rowOn ? sys.z[6 * (size_t)row + r] : Scalar(0);
+		pio[r] = rowOn ? pold[6 * (size_t)row + r] : Scalar(0);
+	}
+	TRACE_MARK();
+	k += __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	const Scalar rzk = to_uniform(wave_sum(s_k)), rz0 = to_uniform(wave_sum(s_0)), rzm = to_uniform(wave_sum(s_m));
+	if (!(k < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))   // uniform over the grid
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }   // NaN: reported as a failed solve
+		return;
+	}
+	const Scalar beta = k > 0 ? rzk / rzm : Scalar(0);
+	Scalar pi[6];
+#pragma unroll
+	for (int r = 0; r < 6; r++) pi[r] = zi[r] + beta * pio[r];
+	Scalar acc[6] = { 0, 0, 0, 0, 0, 0 };
+	Scalar dotT = 0;
+	// (trip counts of the wave = those of its longer row: the other half idles through masked steps)
+	const int nb = b1 - b0;
+	const int nbMax = max(__builtin_amdgcn_readlane(nb, 0), __builtin_amdgcn_readlane(nb, 32));
+	int done = 0;
+	for (; done + 10 < nbMax; done += 20) upper_steps<4>(st, sys, pold, b0 + done, b0, b1, grp, c, beta, pi, acc, dotT);
+	if (done + 5 < nbMax) upper_steps<2>(st, sys, pold, b0 + done, b0, b1, grp, c, beta, pi, acc, dotT);
+	else if (done < nbMax) upper_steps<1>(st, sys, pold, b0 + done, b0, b1, grp, c, beta, pi, acc, dotT);
+	TRACE_MARK();
+	Scalar qv[6];
+#pragma unroll
+	for (int r = 0; r < 6; r++) qv[r] = half_wave_sum(acc[r], hi);
+	Scalar dot = half_wave_sum(dotT, hi);
+#pragma unroll
+	for (int r = 0; r < 6; r++) dot += pi[r] * qv[r];      // (uniform over the half-wave)
+	if (rowOn && hl < 6)
+	{
+		Scalar q = qv[0], pr = pi[0];
+#pragma unroll
+		for (int r = 1; r < 6; r++) { q = hl == r ? qv[r] : q; pr = hl == r ? pi[r] : pr; }
+		pnew[6 * (size_t)row + hl] = pr;
+		sys.ap[6 * (size_t)row + hl] = q;
+	}
+	__shared__ Scalar part[UPPER_ROWS];
+	if (hl == 0) part[lr] = rowOn ? dot : Scalar(0);
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		Scalar s2 = 0;
+#pragma unroll
+		for (int w = 0; w < UPPER_ROWS; w++) s2 += part[w];
+		pq_slot(sys, k)[blockIdx.x] = s2;
+	}
+	TRACE_MARK();
+	TRACE_FLUSH(0, blockIdx.x * UPPER_WAVES + wv);
+}
+
+// second launch of the upper-triangle iteration: one workgroup per aggregate
+constexpr int ROWS_T = 512;
+__global__ __launch_bounds__(ROWS_T) void pcg_rows_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	extern __shared__ __align__(16) unsigned char rows_lds[];
+	Scalar* rown = reinterpret_cast<Scalar*>(rows_lds);      // [6 agg] updated residual of the own rows
+	Scalar* part = rown + 6 * sys.agg;                       // [8][12]
+	Scalar* wsum = part + 96;                                // [3][8]
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6, I = blockIdx.x;
+	const int CD = 6 * sys.cl, Nc = CD * sys.nc;
+	const Scalar* p = (k & 1) ? sys.p0 : sys.p1;              // what the SpMV of this iteration wrote
+	const Scalar* rin = (k & 1) ? sys.r2 : sys.r;
+	Scalar* rout = (k & 1) ? sys.r : sys.r2;
+	Scalar* rcout = sys.rc + ((k & 1) ? 0 : Nc);
+	TRACE_DECL
+	TRACE_MARK();
+	const int kb_v = vector_load_flag(sys.kbase);
+	const int failed_v = vector_load_flag(sys.fail) | vector_load_flag(sys.done);
+	Scalar a_k = 0, a_0 = 0, a_q = 0;
+	for (int u = t; u < sys.nrz; u += ROWS_T) a_k += rz_slot(sys, k)[u];
+	for (int u = t; u < sys.nrz0; u += ROWS_T) a_0 += sys.rz[u];
+	{
+		// (G4M: 2500 partials of p.Ap -- four independent loads per trip)
+		const Scalar* pq = pq_slot(sys, k);
+		int u = t;
+		Scalar q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+		for (; u + 3 * ROWS_T < sys.npq; u += 4 * ROWS_T) { const Scalar x0 = pq[u], x1 = pq[u + ROWS_T], x2 = pq[u + 2 * ROWS_T], x3 = pq[u + 3 * ROWS_T]; q0 += x0; q1 += x1; q2 += x2; q3 += x3; }
+		for (; u < sys.npq; u += ROWS_T) q0 += pq[u];
+		a_q = (q0 + q1) + (q2 + q3);
+	}
+	const int own0 = 6 * I * sys.agg;
+	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
+	// completed rows of q = A p: the SpMV's share + the transposed products of the lower neighbours, in adjacency order
+	Scalar qrow[2] = { 0, 0 }, rrow[2] = { 0, 0 }, prow[2] = { 0, 0 }, xrow[2] = { 0, 0 };      // (aggregates of up to 170 poses: two entries per thread)
+#pragma unroll
+	for (int e = 0; e < 2; e++)
+	{
+		const int w = t + e * ROWS_T;
+		if (w >= ownN) break;
+		const size_t gi = (size_t)own0 + w;
+		const int pose = (int)(gi / 6), comp = (int)(gi - 6 * (size_t)pose);
+		const int a0 = st.adj_ptr[pose];
+		const int nlow = (st.adj_ptr[pose + 1] - a0) - (st.hsc_rowptr[pose + 1] - st.hsc_rowptr[pose]);
+		Scalar q = sys.ap[gi];
+		rrow[e] = rin[gi]; prow[e] = p[gi]; xrow[e] = sys.xp[gi];
+		// (the SpMV left them in this row's own order: one contiguous range, no index list; 16 per trip -- one trip for most rows)
+		const Scalar* tin = sys.tq + 6 * (size_t)(a0 - st.hsc_rowptr[pose]) + comp;
+		for (int a = 0; a < nlow; a += 16)
+		{
+			Scalar tv[16];
+#pragma unroll
+			for (int m = 0; m < 16; m++) tv[m] = tin[6 * (size_t)min(a + m, nlow - 1)];
+#pragma unroll
+			for (int m = 0; m < 16; m++) q += a + m < nlow ? tv[m] : Scalar(0);
+		}
+		qrow[e] = q;
+	}
+	TRACE_MARK();
+	a_k = wave_sum(a_k); a_0 = wave_sum(a_0); a_q = wave_sum(a_q);
+	if (lane == 0) { wsum[wv] = a_k; wsum[8 + wv] = a_0; wsum[16 + wv] = a_q; }
+	__syncthreads();
+	TRACE_MARK();
+	const int kabs = k + __builtin_amdgcn_readfirstlane(kb_v);
+	const int failed = __builtin_amdgcn_readfirstlane(failed_v);
+	Scalar rzk = 0, rz0 = 0, pqk = 0;
+#pragma unroll
+	for (int w = 0; w < ROWS_T / 64; w++) { rzk += wsum[w]; rz0 += wsum[8 + w]; pqk += wsum[16 + w]; }
+	if (!(kabs < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }
+		return;
+	}
+	if (!(pqk > 0))
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0) *sys.fail = 2;   // not positive definite along p
+		return;
+	}
+	const Scalar alpha = rzk / pqk;
+#pragma unroll
+	for (int e = 0; e < 2; e++)
+	{
+		const int w = t + e * ROWS_T;
+		if (w >= ownN) break;
+		const Scalar r = rrow[e] - alpha * qrow[e];
+		rown[w] = r;
+		rout[own0 + w] = r;
+		sys.xp[own0 + w] = xrow[e] + alpha * prow[e];
+	}
+	__syncthreads();
+	// P^T r_{k+1} of the own aggregate: 8 interleaved partial sums per coarse unknown, folded after the barrier
+	if (t < 8 * CD)
+	{
+		const int u = t % CD, h = t / CD, a = u / 6, c = u - 6 * a;
+		Scalar s3 = 0;
+		for (int il = h; 6 * il + c < ownN; il += 8)
+			s3 += (a == 0 ? Scalar(1) : agg_weight_local(I, il, sys, g.Pf)) * rown[6 * il + c];
+		part[t] = s3;
+	}
+	__syncthreads();
+	if (t < CD)
+	{
+		Scalar s3 = 0;
+#pragma unroll
+		for (int h = 0; h < 8; h++) s3 += part[CD * h + t];
+		rcout[CD * I + t] = s3;
+	}
+	TRACE_MARK();
+	TRACE_FLUSH(2, blockIdx.x * (ROWS_T / 64) + wv);
+}
+
+// lowpos[b] for every off-diagonal block b = (i, j): its position among the lower neighbours of row j, counted over all rows (the
+// SpMV parks B^T p_i there, pcg_rows_kernel reads the range of row j)
+__global__ __launch_bounds__(256) void build_lowpos_kernel(DeviceStructure st, int Pf, int* __restrict__ lowpos)
+{
+	const int row = blockIdx.x * 256 + threadIdx.x;
+	if (row >= Pf) return;
+	const int a0 = st.adj_ptr[row];
+	const int nlow = (st.adj_ptr[row + 1] - a0) - (st.hsc_rowptr[row + 1] - st.hsc_rowptr[row]);
+	const int base = a0 - st.hsc_rowptr[row];
+	for (int a = 0; a < nlow; a++) lowpos[st.adj_blk[a0 + a] & 0x7fffffff] = base + a;
+}
+
+void launch_build_lowpos(const DeviceGraph& g, const DeviceStructure& st, int* lowpos, hipStream_t s)
+{
+	if (g.Pf > 0) hipLaunchKernelGGL(build_lowpos_kernel, dim3((g.Pf + 255) / 256), dim3(256), 0, s, st, g.Pf, lowpos);
+}
+
+static void* spmv_upper_kernel_for(const DeviceSystem&) { return (void*)pcg_spmv_upper_kernel; }
+int spmv_upper_grid(int Pf) { return (Pf + UPPER_ROWS - 1) / UPPER_ROWS; }
+static size_t rows_lds_bytes(const DeviceSystem& sys) { return sizeof(Scalar) * (6 * (size_t)sys.agg + 96 + 24); }
+
+void launch_pcg_upper_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s, int which)
+{
+	typedef void (*K3)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar);
+	if (which & 1) hipLaunchKernelGGL((K3)spmv_upper_kernel_for(sys), dim3(spmv_upper_grid(g.Pf)), dim3(64 * UPPER_WAVES), 0, s, g, st, sys, k, maxIter, tol2);
+	if (which & 2) hipLaunchKernelGGL(pcg_rows_kernel, dim3(sys.nc), dim3(ROWS_T), rows_lds_bytes(sys), s, g, st, sys, k, maxIter, tol2);
+	if (which & 4)
+		hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(PCG2_T), pcg2_lds_bytes(sys), s,
+			g, sys, k, k + 1, maxIter, tol2, 1);
 }
 
 static bool spmv_wants_occupancy(const DeviceGraph& g) { return 2 * (long long)g.Pf > 3 * 1024; }   // two waves per row vs 1024 SIMDs x occupancy 3
@@ -954,6 +1258,13 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 	hipError_t e = hipSuccess;
 	for (int k = 0; k < chunk && e == hipSuccess; k++)
 	{
+		if (sys.upper && sys.agg > 0)
+		{
+			e = add_kernel_node(graph, last, spmv_upper_kernel_for(sys), dim3(spmv_upper_grid(g.Pf)), dim3(64 * UPPER_WAVES), 0, g, st, sys, k, maxIter, tol2);
+			if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_rows_kernel, dim3(sys.nc), dim3(ROWS_T), (unsigned)rows_lds_bytes(sys), g, st, sys, k, maxIter, tol2);
+			if (e == hipSuccess) e = add_kernel_node(graph, last, pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(PCG2_T), (unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
+			continue;
+		}
 		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)

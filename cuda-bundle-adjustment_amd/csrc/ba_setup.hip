@@ -696,8 +696,20 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); d_gjPivots.resize(2 * 32 * 32); sys.gj_pivots = d_gjPivots.data();
 	sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 	d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
-	d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
-	d_hrow.zero(stream);         // (padding slots are never written)
+	sys.upper = agg > 0 && (spmvUpper < 0 ? spmvRows == 4 : spmvUpper != 0) ? 1 : 0;
+	if (sys.upper)
+	{
+		d_tq.resize((size_t)6 * nblk); sys.tq = d_tq.data(); d_hrow.release(); sys.hrow = nullptr;
+		d_lowpos.resize((size_t)nblk); sys.lowpos = d_lowpos.data();
+		DeviceGraph gg; gg.Pf = Pf;
+		launch_build_lowpos(gg, st, d_lowpos.data(), stream);
+		sys.npq = spmv_upper_grid(Pf);          // (fewer p.Ap partials than the row-sum SpMV leaves: the rings are sized for those)
+	}
+	else
+	{
+		d_hrow.resize((size_t)36 * 20 * ellM * Pf); sys.hrow = d_hrow.data();
+		d_hrow.zero(stream);         // (padding slots are never written)
+	}
 	sys.spmv_rows = spmvRows;
 	sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 	sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;

@@ -10,14 +10,18 @@ using namespace cubahip;
 // -----------------------------------------------------------------------------------------------------
 // C ABI
 // -----------------------------------------------------------------------------------------------------
+namespace cubahip_host { std::atomic<int> g_activeCalls{ 0 }; }
+
 namespace
 {
 std::string g_createError;
+struct CallScope { CallScope() { g_activeCalls.fetch_add(1, std::memory_order_relaxed); } ~CallScope() { g_activeCalls.fetch_sub(1, std::memory_order_relaxed); } };
 
 template <typename F>
 int guarded(cuba_hip_solver* s, F&& f)
 {
 	if (!s) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	CallScope scope;
 	try
 	{
 		if (hipSetDevice(s->device) != hipSuccess) { s->lastError = "hipSetDevice failed"; return CUBA_HIP_ERR_RUNTIME; }
@@ -131,6 +135,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "direct_max_unknowns") { s->directMaxUnknowns = (int)value; s->directRefused = false; }
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
+		else if (k == "spmv_upper") { s->spmvUpper = (int)value; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
 		else throw ArgError{ "unknown option: " + k };
@@ -316,6 +321,7 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
 		else if (k == "pcg_unconverged_solves") *value = s->cntPcgUnconverged;
 		else if (k == "pcg_graph_instantiations") *value = s->gb.builds.load();
 		else if (k == "precond_fp32_fallbacks") *value = s->cntFp32Fallbacks;
+		else if (k == "pcg_iterations_plain_launches") *value = s->cntPcgPlain;
 		else if (k == "exact_solve_fallbacks") *value = s->cntDirect;
 		else if (k == "exact_solve_failures") *value = s->cntDirectFailed;
 		else if (k == "graph_uploads") *value = s->cntUploads;

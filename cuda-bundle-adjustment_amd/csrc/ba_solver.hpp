@@ -95,6 +95,13 @@ private:
 
 using Clock = std::chrono::steady_clock;
 
+// Calls into the library that are in flight right now, over all handles of the process (every C-ABI entry point counts itself in and
+// out).  More than one = several handles are driven concurrently from distinct host threads; the reduced solve then enqueues its PCG
+// batches as plain launches instead of hipGraph launches: graph launches of two streams serialise against each other on this runtime
+// (two KITTI-00 graphs side by side: 15.4 / 11.7 ms per run as graphs, 8.9 / 9.4 ms as plain launches, 6.8 ms alone:
+// profiles/r05c_concurrent_handles_first_look.txt), and the two forms give bit-identical results.
+extern std::atomic<int> g_activeCalls;
+
 }  // namespace cubahip_host
 using namespace cubahip_host;
 
@@ -110,6 +117,9 @@ struct cuba_hip_solver
 	int pcgMaxIter = 0;          // 0 = automatic
 	int coarseLinear = 1;        // 1: constant + linear coarse functions per aggregate (12 unknowns), 0: constant only (6)
 	int pcgAggregate = -1;       // poses per coarse aggregate: -1 automatic, 0 = block-Jacobi only
+	int spmvUpper = -1;          // option "spmv_upper": three-launch PCG iteration on the upper-triangular storage (ba_pcg.hip): -1 = automatic
+	                             // (graphs whose SpMV is bound by bytes: more than 1536 free poses), 0 / 1 = off / on
+	DevBuf<Scalar> d_tq; DevBuf<int> d_lowpos;
 	// device-side set-up (ba_structure.hip): the edge sort and the whole symbolic structure are built on the GPU; the host
 	// pipeline below stays as the independent cross-check ("device_setup" = 0) and for graphs without edges
 	bool deviceSetup = true;
@@ -233,7 +243,8 @@ struct cuba_hip_solver
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
 	{
-		if (sys.agg > 0)
+		if (sys.agg > 0 && sys.upper) launch_pcg_upper_iteration(g, st, sys, k, maxIter, tol2, s);
+		else if (sys.agg > 0)
 		{
 			launch_pcg_spmv(g, st, sys, k, maxIter, tol2, s);
 			launch_pcg2_fused(g, sys, k, k + 1, maxIter, tol2, 1, s);
@@ -285,6 +296,7 @@ struct cuba_hip_solver
 	int maxIterAlloc = 0;
 	long long nmul = 0;
 	int64_t cntPcgIters = 0, cntTrials = 0, cntCoarseRefresh = 0, cntPcgLooks = 0, cntPcgEnqueued = 0, cntPcgUnconverged = 0;
+	int64_t cntPcgPlain = 0;          // PCG iterations enqueued as plain launches while hipGraphs were switched on (graph not built yet, or another handle active)
 	int64_t cntCoarseInline = 0;      // coarse inversions that ran on the WORK stream (in front of a solve), a subset of cntCoarseRefresh
 	int64_t cntFp32Fallbacks = 0;     // solves repeated with the fp64 coarse inverse after the fp32-stored one broke the PCG down
 	int64_t cntUploads = 0;           // successful cuba_hip_set_graph calls on this handle (never reset: identifies what the device holds)

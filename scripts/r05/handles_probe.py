@@ -48,7 +48,7 @@ for group in ([h1, h2], [h1, h2, h3, h4]):
         bar.wait()
         for _ in range(7):
             h.restore_state(); t = time.perf_counter(); chi = h.optimize(10)["chi2"]; ts.append(time.perf_counter() - t)
-        res[i] = (1e3 * float(np.median(ts)), chi)
+        res[i] = (1e3 * float(np.median(ts)), chi, h.counter("pcg_iterations_plain_launches"), h.counter("pcg_iterations_enqueued"))
     th = [threading.Thread(target=work, args=(i,)) for i in range(len(group))]
     for t in th: t.start()
     bar.wait(); t0 = time.perf_counter()
@@ -56,7 +56,7 @@ for group in ([h1, h2], [h1, h2, h3, h4]):
     wall = time.perf_counter() - t0
     rate = len(group) * 7 * 10 * E / wall
     print(f"  {len(group)} graphs concurrently: per-graph median " + ", ".join(f"{r[0]:.3f}" for r in res) + f" ms; aggregate {rate / 1e6:.0f} M edge-iterations/s = {rate / (10 * E / (solo * 1e-3)):.2f} x one graph; "
-          + f"bit-identical to solo: {all(np.array_equal(r[1], chi_solo) for r in res)}", flush=True)
+          + f"bit-identical to solo: {all(np.array_equal(r[1], chi_solo) for r in res)}; plain-launch / enqueued iterations so far " + ", ".join(f"{r[2]}/{r[3]}" for r in res), flush=True)
 h2.close(); h3.close(); h4.close()
 a, _ = timed(h1)
 print(f"  after closing the others: {a:.3f} ms ({a / solo:.2f} x)", flush=True)

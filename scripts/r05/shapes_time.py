@@ -1,0 +1,28 @@
+"""round 5: wall of optimize(10) on the large shapes (bench protocol: warm-up iteration, perturbed starts) with and without an option.
+   python scripts/r05/shapes_time.py s2m spmv_upper=0     (one handle per process)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from cuba_amd.capi import HipSolver
+from cuba_amd.graph import flatten
+from cuba_amd.synth import synth_named
+RK = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
+shape = sys.argv[1]
+opts = {k: float(v) for k, v in (a.split("=") for a in sys.argv[2:] if "=" in a)}
+fp = flatten(synth_named(shape))
+h = HipSolver(fp, RK, **opts)
+chi = h.optimize(10)["chi2"]
+h.set_state(fp.q, fp.t, fp.Xw); h.optimize(1)
+n = bench.prepare_slots(h, fp, h.state(), 4, seed=1000)
+def timed(slot):
+    h.restore_state(slot); c0 = h.counters(); t = time.perf_counter(); h.optimize(10); dt = time.perf_counter() - t
+    return 1e3 * dt, h.counters()["pcg_iterations"] - c0["pcg_iterations"]
+timed(n)
+w = [timed(1 + k) for k in range(3)]
+timed(0); r = [timed(0) for _ in range(3)]
+kt = h.time_kernels(10)
+print(f"{shape} {opts}: perturbed {np.median([x[0] for x in w]):.2f} ms ({int(np.median([x[1] for x in w]))} PCG iterations), replay {np.median([x[0] for x in r]):.2f} ms; "
+      f"chi2[-1] {chi[-1]:.9e}; kernels (us): " + ", ".join(f"{k} {1e3 * v:.1f}" for k, v in kt.items() if v > 0), flush=True)
+h.close()

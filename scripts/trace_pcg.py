@@ -20,9 +20,11 @@ from cuba_amd.synth import synth_named  # noqa: E402
 shape = sys.argv[1] if len(sys.argv) > 1 else "kitti00"
 fp = flatten(synth_named(shape))
 rk = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
-h = capi.HipSolver(fp, rk)
+opts = {k: float(v) for k, v in (a.split("=") for a in sys.argv[2:] if "=" in a)}      # e.g. spmv_upper=1
+h = capi.HipSolver(fp, rk, **opts)
 h.build_structure()
 h.optimize(3)
+upper = opts.get("spmv_upper", -1) == 1 or (opts.get("spmv_upper", -1) < 0 and fp.Pf > 1536)
 lib = capi.load_library("f64")
 buf = np.zeros((3, 8192, 8), dtype=np.uint64)
 rc = lib.cuba_hip_debug_read_trace(buf.ctypes.data_as(C.c_void_p))          # the PCG translation unit's stamps (kernels 0, 1)
@@ -30,12 +32,19 @@ assert rc == 0, rc
 gj = np.zeros((3, 8192, 8), dtype=np.uint64)
 rc = lib.cuba_hip_debug_read_trace_coarse(gj.ctypes.data_as(C.c_void_p))    # the coarse translation unit's (kernel 2)
 assert rc == 0, rc
-buf[2] = gj[2]
-for kid, name, stages in ((0, "pcg_spmv", ["entry", "indices+scalars", "operands", "fold+barrier", "end"]),
+if upper:
+    # the upper-triangle iteration: kernel 0 = pcg_spmv_upper, 1 = the preconditioner-only instantiation of the fused kernel, 2 = pcg_rows
+    table = ((0, "pcg_spmv_upper", ["entry", "scalars+row pointers", "operands + products", "reductions + stores"]),
+             (2, "pcg_rows", ["entry", "loads landed (q rows complete)", "barrier (alpha)", "end"]),
+             (1, "pcg2_fused<PRE>", ["entry", "loads landed", "restricted sums", "barrier 1", "barrier yc", "end"]))
+else:
+    buf[2] = gj[2]
+    table = None
+for kid, name, stages in table or ((0, "pcg_spmv", ["entry", "indices+scalars", "operands", "fold+barrier", "end"]),
                           (1, "pcg2_fused", ["entry", "loads landed", "restricted sums", "barrier 1", "barrier yc", "end"]),
                           (2, "dense_gj_step (last launch that has a look-ahead workgroup... the last step has none)", ["entry", "tile loads", "tiles done", "end (look-ahead chain in one workgroup)"])):
     t = buf[kid].astype(np.int64)
-    if kid == 2:
+    if kid == 2 and not upper:
         la = t[8000:8004]
         print("dense_gj_step, look-ahead workgroup (4 waves): ns since entry at [loads, tiles done, chain done]:",
               [[int((w[s] - w[0]) * 10) for s in (1, 2, 3)] for w in la if w[0] > 0])

@@ -288,7 +288,7 @@ def test_shuffled_pose_ids(solvers, name):
     assert bad == 0
     ho = HipSolver(fp_ord, RK_HUBER); ho.optimize(10)
     it_ord = ho.pcg_history()[0]
-    hn = HipSolver(fp, RK_HUBER, pose_reorder=0); hn.optimize(10)
+    hn = HipSolver(fp, RK_HUBER, pose_reorder=0, direct_fallback=0); hn.optimize(10)      # (the PCG alone: no hand-over to the exact solver)
     it_raw = hn.pcg_history()[0]
     print(f"\n[{name}] PCG iterations per solve: id-ordered {it_ord.tolist()}  shuffled {it.tolist()}  shuffled, pose_reorder=0 {np.abs(it_raw).tolist()}")
     assert it.sum() <= 1.15 * it_ord.sum()                           # the walk recovers the trajectory
@@ -328,7 +328,7 @@ def test_shuffled_pose_ids_stage_outputs_keep_the_callers_numbering(solvers):
     assert all(np.array_equal(a, b) for a, b in zip(h.state(), (q0, t0, X0)))
     # the renumbering really was active: at weak damping the caller's order needs several times the iterations
     h.set_lambda(1e-9 * md); assert h.solve()
-    hn = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, pose_reorder=0); hn.set_lambda(1e-9 * md); assert hn.solve()
+    hn = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, pose_reorder=0, direct_fallback=0); hn.set_lambda(1e-9 * md); assert hn.solve()
     assert 1.2 * h.pcg_history()[0][-1] < hn.pcg_history()[0][-1], (h.pcg_history()[0], hn.pcg_history()[0])
     # a landmark partition set on a renumbered handle: back to the caller's order, same results as a fresh handle
     ref = OracleSolver(fp, RK_HUBER).optimize(3)["chi2"]

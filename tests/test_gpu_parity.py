@@ -391,7 +391,7 @@ def test_preconditioner_modes_agree(solvers, small_fp):
     o.set_lambda(lam); assert o.solve()
     its = {}
     for agg in (0, 16, 5, 2):      # 2 poses per aggregate: coarse dimension 600 > one workgroup of the two-level kernel
-        h = HipSolver(fp, RK_HUBER, pcg_aggregate=agg, pcg_tol=1e-11)
+        h = HipSolver(fp, RK_HUBER, pcg_aggregate=agg, pcg_tol=1e-11, direct_fallback=0)      # (iteration counts of the PCG itself)
         h.set_lambda(lam); assert h.solve()
         assert rel(h.array("xp"), o.array("xp")) < 1e-6 and rel(h.array("xl"), o.array("xl")) < 1e-6
         its[agg] = h.counters()["pcg_iterations"]
@@ -666,3 +666,40 @@ def test_exact_reduced_solve_reports_a_non_positive_pivot():
     A = 0.5 * (A + A.T)
     x, bad = dense_solve(A, rng.normal(size=n))
     assert bad
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(pcg_aggregate=6), dict(coarse_linear=0), dict(precond_fp32=0), dict(pcg_graph=0)],
+                         ids=["default", "aggregate6", "constant_coarse", "fp64_inverse", "eager"])
+def test_upper_triangle_iteration_matches_the_two_launch_form(solvers, opts):
+    """Option spmv_upper (automatic beyond 1536 free poses): the PCG iteration as three launches straight from the upper-triangular BSR
+    storage -- SpMV with the transposed products parked per block, row updates + P^T r per aggregate, preconditioner -- instead of the
+    SpMV on the row-ordered copy of both triangles + the fused two-level kernel.  Same mathematics, other summation orders: same
+    trajectory to the solver tolerance, iteration counts within one or two, still bit-reproducible; exact increment of one solve against
+    the oracle."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
+    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
+    a = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, spmv_upper=0, **opts); ra = a.optimize(6)["chi2"]
+    b = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, spmv_upper=1, **opts); rb = b.optimize(6)["chi2"]
+    assert rel(ra, ref) < 1e-9 and rel(rb, ref) < 1e-9 and rel(ra, rb) < 1e-10
+    ia, ib = a.pcg_history()[0], b.pcg_history()[0]
+    assert a.pcg_history()[1] == 0 and b.pcg_history()[1] == 0 and len(ia) == len(ib)
+    assert np.abs(ia - ib).max() <= 2, (ia.tolist(), ib.tolist())
+    b2 = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, spmv_upper=1, **opts)
+    assert np.array_equal(b2.optimize(6)["chi2"], rb)
+    o = OracleSolver(fp, RK_HUBER); o.compute_errors(); o.build_system()
+    lam = 1e-6 * o.max_diagonal()
+    o.set_lambda(lam); assert o.solve()
+    b.set_state(fp.q, fp.t, fp.Xw); b.set_lambda(lam); assert b.solve()
+    assert rel(b.array("xp"), o.array("xp")) < 1e-8 and rel(b.array("xl"), o.array("xl")) < 1e-8
+    kt = b.time_kernels(3)
+    assert kt["pcg_spmv"] > 0 and kt["pcg_update"] > 0
+
+
+def test_upper_triangle_iteration_float32_build(solvers):
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(200, 8000, 32000, seed=13))
+    ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
+    a = HipSolver(fp, RK_HUBER, precision="f32", spmv_upper=0).optimize(6)["chi2"]
+    b = HipSolver(fp, RK_HUBER, precision="f32", spmv_upper=1).optimize(6)["chi2"]
+    assert len(a) == len(b) and rel(b[:len(ref)], ref[:len(b)]) < 1e-3 and rel(a, b) < 1e-3
