@@ -84,10 +84,10 @@ void cuba_hip_solver::dropPcgGraph()
 void cuba_hip_solver::ensureOverlapObjects()
 {
 	if (gjStream) return;
-	int prioLow = 0, prioHigh = 0;
-	HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
 	// (low priority: the sweep fills the gaps of the latency-bound PCG kernels it runs under; confining it to every n-th CU instead
 	// was measured at <= 1 %, profiles/r03*)
+	int prioLow = 0, prioHigh = 0;
+	HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
 	HIP_TRY(hipStreamCreateWithPriority(&gjStream, hipStreamNonBlocking, prioLow));
 	HIP_TRY(hipEventCreateWithFlags(&evSetup, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&evAssembled, hipEventDisableTiming));
@@ -408,7 +408,10 @@ bool cuba_hip_solver::solveReducedOnce()
 	}
 	// first solve on this structure: the usual chunk lengths are ordered at once (the helper thread builds them while this solve runs
 	// on plain launches), longest first -- the first batches of a run are the long ones
-	if (useGraph && pcgGraphs.empty() && graphsOrderedFor != (const void*)sys.acinv)
+	// (graphs only while this is the one handle of the process: see g_liveHandles)
+	const bool graphs = useGraph && g_liveHandles.load(std::memory_order_relaxed) <= 1;
+	if (useGraph && !graphs && (!pcgGraphs.empty() || graphsOrderedFor)) dropPcgGraph();
+	if (graphs && pcgGraphs.empty() && graphsOrderedFor != (const void*)sys.acinv)
 	{
 		for (int c = 64; c >= 4; c /= 2) (void)pcgGraphIfReady(c, maxIter, tol2);
 		graphsOrderedFor = (const void*)sys.acinv;
@@ -455,16 +458,13 @@ bool cuba_hip_solver::solveReducedOnce()
 			// batch instead of one per power of two.  Not on the first request -- the reference's timing protocol meets most lengths for
 			// the first time inside its timed part, and an instantiation costs ~2 us per node.
 			// (the exact graph is ordered on the second request and used from the moment it exists)
-			if (useGraph && exactBatchGraphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
+			if (graphs && exactBatchGraphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
 			{
 				if ((pcgGraphs.count(std::make_pair(todo, (const Scalar*)sys.acinv)) || ++batchRequests[todo] >= 2) && pcgGraphIfReady(todo, maxIter, tol2)) c = todo;
 			}
-			// (another handle is being driven right now: plain launches -- see g_activeCalls; the graphs are still ordered, for later)
-			const bool alone = g_activeCalls.load(std::memory_order_relaxed) <= 1;
-			hipGraphExec_t exec = useGraph ? pcgGraphIfReady(c, maxIter, tol2) : nullptr;
-			if (!alone) exec = nullptr;
+			hipGraphExec_t exec = graphs ? pcgGraphIfReady(c, maxIter, tol2) : nullptr;
 			if (exec) { HIP_TRY(hipGraphLaunch(exec, stream)); noteReport(); }     // (every graph reports; the host waits for the last)
-			else if (useGraph)
+			else if (graphs)
 			{
 				// the same chunk as plain launches: chunk-local iteration numbers + the advance / stop test / report node
 				for (int k = 0; k < c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
@@ -474,7 +474,7 @@ bool cuba_hip_solver::solveReducedOnce()
 			else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 			k0 += c; todo -= c;
 		}
-		if (!useGraph) { launch_pcg_report(sys, stream); noteReport(); }      // (graphs and chunks of plain launches end with this report)
+		if (!graphs) { launch_pcg_report(sys, stream); noteReport(); }       // (graphs and chunks of plain launches end with this report)
 		waitReport();
 		if (hInts[0] != 0)
 		{

@@ -12,12 +12,15 @@ void cuba_hip_solver::finishValues()
 	HIP_TRY(hipStreamWaitEvent(stream, evValues, 0));
 	topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
 		nullptr, nullptr, d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
+	sortedValuesValid = true;
 }
 
 void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,
 	int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega, bool deferValues)
 {
-	if (valuesPending) { HIP_TRY(hipStreamSynchronize(upStream)); valuesPending = false; }      // (a begin without its end: the old upload must not outlive its arrays' replacement)
+	// (a begin without its end: the old upload must not outlive its arrays' replacement, and the sorted measurement / information arrays
+	// it was going to fill were never gathered -- a "same values" promise for THIS call must not keep them: round-4 advisor)
+	if (valuesPending) { HIP_TRY(hipStreamSynchronize(upStream)); valuesPending = false; sortedValuesValid = false; }
 	deferredUpload = false;
 	if (Pt_ < 0 || Lt_ < 0 || E_ < 0 || Pf_ < 0 || Pf_ > Pt_ || Lf_ < 0 || Lf_ > Lt_) throw ArgError{ "bad vertex counts" };
 	if (Pt_ >= STEREO_BIT) throw ArgError{ "too many poses" };
@@ -84,20 +87,22 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 			d_rawEp.resize(E);
 			HIP_TRY(hipMemcpyAsync(d_rawEp.data(), d_rawEpCaller.data(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, stream));
 		}
-		const bool keepValues = promisedValues && reuseSort && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
+		const bool keepValues = promisedValues && reuseSort && sortedValuesValid && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
 		const bool defer = deferValues && !keepValues && E > 0;
 		deferredUpload = defer;          // (enqueued LAST, below: the copy engine serves its queue in order, and the small uploads of this call must not wait behind 18 MB)
 		if (defer) { d_rawMeas.resize((size_t)3 * E); d_rawOmega.resize(E); }
 		else if (!keepValues) { d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream); }
 		lap("set_graph: raw uploads enqueued");
+		if (!keepValues) sortedValuesValid = false;
 		if (!reuseSort) runDeviceEdgeSort(!defer);
 		else if (!keepValues && !defer)
 		{
 			d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E);
 			topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
 				nullptr, nullptr, d_mu.data(), d_mv.data(), d_mr.data(), d_w.data(), stream);
+			sortedValuesValid = true;
 		}
-		if (defer) { d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E); valuesPending = true; }
+		if (defer) { d_mu.resize(E); d_mv.resize(E); d_mr.resize(E); d_w.resize(E); valuesPending = true; }      // (finishValues gathers them and marks them valid)
 		sameTopology = sameCounts && reuseSort;
 		devTopology = true; hostTopoValid = false;
 		if (reorderActive) { stageState(); permuteStateRows(state, camv); }          // the caller's rows -> the internal pose order kept from the last call
@@ -751,6 +756,7 @@ void cuba_hip_solver::runDeviceEdgeSort(bool withValues)
 	topo::launch_gather_edges(d_perm.data(), d_rawEp.data(), d_rawEl.data(), d_rawDim.data(), d_rawMeas.data(), d_rawOmega.data(), E,
 		d_epose.data(), d_elm.data(), withValues ? d_mu.data() : nullptr, d_mv.data(), d_mr.data(), d_w.data(), stream);
 	topo::launch_segment_ptr(d_elm.data(), E, Lt, d_lmptr.data(), stream);
+	if (withValues) sortedValuesValid = true;
 }
 
 std::vector<int> cuba_hip_solver::chainOrder(const std::vector<int>& rowptr, const std::vector<int>& colind, const std::vector<int>& prodPtr) const

@@ -10,18 +10,19 @@ using namespace cubahip;
 // -----------------------------------------------------------------------------------------------------
 // C ABI
 // -----------------------------------------------------------------------------------------------------
-namespace cubahip_host { std::atomic<int> g_activeCalls{ 0 }; }
+namespace cubahip_host
+{
+std::atomic<int> g_liveHandles{ 0 };
+}
 
 namespace
 {
 std::string g_createError;
-struct CallScope { CallScope() { g_activeCalls.fetch_add(1, std::memory_order_relaxed); } ~CallScope() { g_activeCalls.fetch_sub(1, std::memory_order_relaxed); } };
 
 template <typename F>
 int guarded(cuba_hip_solver* s, F&& f)
 {
 	if (!s) return CUBA_HIP_ERR_INVALID_ARGUMENT;
-	CallScope scope;
 	try
 	{
 		if (hipSetDevice(s->device) != hipSuccess) { s->lastError = "hipSetDevice failed"; return CUBA_HIP_ERR_RUNTIME; }
@@ -90,6 +91,7 @@ int cuba_hip_create(int device, cuba_hip_solver** out)
 	s->device = device;
 	if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return CUBA_HIP_ERR_RUNTIME; }
 	s->ownStream = true;
+	g_liveHandles.fetch_add(1, std::memory_order_relaxed);
 	*out = s;
 	return CUBA_HIP_OK;
 }
@@ -100,6 +102,7 @@ int cuba_hip_destroy(cuba_hip_solver* s)
 	(void)hipSetDevice(s->device);
 	(void)hipStreamSynchronize(s->stream);
 	delete s;
+	g_liveHandles.fetch_sub(1, std::memory_order_relaxed);
 	return CUBA_HIP_OK;
 }
 

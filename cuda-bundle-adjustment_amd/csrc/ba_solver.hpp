@@ -95,12 +95,15 @@ private:
 
 using Clock = std::chrono::steady_clock;
 
-// Calls into the library that are in flight right now, over all handles of the process (every C-ABI entry point counts itself in and
-// out).  More than one = several handles are driven concurrently from distinct host threads; the reduced solve then enqueues its PCG
-// batches as plain launches instead of hipGraph launches: graph launches of two streams serialise against each other on this runtime
-// (two KITTI-00 graphs side by side: 15.4 / 11.7 ms per run as graphs, 8.9 / 9.4 ms as plain launches, 6.8 ms alone:
-// profiles/r05c_concurrent_handles_first_look.txt), and the two forms give bit-identical results.
-extern std::atomic<int> g_activeCalls;
+// Solver handles alive in this process.  With more than one, no handle instantiates or replays hipGraphs: every PCG batch goes out as
+// plain launches of the same kernels with the same arguments (bit-identical results, ~2 % slower for a handle that runs alone).
+// Measured on this runtime (profiles/r05c_* ... r05l_*): dependent-kernel chains of two streams overlap perfectly, two KITTI-00 graphs
+// optimised side by side from two host threads take 8.9 / 8.9 ms per run (6.8 alone: 1.5 x the throughput) -- but only in a process that
+// has NEVER instantiated a hipGraph.  Once one handle has (even if it destroyed them since, and whether or not anything is launched as a
+// graph any more) the same pair takes 15.4 / 11.7 ms: no overlap at all.  So: a process that will drive several handles at once starts
+// with CUBA_HIP_GRAPHS=0 in its environment (or "pcg_graph" = 0 on every handle before its first solve); the automatic rule below only
+// keeps a second handle from adding graphs of its own.
+extern std::atomic<int> g_liveHandles;
 
 }  // namespace cubahip_host
 using namespace cubahip_host;
@@ -164,7 +167,7 @@ struct cuba_hip_solver
 	DevBuf<Scalar> d_mu, d_mv, d_mr, d_w, d_perEdge;
 	DevBuf<int> d_waveLm, d_bigLm, d_rowptr, d_colind, d_lmNfree, d_adjPtr, d_adjBlk, d_adjCol;
 	DevBuf<int2> d_ell;
-	DevBuf<long long> d_lmPairBase;
+	DevBuf<long long> d_lmPairBase;     // exclusive scan of the per-landmark product counts (device structure build)
 	DevBuf<Scalar> d_red;        // [hsc | bsc | bp]
 	DevBuf<Scalar> d_parts, d_lmSys, d_lmInv, d_xp, d_xl, d_minv, d_r, d_z, d_p0, d_p1, d_ap, d_rz, d_pq;
 	DevBuf<unsigned long long> d_maxdiag;
@@ -205,7 +208,8 @@ struct cuba_hip_solver
 	// kbase counter supplies the offset): replaying it costs one host call instead of 2-3 launches per iteration
 	// (graphs are kept per chunk length -- 4, 8, ..., 256 and the exact batch lengths that come back)
 	std::map<std::pair<int, const Scalar*>, hipGraphExec_t> pcgGraphs;   // key: chunk length, coarse inverse the kernels read
-	bool useGraph = true;
+	bool useGraph = graphsByDefault();
+	static bool graphsByDefault() { const char* e = std::getenv("CUBA_HIP_GRAPHS"); return !(e && e[0] == '0'); }
 	hipStream_t captureStream = nullptr;   // private stream used only by time_kernels to record timing graphs (the work stream may be the
 	                                       // legacy default stream, which cannot be captured)
 	hipStream_t capStream()
@@ -235,7 +239,6 @@ struct cuba_hip_solver
 	void graphWorker();
 	// the graph of `chunk` iterations if it exists; otherwise it is ordered (once) and nullptr returned
 	hipGraphExec_t pcgGraphIfReady(int chunk, int maxIter, Scalar tol2);
-	// (tests, time_kernels: wait until every ordered graph exists)
 	void dropPcgGraph();
 	std::map<int, int> batchRequests;      // how often a batch of this length was asked for since the graphs were dropped
 	bool exactBatchGraphs = true;          // option "pcg_exact_batch_graphs"
@@ -398,6 +401,7 @@ struct cuba_hip_solver
 	// edge may still be crossing PCIe -- on a second stream -- while the structure analysis (which needs the index arrays only) runs
 	hipStream_t upStream = nullptr; hipEvent_t evValues = nullptr;
 	bool valuesPending = false, deferredUpload = false;
+	bool sortedValuesValid = false;     // d_mu / d_mv / d_mr / d_w hold the gathered values of the last upload (false while a two-step upload is open or was abandoned)
 	int* h_tileStage = nullptr; size_t tileStageCap = 0; hipEvent_t evTileInputs = nullptr;     // page-locked staging of the tile-order inputs
 	void finishValues();
 	void setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,

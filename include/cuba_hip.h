@@ -67,7 +67,16 @@ enum
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
 
-/* Replaces: CudaBundleAdjustment::create() -> CudaBlockSolver construction (src/cuda_bundle_adjustment.cpp:905-908). */
+/* Replaces: CudaBundleAdjustment::create() -> CudaBlockSolver construction (src/cuda_bundle_adjustment.cpp:905-908).
+   Threads: a handle is not re-entrant; distinct handles may be driven from distinct host threads at once (the reference's
+   CudaBundleAdjustment objects are independent too, include/cuda_bundle_adjustment.h:34-125).  Each handle owns one work stream, one
+   low-priority side stream (coarse inversions), one upload stream, and -- while it is the only live handle of the process and graphs
+   are on -- a helper thread that calls hipGraphInstantiate / hipGraphExecDestroy in the background (relevant for callers that fork, or
+   that capture with hipStreamCaptureModeGlobal).  A process that will drive SEVERAL handles side by side should export
+   CUBA_HIP_GRAPHS=0 before its first solve (= option "pcg_graph" 0 on every handle; no helper thread then): on this runtime a process
+   that has ever instantiated a hipGraph no longer overlaps the kernel chains of two streams (two KITTI-00 graphs from two threads:
+   1.5 x one graph's throughput without graphs, 1.0 x with; a lone handle is ~2 % faster with graphs).  The
+   library itself stops using graphs while more than one handle is alive. */
 int cuba_hip_create(int device, cuba_hip_solver** out);
 int cuba_hip_destroy(cuba_hip_solver* s);
 const char* cuba_hip_last_error(const cuba_hip_solver* s);
@@ -86,7 +95,7 @@ void cuba_hip_host_free(void* p);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Options (19).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
+/* Options (20).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
    "direct_fallback" (default 1: a reduced solve whose PCG uses up its iteration budget, breaks down, or follows such a solve in the
    same Levenberg-Marquardt run is solved EXACTLY on the device -- dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip, the
@@ -112,7 +121,11 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    the previous run solve for solve so far sizes its next batch of iterations from that run instead of extrapolating),
    "pcg_exact_batch_graphs" (default 1: a batch length that is asked for a second time on one structure gets a hipGraph of exactly
    that length -- one hand-over per batch instead of one per power of two).
-   Execution: "pcg_graph" (default 1: PCG iterations are replayed as hipGraphs of 4 ... 256 iterations; 0 = eager launches),
+   "spmv_upper" (default -1 = automatic: on beyond 1536 free poses, where the PCG kernels are bound by bytes; 1 / 0 = on / off: the
+   PCG iteration as three launches straight from the upper-triangular BSR storage -- SpMV with the transposed products parked per
+   block, row updates + P^T r per aggregate, preconditioner -- instead of two launches on a row-ordered copy of both triangles).
+   Execution: "pcg_graph" (default 1, or 0 when the environment has CUBA_HIP_GRAPHS=0: PCG iterations are replayed as hipGraphs of
+   4 ... 256 iterations; 0 = eager launches; see cuba_hip_create about processes with several handles),
    "fused_tail" (default 1: cuba_hip_optimize runs back-substitution, update and evaluation of a trial as ONE pass over the edges;
    0 = the four-launch tail, which a landmark partition and "profile" use in any case), "device_setup" (default 1: the edge sort of
    cuba_hip_set_graph and the whole symbolic analysis of cuba_hip_build_structure run on the GPU; 0 = the host pipeline, the

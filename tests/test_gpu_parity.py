@@ -450,6 +450,13 @@ def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small
     assert rel(h.optimize(4)["chi2"], base) < 1e-9
     h.set_graph(fp2)                                                 # the promise above covered one call only
     assert rel(h.optimize(4)["chi2"], moved) < 1e-9
+    # a two-step upload that is never finished leaves sorted value arrays that were never gathered: a "same values" promise for the
+    # call after it must not keep them (round-4 advisor: the plain C ABI was exposed, the C++ layer's upload counter was not)
+    h.set_graph(fp)
+    assert rel(h.optimize(4)["chi2"], base) < 1e-9
+    h.set_graph(fp2, two_step="begin_only")                          # cuba_hip_set_graph_begin without its _end
+    h.hint_unchanged(True, True); h.set_graph(fp2)
+    assert rel(h.optimize(4)["chi2"], moved) < 1e-9
 
 
 def test_coarse_refresh_schedule(solvers):
