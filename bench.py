@@ -51,11 +51,24 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MI
 LM_RUN = 10               # iterations per LM run (the reference protocol: optimize(10))
 
 
-def algorithmic_bytes(fp, nblk, nc):
-    """Compulsory bytes per launch of each hot kernel. nc = coarse aggregates."""
+def algorithmic_bytes(fp, nblk, nc, upper=False):
+    """Compulsory bytes per launch of each hot kernel. nc = coarse aggregates.
+    upper: the three-launch PCG iteration on the upper-triangular storage (graphs beyond 1536 free poses): pcg_spmv = the SpMV that
+    parks the transposed products, pcg_update = the row updates (pcg_rows_kernel), pcg_precond = the preconditioner launch."""
     E, Pf, Pt, Lf, Lt = fp.E, fp.Pf, fp.Pt, fp.Lf, fp.Lt
     Nc = int(round(6 * nc))
     edge_in = 40 * E                     # pose idx 4 + landmark idx 4 + 3 x 8 measurement + 8 information
+    if upper:
+        off = nblk - Pf                  # off-diagonal blocks
+        return {
+            "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
+            "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
+            "pcg_spmv": 288 * nblk + 8 * nblk + 48 * off + 4 * 48 * Pf,      # blocks once + (column, position) + parked products out + z, p in / p, q out
+            "pcg_update": 48 * off + (4 + 2) * 48 * Pf,                      # parked products in + q, r, p, x in / r, x out
+            "pcg_precond": 4 * Nc * ((Nc + 3) // 4 * 4) + 8 * Nc + (288 + 2 * 48) * Pf,   # fp32 coarse inverse + P^T r + block inverses, r in / z out
+            "coarse_setup": 288 * nblk + 3 * 8 * Nc * Nc,
+            "back_substitute": edge_in + (24 + 72 + 24) * Lf + (96 + 48) * Pt,
+        }
     return {
         "residual_chi2": edge_in + 24 * Lt + 96 * Pt,
         "linearize_schur": edge_in + (24 + 72) * Lf + 24 * (Lt - Lf) + 96 * Pt + 288 * nblk + 96 * Pf,
@@ -116,7 +129,7 @@ def source_sha16():
 
 
 # bench-line kernel key -> kernel names in the rocprofv3 outputs (template instantiations carry their arguments in the name)
-PROFILE_NAMES = {"pcg_spmv": ["pcg_spmv_kernel", "pcg_spmv_row_kernel", "pcg_spmv_upper_kernel"], "pcg_update": ["pcg2_fused_kernel"],
+PROFILE_NAMES = {"pcg_spmv": ["pcg_spmv_kernel", "pcg_spmv_row_kernel", "pcg_spmv_upper_kernel"], "pcg_update": ["pcg_rows_kernel", "pcg2_fused_kernel"],
                  "residual_chi2": ["residual_chi2_kernel"], "back_substitute": ["back_substitute_kernel"],
                  "linearize_schur": ["lm_pass_kernel<1", "schur_pass_kernel"]}
 
@@ -268,17 +281,19 @@ def shapes_leg(rk, device_index, stream, names=("kitti07", "s2m", "g4m"), runs=3
             try:
                 c = h.counters()
                 kt = {k: v for k, v in h.time_kernels(reps=10).items() if v > 0}
-                alg = algorithmic_bytes(fp, c["hsc_blocks"], c["coarse_dim"] / 6.0 if kt.get("coarse_setup", 0) > 0 else 0)
+                upper = kt.get("pcg_precond", 0) > 0 and kt.get("coarse_setup", 0) > 0        # (the two-launch iteration has no separate preconditioner launch)
+                alg = algorithmic_bytes(fp, c["hsc_blocks"], c["coarse_dim"] / 6.0 if kt.get("coarse_setup", 0) > 0 else 0, upper=upper)
                 ev = profile_evidence(name, list(kt))
                 table = kernel_table(kt, alg, ev)
                 it_per_run = int(np.median(iters))
-                share = {"pcg_spmv": it_per_run, "pcg_update": it_per_run}
+                share = {"pcg_spmv": it_per_run, "pcg_update": it_per_run, "pcg_precond": it_per_run if upper else 0}
                 dom = max(share, key=lambda k: share[k] * kt.get(k, 0))
                 sp = table.get("pcg_spmv")
                 if sp:
                     rec["roofline"] = {"bound": "hbm", "kernel": "pcg_spmv", "achieved": sp["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": sp["achieved_GBs"] / HBM_PEAK_GBS, "traffic": sp.get("traffic"), "alg_bytes_per_launch": sp["alg_bytes"],
-                                       "ms_per_launch": sp["ms_per_launch"], "largest_share": dom, "traffic_source": ev["pmc_file"],
+                                       "ms_per_launch": sp["ms_per_launch"], "largest_share": dom, "iteration": "upper-triangle, three launches" if upper else "two launches",
+                                       "traffic_source": ev["pmc_file"],
                                        "traffic_stale": ev["stale"], "rocprof_source": ev["stats_file"], "kernels": table}
             except Exception as e:   # noqa: BLE001
                 rec["roofline"] = {"error": repr(e)[:200]}
@@ -315,6 +330,104 @@ def shapes_leg(rk, device_index, stream, names=("kitti07", "s2m", "g4m"), runs=3
     return res
 
 
+def float32_leg(rk, device_index, stream, names=("kitti00", "g4m"), runs=3):
+    """BASELINE configs[4]'s "plus USE_FLOAT32 variant" (the reference: src/scalar.h:25-29, README "no significant speedup"): the all-fp32
+    library (libcuba_hip_f32.so) under the bench protocol on the headline shape and on configs[4]'s graph -- wall of 10 LM iterations from
+    perturbed starts, iterations actually run (an fp32 run may stop early), chi2 of a run from the generator's guess against the fp64 golden."""
+    import torch
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import synth_named
+    gpath = os.path.join(ROOT, "tests", "golden", "baseline_shapes_chi2.json")
+    golden = json.load(open(gpath))["shapes"] if os.path.exists(gpath) else {}
+    res = {}
+    for name in names:
+        try:
+            fp = flatten(synth_named(name))
+            h = HipSolver(fp, rk, device=device_index, stream=stream, precision="f32")
+            got = h.optimize(LM_RUN)["chi2"]
+            rec = {"edges": fp.E, "iterations_run": len(got), "chi2_last": float(got[-1]) if len(got) else None}
+            if name in golden and len(got):
+                ref = np.array(golden[name]["chi2"])[:len(got)]
+                rec["chi2_max_rel_diff_vs_fp64_golden"] = float(np.max(np.abs(got - ref) / ref))
+            h.set_state(fp.q, fp.t, fp.Xw); h.optimize(1)
+            nslots = prepare_slots(h, fp, h.state(), runs + 1, seed=1000)
+
+            def timed(slot):
+                h.restore_state(slot)
+                torch.cuda.synchronize(); t = time.perf_counter(); r = h.optimize(LM_RUN)["chi2"]; torch.cuda.synchronize()
+                return time.perf_counter() - t, len(r)
+            timed(nslots)
+            walls, its = zip(*[timed(1 + k) for k in range(runs)])
+            rec.update({"wall_ms_10iter": float(np.median(walls)) * 1e3, "wall_ms_10iter_min": min(walls) * 1e3, "iterations_in_timed_runs": list(its),
+                        "edge_iterations_per_s": fp.E * float(np.median(its)) / float(np.median(walls))})
+            h.close()
+            res[name] = rec
+        except Exception as e:   # noqa: BLE001
+            res[name] = {"error": repr(e)[:300]}
+    return res
+
+
+def concurrent_child(shape, counts=(2, 4), runs=5):
+    """(child process of concurrent_leg) N handles on ONE GPU, one host thread each, every thread optimising its own copy of the graph"""
+    import threading
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.graph import flatten
+    from cuba_amd.synth import synth_named
+    rk = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
+    fp = flatten(synth_named(shape))
+    hs = []
+    for _ in range(max(counts)):
+        h = HipSolver(fp, rk); h.optimize(1); h.snapshot_state(); h.optimize(LM_RUN); hs.append(h)
+
+    def timed(h):
+        ts, chi = [], None
+        for _ in range(runs):
+            h.restore_state(); t = time.perf_counter(); chi = h.optimize(LM_RUN)["chi2"]; ts.append(time.perf_counter() - t)
+        return float(np.median(ts)), chi
+    solo, chi_solo = timed(hs[0])
+    out = {"shape": shape, "edges": fp.E, "graphs_env": os.environ.get("CUBA_HIP_GRAPHS", "1"), "solo_wall_ms_10iter": solo * 1e3,
+           "solo_with_idle_handles_alive": len(hs), "runs_per_thread": runs, "groups": {}}
+    for n in counts:
+        group, res = hs[:n], [None] * n
+        bar = threading.Barrier(n + 1)
+
+        def work(i):
+            bar.wait()
+            res[i] = timed(group[i])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+        [t.start() for t in th]
+        bar.wait(); t0 = time.perf_counter()
+        [t.join() for t in th]
+        wall = time.perf_counter() - t0
+        rate = n * runs * LM_RUN * fp.E / wall
+        out["groups"][str(n)] = {"per_graph_wall_ms_10iter": [r[0] * 1e3 for r in res], "aggregate_edge_iterations_per_s": rate,
+                                 "throughput_vs_one_graph": rate / (LM_RUN * fp.E / solo),
+                                 "bit_identical_to_solo": bool(all(np.array_equal(r[1], chi_solo) for r in res))}
+    for h in hs:
+        h.close()
+    print("CONCURRENT " + json.dumps(out), flush=True)
+
+
+def concurrent_leg(shape):
+    """2 and 4 graphs of the bench shape optimised concurrently on ONE GPU from distinct host threads (include/cuba_hip.h: distinct handles
+    may be driven from distinct threads; the reference's CudaBundleAdjustment objects are independent, include/cuda_bundle_adjustment.h:34-125
+    -- ORB-SLAM's local and global BA).  Measured in child processes because the property is a process-wide one on this runtime: once a
+    process has instantiated a hipGraph the kernel chains of two streams no longer overlap, so the leg runs both
+    ways -- CUBA_HIP_GRAPHS=0 (what a multi-handle application should export) and the default."""
+    import subprocess
+    res = {}
+    for label, env in (("graphs_off", {"CUBA_HIP_GRAPHS": "0"}), ("default", {})):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--concurrent-child", "--shape", shape], capture_output=True, text=True,
+                               timeout=300, env={**os.environ, **env})
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("CONCURRENT ")), None)
+            res[label] = json.loads(line[len("CONCURRENT "):]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:   # noqa: BLE001
+            res[label] = {"error": repr(e)[:300]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,10 +438,15 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the C++-API leg (the reference's sample protocol)")
     ap.add_argument("--no-shapes", action="store_true", help="skip the kitti07 / s2m / g4m legs (N = 1 only)")
     ap.add_argument("--repeats", type=int, default=5, help="further timed blocks of --steps steps for the median / min / max")
+    ap.add_argument("--concurrent-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-handles leg (N = 1 only)")
     ap.add_argument("--partition", action="store_true",
                     help="N>1: ONE graph, landmark-partitioned over the ranks with an RCCL all-reduce of [Hsc|bsc|bp] "
                          "per trial (BASELINE config 5, strong scaling) instead of one independent graph per GPU")
     args = ap.parse_args()
+    if args.concurrent_child:
+        concurrent_child(args.shape)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -489,7 +607,7 @@ def main():
         kt = solver.time_kernels(reps=20)
         nblk = c1["hsc_blocks"]
         nc = 0 if kt["coarse_setup"] == 0 else c1["coarse_dim"] / 6.0        # algorithmic_bytes() takes the coarse dimension / 6
-        alg = algorithmic_bytes(fp, nblk, nc)
+        alg = algorithmic_bytes(fp, nblk, nc, upper=kt.get("pcg_precond", 0) > 0 and kt.get("coarse_setup", 0) > 0)
         launches = {"residual_chi2": trials + args.steps, "linearize_schur": trials, "pcg_spmv": pcg_iters,
                     "pcg_update": pcg_iters, "back_substitute": trials, "pcg_precond": pcg_iters + trials,
                     "coarse_setup": c1["coarse_refreshes"] - c0["coarse_refreshes"]}
@@ -574,6 +692,9 @@ def main():
         # ---- the other single-GPU BASELINE configurations, driver-timed in the same line (before any CPU leg: see shapes_leg) ----
         if world == 1 and not args.no_shapes and args.shape == "kitti00":
             out["shapes"] = shapes_leg(rk, device_index, torch.cuda.current_stream().cuda_stream, cpu=not args.no_cpu_baseline)
+            out["float32"] = float32_leg(rk, device_index, torch.cuda.current_stream().cuda_stream)
+        if world == 1 and not args.no_concurrent:
+            out["concurrent"] = concurrent_leg(args.shape)
         # ---- CPU baseline + parity leg (rank 0, N = 1 only): the oracle on the host cores ------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import OracleSolver

@@ -14,8 +14,8 @@
 // padding.
 //
 // Right-looking, two-level blocking (panel = 128 columns = 4 tile columns of 32):
-//   for every tile column k of the panel:   chol_panel_kernel  L_kk = chol(A_kk), X_k = L_kk^-1 (every workgroup, in LDS: 2 x 32
-//                                                              dependent steps, one barrier each), A_ik <- A_ik X_k^T (matrix cores)
+//   for every tile column k of the panel:   chol_panel_kernel  X_k = chol(A_kk)^-1 (every workgroup, in LDS: one sweep of 32 dependent steps
+//                                                              that eliminates A_kk and the identity beside it), A_ik <- A_ik X_k^T (matrix cores)
 //                                           chol_upd32_kernel  A_ij -= A_ik A_jk^T for the remaining tile columns j of the panel
 //   once per panel:                         chol_trail_kernel  A_IJ -= W_I W_J^T over 128 x 128 macro tiles, k = 128 (where the flops are:
 //                                                              n^3 / 3 in total, C read and written once per panel instead of once per tile column)
@@ -93,21 +93,36 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(DenseCholesky d, int k)
 #pragma unroll
 	for (int u = 0; u < 4; u++) { Tm[r][cb + 8 * u] = own[u]; F[r][cb + 8 * u] = fv[u]; }
 	__syncthreads();
-	// Unscaled right-looking elimination: after step j the columns <= j + 1 of Tm are final, T[r][c] = L[r][c] L[c][c].  Thread (r, cb)
-	// keeps its four elements (r, cb + 8u) in registers and publishes column j + 1 for the next step.
+	// Unscaled right-looking elimination, 32 dependent steps with one barrier each: after step j the columns <= j + 1 of Tm are final,
+	// T[r][c] = L[r][c] L[c][c].  The same row operations -- row r -= (T[r][j] / T[j][j]) row j -- applied to the identity beside it give
+	// M = (unit-lower factor)^-1, so X = L^-1 = diag(T)^-1/2 M comes out of the SAME sweep.  (Measured against a second sweep of 32 steps
+	// for the triangular inversion: the same 19 us per tile column -- a step is bound by its LDS operations, ten reads and five writes here,
+	// not by its barrier --, so the one-sweep form is kept for being shorter, not faster: profiles/r05n_exact_solve_times.txt.)
+	// Thread (r, cb) keeps its four elements (r, cb + 8u) of T and of M in registers and publishes column j + 1 of T and row j + 1 of M
+	// for the next step.
+	Scalar mm[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) { mm[u] = r == cb + 8 * u ? Scalar(1) : Scalar(0); Xs[r][cb + 8 * u] = mm[u]; }
+	__syncthreads();
 	bool bad = false;
 #pragma unroll
 	for (int j = 0; j < CH_T; j++)
 	{
 		Scalar dj = Tm[j][j];
 		if (!(dj > Scalar(0))) { bad = true; dj = Scalar(1); }
-		const Scalar lr = Tm[r][j] * fast_rcp(dj);
+		const Scalar lr = r > j ? Tm[r][j] * fast_rcp(dj) : Scalar(0);
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 		{
 			const int c = cb + 8 * u;
 			if (c > j && r >= c) own[u] -= lr * Tm[c][j];
+			if (c <= j) mm[u] -= lr * Xs[j][c];                 // (row j of M is final: rows below it change)
 			if (c == j + 1) Tm[r][c] = own[u];
+		}
+		if (r == j + 1)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++) Xs[r][cb + 8 * u] = mm[u];
 		}
 		__syncthreads();
 	}
@@ -117,36 +132,12 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(DenseCholesky d, int k)
 		rdiag[tid] = dd > Scalar(0) ? Scalar(1) / sqrt(dd) : Scalar(1);
 	}
 	__syncthreads();
-	// L (zero above the diagonal) into Tm; X = L^-1 row by row: row k2 is final once the rows above it are
-	Scalar acc[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++)
 	{
-		const int c = cb + 8 * u;
-		own[u] = r >= c ? own[u] * rdiag[c] : Scalar(0);
-		acc[u] = r == c ? Scalar(1) : Scalar(0);
-	}
-	__syncthreads();             // (every read of the unscaled diagonal is through)
+		const Scalar rd = rdiag[r];
 #pragma unroll
-	for (int u = 0; u < 4; u++) Tm[r][cb + 8 * u] = own[u];
+		for (int u = 0; u < 4; u++) Xs[r][cb + 8 * u] = cb + 8 * u <= r ? mm[u] * rd : Scalar(0);       // X = L^-1, zero above the diagonal
+	}
 	__syncthreads();
-#pragma unroll
-	for (int k2 = 0; k2 < CH_T; k2++)
-	{
-		if (r == k2)
-		{
-			const Scalar rd = rdiag[k2];           // 1 / L[k2][k2]
-#pragma unroll
-			for (int u = 0; u < 4; u++) Xs[k2][cb + 8 * u] = acc[u] * rd;
-		}
-		__syncthreads();
-		if (r > k2)
-		{
-			const Scalar l = Tm[r][k2];
-#pragma unroll
-			for (int u = 0; u < 4; u++) acc[u] -= l * Xs[k2][cb + 8 * u];
-		}
-	}
 	// own tile: Out[r][c] = sum_m F[r][m] X[c][m] on the matrix cores (wave w owns the 16 x 16 output tile (w >> 1, w & 1))
 	const int wv = tid >> 6, lane = tid & 63, wi = wv >> 1, wj = wv & 1;
 	MfmaAcc o = mfma_zero();
