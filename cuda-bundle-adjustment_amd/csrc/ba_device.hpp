@@ -77,6 +77,12 @@ __device__ __forceinline__ int vector_load_flag(const int* p)
 	return p[zero];
 }
 
+// the damping of a launch: the kernel argument, or -- when that is negative -- what the device-resident LM decision left in sys.lam_dev
+__device__ __forceinline__ Scalar launch_lambda(const DeviceSystem& sys, Scalar lambda)
+{
+	return lambda < Scalar(0) ? sys.lam_dev[0] : lambda;
+}
+
 // 1/x for a normal positive x: hardware reciprocal estimate + two Newton steps (full double precision, none of the
 // scaling / fix-up steps of the IEEE division sequence)
 __device__ __forceinline__ Scalar fast_rcp(Scalar x)

@@ -238,7 +238,8 @@ int cuba_hip_dist_optimize(cuba_hip_dist* d, int niterations, double* chi2_per_i
 				rho = ok ? (F - Fhat) / scale : -1;
 				if (rho > 0)
 				{
-					const double a = 1 - std::pow(2 * rho - 1, 3);
+					const double t3 = 2 * rho - 1;
+					const double a = 1 - t3 * t3 * t3;          // (the expressions of the device-resident decision, ba_edge.hip: lm_decide)
 					lam *= std::max(1. / 3, std::min(a, 2. / 3));
 					nu = 2;
 					F = Fhat;

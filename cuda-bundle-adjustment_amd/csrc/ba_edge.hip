@@ -230,8 +230,47 @@ __global__ __launch_bounds__(256) void eval_trial_kernel(DeviceGraph g, DeviceSy
 // Second stage of the three sums of a trial (landmark part of the denominator from the back-substitution, chi2, pose part) and
 // the report to the host in one launch: each sum is added exactly as reduce_parts_kernel adds it; the results go into the
 // mapped host block, the ticket follows them.
+// The Levenberg-Marquardt decision of one trial, taken on the device: gain ratio, acceptance, next damping (control flow and arithmetic of
+// CudaBundleAdjustmentImpl::optimize, /root/reference/src/cuda_bundle_adjustment.cpp:816-851; no fused multiply-adds: the host loop of the
+// stage API and the multi-GPU driver evaluate the same expressions and must get the same bits).  ok = 0: the reduced solve failed, rho = -1.
+// `halt` marks what ends a run without the host being able to foresee it (a rejected trial with rho == 0, a damping that is no longer
+// finite, the tenth rejection in a row): every later trial the host may already have enqueued is then rejected whatever it computed.
+__device__ __forceinline__ void lm_decide(double* st, Scalar* lamOut, double* ring, int ok, double sumLm, double Fhat, double sumPose)
+{
+#pragma clang fp contract(off)
+	const double F = st[0], lam = st[1], nu = st[2];
+	const bool halt = st[3] != 0.0;
+	const int trial = (int)st[4];
+	const double scale = (ok ? sumLm + sumPose : 0.0) + 1e-3;
+	const double rho = ok ? (F - Fhat) / scale : -1.0;
+	const bool acc = !halt && rho > 0;
+	double lamN = lam, nuN = nu, Fn = F, rej = st[6];
+	bool haltN = halt;
+	if (!halt)
+	{
+		if (acc)
+		{
+			const double t = 2 * rho - 1;
+			const double a = 1 - t * t * t;
+			lamN = lam * fmax(1. / 3, fmin(a, 2. / 3));
+			nuN = 2; Fn = Fhat; rej = 0;
+		}
+		else
+		{
+			lamN = lam * nu; nuN = nu * 2; rej += 1;
+			if (!(rho < 0) && rho <= 0) haltN = true;         // (rho == 0: the reference leaves its trial loop and then its iteration loop)
+			if (rej >= st[7]) haltN = true;
+		}
+		if (!(fabs(lamN) <= 1.7e308)) haltN = true;           // (not finite)
+	}
+	double* rec = ring + (size_t)(trial % LM_RING) * LM_REC;
+	rec[0] = ok ? Fhat : 0.0; rec[1] = scale; rec[2] = rho; rec[3] = lamN; rec[4] = Fn; rec[5] = acc ? 1.0 : 0.0; rec[6] = haltN ? 1.0 : 0.0; rec[7] = nuN;
+	st[0] = Fn; st[1] = lamN; st[2] = nuN; st[3] = haltN ? 1.0 : 0.0; st[4] = (double)(trial + 1); st[5] = acc ? 1.0 : 0.0; st[6] = rej;
+	lamOut[0] = (Scalar)lamN;
+}
+
 __global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, const Scalar* pA, int nA, Scalar* oA, const Scalar* pB, int nB, Scalar* oB,
-	const Scalar* pC, int nC, Scalar* oC)
+	const Scalar* pC, int nC, Scalar* oC, double* lmState, Scalar* lmLam, double* lmRing)
 {
 	__shared__ Scalar sh[3][16];
 	// the three sums side by side: thread shares first, then one barrier for all of them (each is added exactly as
@@ -244,6 +283,7 @@ __global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, c
 		const bool in = threadIdx.x < 16;
 		const Scalar tA = wave_sum(in ? sh[0][threadIdx.x] : Scalar(0)), tB = wave_sum(in ? sh[1][threadIdx.x] : Scalar(0)), tC = wave_sum(in ? sh[2][threadIdx.x] : Scalar(0));
 		store_slot_group(oA, tA); store_slot_group(oB, tB); store_slot_group(oC, tC);
+		if (lmState && threadIdx.x == 0) lm_decide(lmState, lmLam, lmRing, 1, (double)tA, (double)tB, (double)tC);
 	}
 	__threadfence_system();          // every writer's results before the ticket
 	__syncthreads();
@@ -374,6 +414,7 @@ __device__ __forceinline__ void update_pose_rows(const DeviceGraph& g, const Dev
 __global__ __launch_bounds__(LIN_BLOCK) void trial_tail_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
 	const Scalar* __restrict__ old, Scalar* __restrict__ scParts, Scalar* __restrict__ chiParts, int nLmGroups, int poseBlocks, Scalar* __restrict__ scaleParts, int nScale)
 {
+	lambda = launch_lambda(sys, lambda);
 	if ((int)blockIdx.x >= nLmGroups)
 	{
 		const int b = blockIdx.x - nLmGroups;
@@ -491,6 +532,7 @@ __global__ __launch_bounds__(256) void big_trial_tail_kernel(DeviceGraph g, Devi
 	__shared__ Scalar red[4][3];
 	__shared__ Scalar xsh[3];
 	__shared__ Scalar rsh[4];
+	lambda = launch_lambda(sys, lambda);
 	DeviceGraph go = g;                   // the pre-update estimate
 	go.q = const_cast<Scalar*>(old); go.t = go.q + 4 * (size_t)g.Pt; go.Xw = go.q + 7 * (size_t)g.Pt;
 	const int il = st.big_lm[blockIdx.x];
@@ -564,7 +606,8 @@ size_t trial_tail_parts(const DeviceGraph& g, const DeviceStructure& st)
 	return 2 * nA + 4 * 256 + 64;
 }
 
-void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, const Scalar* old, hipStream_t s)
+void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, const Scalar* old, hipStream_t s,
+	const LmDevice* decide)
 {
 	const int nLm = (st.nWaves + LIN_BLOCK / WAVE - 1) / (LIN_BLOCK / WAVE);
 	const int nA = nLm + st.nBig;
@@ -576,7 +619,41 @@ void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, co
 	if (nLm + poseBlocks + nScale > 0)
 		hipLaunchKernelGGL(trial_tail_kernel, dim3(nLm + poseBlocks + nScale), dim3(LIN_BLOCK), 0, s, g, st, sys, lambda, old, scParts, chiParts, nLm, poseBlocks, scaleParts, nScale);
 	if (st.nBig > 0) hipLaunchKernelGGL(big_trial_tail_kernel, dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda, old, scParts + nLm, chiParts + nLm);
-	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, scParts, nA, sys.slots + NSLOT, chiParts, nA, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT);
+	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, scParts, nA, sys.slots + NSLOT, chiParts, nA, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT,
+		decide ? decide->state : (double*)nullptr, decide ? decide->lam : (Scalar*)nullptr, decide ? decide->ring : (double*)nullptr);
+}
+
+// decision of a trial whose reduced solve failed + the report, one thread
+__global__ void lm_decide_failed_kernel(DeviceSystem sys, double* lmState, Scalar* lmLam, double* lmRing)
+{
+	if (threadIdx.x != 0) return;
+	lm_decide(lmState, lmLam, lmRing, 0, 0.0, 0.0, 0.0);
+	__threadfence_system();
+	if (sys.host_flags)
+	{
+		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
+		__threadfence_system();
+		sys.host_flags[3] = ++(*sys.ticket);
+	}
+}
+
+void launch_lm_decide_failed(const DeviceSystem& sys, const LmDevice& lm, hipStream_t s)
+{
+	hipLaunchKernelGGL(lm_decide_failed_kernel, dim3(1), dim3(64), 0, s, sys, lm.state, lm.lam, lm.ring);
+}
+
+// the reference's pop() when -- and only when -- the decision before it was a rejection
+__global__ __launch_bounds__(256) void restore_if_rejected_kernel(Scalar* __restrict__ state, const Scalar* __restrict__ backup, size_t count, const double* lmState)
+{
+	if (lmState[5] != 0.0) return;
+	const size_t stride = (size_t)gridDim.x * 256;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) state[i] = backup[i];
+}
+
+void launch_restore_if_rejected(Scalar* state, const Scalar* backup, size_t count, const LmDevice& lm, hipStream_t s)
+{
+	const unsigned grid = (unsigned)std::min<size_t>(512, (count + 255) / 256);
+	if (grid) hipLaunchKernelGGL(restore_if_rejected_kernel, dim3(grid), dim3(256), 0, s, state, backup, count, lm.state);
 }
 
 // Everything between a converged reduced solve and the LM decision in four launches: back-substitution, update, evaluation of
@@ -594,7 +671,8 @@ void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const De
 	const int nRes = n > 0 ? min((n + 255) / 256, 2048) : 0;
 	const int nScale = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
 	if (nRes + nScale > 0) hipLaunchKernelGGL(eval_trial_kernel, dim3(nRes + nScale), dim3(256), 0, s, g, sys, lambda, resParts, nRes, scaleParts, nScale);
-	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, sys.parts, nA, sys.slots + NSLOT, resParts, nRes, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT);
+	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, sys.parts, nA, sys.slots + NSLOT, resParts, nRes, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT,
+		(double*)nullptr, (Scalar*)nullptr, (double*)nullptr);
 }
 
 }  // namespace cubahip

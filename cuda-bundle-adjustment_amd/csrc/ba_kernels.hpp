@@ -126,6 +126,8 @@ struct DeviceSystem
 	                           // indexed by the workgroup's position inside its aggregate (P^T q is summed from these:
 	                           // aggregates are whole multiples of spmv_rows rows)
 	Scalar* r2 = nullptr;      // second residual buffer (the fused two-level kernel ping-pongs r / r2)
+	// device-resident Levenberg-Marquardt decision (cuba_hip_optimize): kernels that are handed a NEGATIVE damping read it from here
+	const Scalar* lam_dev = nullptr;
 	// upper-triangle iteration (large graphs; ba_pcg.hip): three launches per iteration straight from the upper-triangular BSR storage
 	int upper = 0;
 	Scalar* tq = nullptr;      // [6 * (nblk - Pf)] transposed products B^T p_i of the off-diagonal blocks, written by the SpMV in the order of the rows that
@@ -158,8 +160,20 @@ void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const De
 // the same in two launches: back-substitution, update and evaluation fused into one pass over the edges (`old` = copy of the state
 // [q | t | Xw] made before the trial: the pass reads the pre-update estimate from it while it writes the updated one), then the sums
 // + report.  trial_tail_parts(): numbers of partial-sum scratch (sys.parts) it needs.
-void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, const Scalar* old, hipStream_t s);
+struct LmDevice;
+void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, const Scalar* old, hipStream_t s,
+	const LmDevice* decide = nullptr);
 size_t trial_tail_parts(const DeviceGraph& g, const DeviceStructure& st);
+// Device-resident LM decision (control flow of CudaBundleAdjustmentImpl::optimize, /root/reference/src/cuda_bundle_adjustment.cpp:816-851):
+// state = {F, lambda, nu, halt, trials, accepted (last trial), rejections in a row, max rejections} in device memory, lam = the damping as
+// the kernels read it (sys.lam_dev), ring = device-mapped host records, LM_REC numbers per trial {Fhat, denominator, rho, next lambda,
+// next F, accepted, halt, next nu}.  launch_trial_tail_fused(.., decide) lets the sums' second stage take the decision of the trial instead
+// of only reporting them; launch_lm_decide_failed is the decision of a trial whose reduced solve failed (rho = -1);
+// launch_restore_if_rejected copies the backup over the estimates when the last decision was a rejection (the reference's pop()).
+constexpr int LM_REC = 8, LM_RING = 64;
+struct LmDevice { double* state = nullptr; Scalar* lam = nullptr; double* ring = nullptr; };
+void launch_lm_decide_failed(const DeviceSystem& sys, const LmDevice& lm, hipStream_t s);
+void launch_restore_if_rejected(Scalar* state, const Scalar* backup, size_t count, const LmDevice& lm, hipStream_t s);
 // landmark-side part recomputed from xl and the stored bl (stage API; the fused path gets it from back_substitute)
 void launch_landmark_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
 

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		for (size_t i = (size_t)(blockIdx.x - nLmGroups) * LIN_BLOCK + threadIdx.x; i < backupCount; i += stride) backupDst[i] = backupSrc[i];
 		return;
 	}
+	lambda = launch_lambda(sys, lambda);
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	const int wave = blockIdx.x * (LIN_BLOCK / WAVE) + wv;
@@ -160,6 +161,7 @@ template <int MODE, typename ET>
 __global__ __launch_bounds__(256) void big_lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda)
 {
 	__shared__ Scalar red[4][9];
+	lambda = launch_lambda(sys, lambda);
 	const int il = st.big_lm[blockIdx.x];
 	const int e0 = g.lm_ptr[il], e1 = g.lm_ptr[il + 1];
 	Scalar acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };

@@ -493,7 +493,7 @@ bool cuba_hip_solver::solveReducedOnce()
 		}
 		if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 		target = k0 + ((looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
-		looks++; cntPcgLooks++;
+		looks++; cntPcgLooks++; cntHostLooks++;
 	}
 	const auto tSolve1 = Clock::now();
 	if (std::getenv("CUBA_HIP_DEBUG"))
@@ -559,11 +559,84 @@ double cuba_hip_solver::computeScale(double lam)
 	return a + b;
 }
 
+int cuba_hip_solver::optimizeDeviceDecision(int niter, double* chi2Out)
+{
+	const int maxq = 10;
+	const double tau = 1e-5;
+	if (!h_lmRing)
+	{
+		HIP_TRY(hipHostMalloc((void**)&h_lmRing, sizeof(double) * LM_RING * LM_REC, hipHostMallocMapped));
+		HIP_TRY(hipHostGetDevicePointer((void**)&lmRingDev, h_lmRing, 0));
+	}
+	coarseValid = false;
+	startRunHistory();
+	double F = computeErrors();
+	double lam = tau * maxDiagonal();
+	{
+		double* st8 = reinterpret_cast<double*>(hostStage());          // (pinned staging block)
+		st8[0] = F; st8[1] = lam; st8[2] = 2.0; st8[3] = 0.0; st8[4] = 0.0; st8[5] = 1.0; st8[6] = 0.0; st8[7] = (double)maxq;
+		Scalar* l1 = reinterpret_cast<Scalar*>(st8 + 8);
+		l1[0] = (Scalar)lam;
+		HIP_TRY(hipMemcpyAsync(d_lmState.data(), st8, sizeof(double) * 8, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_lamS.data(), l1, sizeof(Scalar), hipMemcpyHostToDevice, stream));
+	}
+	LmDevice lm; lm.state = d_lmState.data(); lm.lam = d_lamS.data(); lm.ring = lmRingDev;
+	int enq = 0, seen = 0, done = 0, rejRun = 0;
+	bool stop = niter <= 0;
+	// outcomes of the trials [seen, upto): every one of them is complete (the caller has waited for a report that follows them in the stream)
+	auto absorb = [&](int upto) {
+		std::atomic_thread_fence(std::memory_order_acquire);
+		for (; seen < upto && !stop; seen++)
+		{
+			const volatile double* r = h_lmRing + (size_t)(seen % LM_RING) * LM_REC;
+			const bool acc = r[5] != 0.0;
+			const double rho = r[2];
+			lam = r[3]; F = r[4];
+			if (acc) rejRun = 0; else rejRun++;
+			// the reference's loops: an iteration ends with an accepted trial, with the maxq-th rejection, or with a rejected trial whose
+			// rho is not < 0; the run ends after niter iterations, or on `qn == maxq || rho <= 0 || !isfinite(lambda)` (:851)
+			const bool iterationEnds = acc || rejRun == maxq || !(rho < 0);
+			if (!iterationEnds) continue;
+			if (chi2Out) chi2Out[done] = F;
+			done++;
+			if (done == niter || rejRun == maxq || rho <= 0 || !std::isfinite(lam)) stop = true;
+			rejRun = 0;
+		}
+	};
+	while (!stop)
+	{
+		if (enq > seen)
+		{
+			// trial enq - 1 is still undecided as far as the host knows.  Trial enq is needed whatever its outcome -- unless that
+			// outcome can end the run: the last iteration, or the maxq-th rejection in a row
+			const bool safe = done + 1 < niter && rejRun + 1 < maxq;
+			if (!safe) { waitReport(); cntHostLooks++; absorb(enq); if (stop) break; }
+		}
+		cntTrials++;
+		lambda = -1.0;                 // (every kernel of the trial reads the damping from device memory: launch_lambda)
+		schur(true);
+		const bool ok = solveReduced();        // (its looks follow every earlier trial's decision in the stream)
+		absorb(enq);
+		if (stop) { cntTrials--; break; }      // (an outcome nobody could foresee ended the run: the device has halted, this trial is void)
+		if (ok) launch_trial_tail_fused(g, st, sys, (Scalar)-1, d_backup.data(), stream, &lm);
+		else launch_lm_decide_failed(sys, lm, stream);
+		noteReport();
+		launch_restore_if_rejected(d_state.data(), d_backup.data(), d_state.size(), lm, stream);
+		enq++;
+		(void)hipStreamQuery(stream);
+	}
+	if (seen < enq) { waitReport(); cntHostLooks++; absorb(enq); }
+	lambda = lam;
+	return done;
+}
+
 int cuba_hip_solver::optimize(int niter, double* chi2Out)
 {
 	lap(nullptr);
 	need();
 	lap("optimize: structure ready");
+	if (deviceDecision && !profile && partHi < 0 && fusedTail && Pf > 0 && Lf > 0 && E > 0 && trial_tail_parts(g, st) <= d_parts.size())
+		return optimizeDeviceDecision(niter, chi2Out);
 	coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
 	startRunHistory();
 	const int maxq = 10;
@@ -606,7 +679,10 @@ int cuba_hip_solver::optimize(int niter, double* chi2Out)
 			rho = ok ? (F - Fhat) / scale : -1;
 			if (rho > 0)
 			{
-				const double a = 1 - std::pow(2 * rho - 1, 3);
+				// (t * t * t, not pow: the expressions of lm_decide in ba_edge.hip, so that this loop and the device-resident decision
+				// give the same damping bit for bit)
+				const double t3 = 2 * rho - 1;
+				const double a = 1 - t3 * t3 * t3;
 				lam *= std::max(1. / 3, std::min(a, 2. / 3));
 				nu = 2;
 				F = Fhat;
@@ -640,7 +716,7 @@ void cuba_hip_solver::enqueueEvaluate(double lam, bool withScale)
 
 void cuba_hip_solver::readEvaluate(bool withScale, double* Fhat, double* scale)
 {
-	waitReport();
+	waitReport(); cntHostLooks++;
 	*Fhat = (double)slot(0);
 	*scale = withScale ? (double)slot(NSLOT) + (double)slot(3 * NSLOT) : 0.0;   // landmark part (back_substitute) + pose part
 }

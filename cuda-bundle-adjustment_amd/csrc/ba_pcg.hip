@@ -24,6 +24,7 @@ __device__ __forceinline__ void pcg_setup_body(const DeviceGraph& g, const Devic
 	// one pose per thread, 64 poses per workgroup (only its first wave works): every load / store of a thread is 288 bytes from its
 	// neighbour's, so the set-up is the address path of the CUs it runs on -- spread over four times as many of them
 	const int i = threadIdx.x < PCG_SETUP_POSES ? bid * PCG_SETUP_POSES + (int)threadIdx.x : g.Pf;
+	lambda = launch_lambda(sys, lambda);
 	Scalar rz = 0;
 	if (i < g.Pf)
 	{

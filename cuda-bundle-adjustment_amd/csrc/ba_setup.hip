@@ -701,6 +701,7 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); d_gjPivots.resize(2 * 32 * 32); sys.gj_pivots = d_gjPivots.data();
 	sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 	d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
+	d_lamS.resize(1); d_lmState.resize(8); sys.lam_dev = d_lamS.data();
 	sys.upper = agg > 0 && (spmvUpper < 0 ? spmvRows == 4 : spmvUpper != 0) ? 1 : 0;
 	if (sys.upper)
 	{

@@ -138,6 +138,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "direct_max_unknowns") { s->directMaxUnknowns = (int)value; s->directRefused = false; }
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
+		else if (k == "device_lm_decision") s->deviceDecision = value != 0;
 		else if (k == "spmv_upper") { s->spmvUpper = (int)value; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
@@ -325,6 +326,7 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
 		else if (k == "pcg_graph_instantiations") *value = s->gb.builds.load();
 		else if (k == "precond_fp32_fallbacks") *value = s->cntFp32Fallbacks;
 		else if (k == "pcg_iterations_plain_launches") *value = s->cntPcgPlain;
+		else if (k == "host_looks") *value = s->cntHostLooks;
 		else if (k == "exact_solve_fallbacks") *value = s->cntDirect;
 		else if (k == "exact_solve_failures") *value = s->cntDirectFailed;
 		else if (k == "graph_uploads") *value = s->cntUploads;

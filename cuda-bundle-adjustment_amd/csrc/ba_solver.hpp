@@ -321,6 +321,7 @@ struct cuba_hip_solver
 		if (h_tileStage) (void)hipHostFree(h_tileStage);
 		if (evTileInputs) (void)hipEventDestroy(evTileInputs);
 		if (h_pinned) (void)hipHostFree(h_pinned);
+		if (h_lmRing) (void)hipHostFree(h_lmRing);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
 	}
 
@@ -583,6 +584,16 @@ struct cuba_hip_solver
 
 	// Levenberg-Marquardt, control flow of CudaBundleAdjustmentImpl::optimize (:793-857).
 	int optimize(int niter, double* chi2Out);
+	// The same loop with the decision of every trial taken ON THE DEVICE (gain ratio, acceptance, next damping: lm_decide in ba_edge.hip):
+	// the host enqueues trial n + 1 behind trial n's tail without having seen its outcome -- the kernels read the damping from device
+	// memory, a rejected trial is undone by a conditional restore launch -- and learns the outcomes one trial late from device-mapped
+	// records, at the look its next reduced solve needs anyway.  One host look per trial instead of two; only a trial whose outcome may
+	// END the run (last iteration, tenth rejection in a row) is waited for.  Same arithmetic as the host loop, bit for bit.
+	int optimizeDeviceDecision(int niter, double* chi2Out);
+	bool deviceDecision = true;         // option "device_lm_decision"
+	DevBuf<double> d_lmState; DevBuf<Scalar> d_lamS;
+	double* h_lmRing = nullptr; double* lmRingDev = nullptr;
+	int64_t cntHostLooks = 0;           // waits of the host for a device report (PCG looks + LM decisions it had to see)
 
 	// chi2 of the trial estimate and sum x (lambda x + b) of the step that led to it, read back with ONE synchronisation
 	void enqueueEvaluate(double lam, bool withScale);

@@ -95,7 +95,7 @@ void cuba_hip_host_free(void* p);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Options (20).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
+/* Options (21).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
    "direct_fallback" (default 1: a reduced solve whose PCG uses up its iteration budget, breaks down, or follows such a solve in the
    same Levenberg-Marquardt run is solved EXACTLY on the device -- dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip, the
@@ -124,6 +124,10 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    "spmv_upper" (default -1 = automatic: on beyond 1536 free poses, where the PCG kernels are bound by bytes; 1 / 0 = on / off: the
    PCG iteration as three launches straight from the upper-triangular BSR storage -- SpMV with the transposed products parked per
    block, row updates + P^T r per aggregate, preconditioner -- instead of two launches on a row-ordered copy of both triangles).
+   "device_lm_decision" (default 1: cuba_hip_optimize takes the decision of every trial -- gain ratio, acceptance, next damping -- on
+   the device and enqueues the next trial without having seen it, a rejected trial being undone by a conditional restore launch: one
+   host look per trial instead of two, results bit-identical to the host-side decision = 0; control flow of
+   /root/reference/src/cuda_bundle_adjustment.cpp:816-851).
    Execution: "pcg_graph" (default 1, or 0 when the environment has CUBA_HIP_GRAPHS=0: PCG iterations are replayed as hipGraphs of
    4 ... 256 iterations; 0 = eager launches; see cuba_hip_create about processes with several handles),
    "fused_tail" (default 1: cuba_hip_optimize runs back-substitution, update and evaluation of a trial as ONE pass over the edges;
@@ -274,7 +278,9 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
    of a solve -- the others ran on the second stream under an earlier trial's PCG), "pcg_unconverged_solves",
    "pcg_graph_instantiations" (hipGraphs of PCG iteration batches built), "precond_fp32_fallbacks" (solves repeated with the fp64
    coarse inverse after the fp32-stored one broke the PCG down), "exact_solve_fallbacks" (reduced solves that went to the exact
-   solver, see "direct_fallback"; 0 on well-conditioned graphs), "exact_solve_failures" (of these, the ones that met a non-positive pivot), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
+   solver, see "direct_fallback"; 0 on well-conditioned graphs), "exact_solve_failures" (of these, the ones that met a non-positive pivot), "host_looks" (times the host waited for a device report:
+   PCG batches + the LM decisions it had to see), "pcg_iterations_plain_launches" (iterations enqueued as plain launches although graphs
+   are on: graph not instantiated yet), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
    life of the handle, never reset: a caller that keeps state about "what the device holds" -- the promises of cuba_hip_hint_unchanged --
    stores this number with it and distrusts its state when the two differ).  Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
 int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);

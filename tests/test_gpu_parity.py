@@ -710,3 +710,37 @@ def test_upper_triangle_iteration_float32_build(solvers):
     a = HipSolver(fp, RK_HUBER, precision="f32", spmv_upper=0).optimize(6)["chi2"]
     b = HipSolver(fp, RK_HUBER, precision="f32", spmv_upper=1).optimize(6)["chi2"]
     assert len(a) == len(b) and rel(b[:len(ref)], ref[:len(b)]) < 1e-3 and rel(a, b) < 1e-3
+
+
+def test_device_resident_lm_decision_is_bit_identical(solvers):
+    """cuba_hip_optimize takes the decision of every trial on the device (gain ratio, acceptance, next damping; a rejected trial is undone
+    by a conditional restore launch) and enqueues the next trial without having seen it: one host look per trial instead of two.  Same
+    control flow as CudaBundleAdjustmentImpl::optimize (src/cuda_bundle_adjustment.cpp:816-851), same arithmetic as the host loop
+    (option device_lm_decision = 0): chi2 per iteration, estimates, trial counts and PCG histories are bit-identical -- with accepted
+    trials only, with rejected ones, with fixed vertices, when the run stops early, for a single iteration."""
+    from test_ref_lm import rough_start
+    HipSolver, OracleSolver = solvers
+    g = synth_ba(60, 1500, 6000, seed=3)
+    cases = [("huber", flatten(synth_ba(200, 8000, 32000, seed=13)), RK_HUBER, 10),
+             ("tukey_rejections", flatten(rough_start(g)), RK_TUKEY, 12),
+             ("none_rough_rotations", flatten(rough_start(g, sx=0.0, st=0.0, sr=0.4)), RK_NONE, 12),
+             ("fixed", flatten(with_fixed(g, fixed_pose_rows=[3, 4, 20], fixed_lm_rows=list(range(0, 300, 7)))), RK_HUBER, 6),
+             ("one_iteration", flatten(g), RK_HUBER, 1)]
+    saw_rejection = False
+    for name, fp, rk, n in cases:
+        a = HipSolver(fp, rk, device_lm_decision=0); ra = a.optimize(n)["chi2"]
+        b = HipSolver(fp, rk); rb = b.optimize(n)["chi2"]
+        assert np.array_equal(ra, rb), (name, ra, rb)
+        assert all(np.array_equal(x, y) for x, y in zip(a.state(), b.state())), name
+        ta, tb = a.counters()["lm_trials"], b.counters()["lm_trials"]
+        assert ta == tb and np.array_equal(a.pcg_history()[0], b.pcg_history()[0]), (name, ta, tb)
+        saw_rejection |= ta > len(ra)
+        la, lb = a.counter("host_looks"), b.counter("host_looks")
+        print(f"\n[{name}] {len(ra)} iterations, {ta} trials: host looks {la} (host decision) -> {lb} (device decision)")
+        assert lb < la or n == 1, (name, la, lb)
+        # a second run on the same handle (the device state is re-initialised) and the oracle
+        b.set_state(fp.q, fp.t, fp.Xw)
+        assert np.array_equal(b.optimize(n)["chi2"], rb), name
+        ro = OracleSolver(fp, rk).optimize(n)["chi2"]
+        assert len(ro) == len(rb) and rel(rb, ro) < (1e-5 if name == "tukey_rejections" else 1e-6), name
+    assert saw_rejection
