@@ -131,7 +131,7 @@ def source_sha16():
 # bench-line kernel key -> kernel names in the rocprofv3 outputs (template instantiations carry their arguments in the name)
 PROFILE_NAMES = {"pcg_spmv": ["pcg_spmv_kernel", "pcg_spmv_row_kernel", "pcg_spmv_upper_kernel"], "pcg_update": ["pcg_rows_kernel", "pcg2_fused_kernel"],
                  "residual_chi2": ["residual_chi2_kernel"], "back_substitute": ["back_substitute_kernel"],
-                 "linearize_schur": ["lm_pass_kernel<1", "schur_pass_kernel"]}
+                 "linearize_schur": ["lm_pass_kernel<1", "schur_pass_kernel"], "pcg_precond": ["pcg2_fused_kernel|true>"]}
 
 
 def newest_profile(pattern):
@@ -163,7 +163,10 @@ def profile_evidence(shape, keys):
             sk[nm] = {"launches": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
 
     def find(table, name):
-        hits = [v for k, v in table.items() if k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name))]
+        # ("name|suffix": an instantiation picked by the end of its argument list -- the fused kernel's preconditioner-only form ends in "true>")
+        name, _, suffix = name.partition("|")
+        hits = [v for k, v in table.items() if (k == name or k.startswith(name + "<") or (name.endswith("<1") and k.startswith(name)))
+                and (not suffix or k.endswith(suffix)) and not (not suffix and name == "pcg2_fused_kernel" and k.endswith("true>"))]
         return max(hits, key=lambda v: v["launches"]) if hits else None
     for key in keys:
         rec = {}

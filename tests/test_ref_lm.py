@@ -3,7 +3,12 @@ CudaBlockSolver and all kernels, compiled from /root/reference/src in place (ora
 cuSOLVER step is a stand-in exact Cholesky) -- runs whole Levenberg-Marquardt trajectories on the MI355X.  The CPU oracle
 and the HIP path must follow them: chi2 per iteration, number of executed iterations, final estimates, per-edge chi2,
 including the degenerate modes that go through the reference's gpu::solveDiagonalSystem (pose-only, landmark-only) and a
-start that makes the reference reject trials.  Skipped when oracle/_ref was not built (needs the reference checkout)."""
+start that makes the reference reject trials.  Skipped when oracle/_ref was not built (needs the reference checkout).
+
+What is NOT here, and why: a BASELINE-size run with the Huber kernel AND rejected trials.  With Huber the reference only starts rejecting at
+lambda ~ 1e-14 x max-diag (iteration ~25 of a 30-iteration run), where the run is chaotic -- the oracle with 1 and with 16 threads ends 40 %
+apart -- so no implementation can be pinned to another there; rejections at BASELINE size are pinned without a robust kernel
+(k00_rot0.5rad_none) and with Tukey (k00_lm10m_tukey, reference-vs-itself spread as the yardstick), Huber with rejections at <= 120 poses."""
 import copy
 
 import numpy as np
