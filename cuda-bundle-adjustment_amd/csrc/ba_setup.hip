@@ -83,9 +83,11 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 		if (!reuseSort)
 		{
 			if (!sameInput) { h_inEp.assign(ep, ep + E); h_inEl.assign(el, el + E); h_inDim.assign(edim, edim + E); }
-			d_rawEpCaller.uploadRaw(ep, E, stream); d_rawEl.uploadRaw(el, E, stream); d_rawDim.uploadRaw(edim, E, stream);
+			d_rawEpCaller.uploadRaw(ep, E, stream); d_rawElCaller.uploadRaw(el, E, stream); d_rawDim.uploadRaw(edim, E, stream);
 			d_rawEp.resize(E);
 			HIP_TRY(hipMemcpyAsync(d_rawEp.data(), d_rawEpCaller.data(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, stream));
+			// internal landmark order from the pose numbering in force (the caller's here; applyPoseOrder renews it under a new one)
+			if (landmarkOrderAllowed()) computeLandmarkOrder(); else resetLandmarkOrder();
 		}
 		const bool keepValues = promisedValues && reuseSort && sortedValuesValid && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
 		const bool defer = deferValues && !keepValues && E > 0;
@@ -180,6 +182,8 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 		d_state.upload(state, stream);
 		d_cam.upload(camv, stream);
 	}
+	if (!useDev && lmOrderActive) { lmOrderActive = false; }          // (host pipeline: the caller's landmark order)
+	if (lmOrderActive) landmarkRowsInPlace(d_state.data() + 7 * (size_t)Pt, Lt, 3, true);
 	d_backup.resize(nState);
 	dropSnapshots();
 	d_perEdge.resize(E);
@@ -719,13 +723,120 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	sys.spmv_rows = spmvRows;
 	sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 	sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
+	buildStagedSchur(nblk, nBig);
 	haveStructure = true;
+}
+
+// Lists of the staged block pass (ba_linearize.hip: schur_stage_body), from device arrays only: product positions sorted by (stage, block)
+// -> slots; slots sorted by block -> the lists of the second pass.  Two host synchronisations (valid products, slots).
+void cuba_hip_solver::buildStagedSchur(int nblk, int nBig)
+{
+	st.staged = 0; st.nStages = 0; st.nSlots = 0;
+	const size_t np = d_prodEa.size();
+	if (schurStaged == 0 || np == 0 || nblk == 0 || nBig > 0 || diagProdBlocks > 0 || Pf == 0) return;
+	const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
+	const int nStages = (g.e_end - g.e_begin + topo::STAGE_RECORDS - 1) / topo::STAGE_RECORDS;
+	if (nStages <= 0) return;
+	d_k64a.resize(std::max(np, d_k64a.size())); d_k64b.resize(std::max(np, d_k64b.size()));
+	d_v32a.resize(std::max(np, d_v32a.size())); d_v32b.resize(std::max(np, d_v32b.size()));
+	d_tmpI0.resize(std::max(np, d_tmpI0.size())); d_tmpI1.resize(std::max(np, d_tmpI1.size()));
+	d_counters.resize(topo::CNT_COUNT);
+	d_counters.zero(stream);
+	sortTemp(np);
+	topo::launch_stage_keys(d_prodPtr.data(), st.prod_beg, st.prod_end, nblk, d_prodLm.data(), d_lmptr.data(), g.e_begin, np, d_k64a.data(), d_v32a.data(), d_counters.data(), stream);
+	HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), d_topoTemp.size(), d_k64a.data(), d_k64b.data(), d_v32a.data(), d_v32b.data(), np, 32 + bitsFor(nStages), stream));
+	const int nInvalid = readBack(d_counters.data() + topo::CNT_BAD);
+	const size_t nvalid = np - (size_t)nInvalid;
+	if (nvalid == 0) return;
+	topo::launch_entry_heads(d_k64b.data(), nvalid, d_tmpI0.data(), stream);
+	HIP_TRY(topo::inclusive_scan_i32(d_topoTemp.data(), d_topoTemp.size(), d_tmpI0.data(), d_tmpI1.data(), nvalid, stream));
+	const int nSlots = readBack(d_tmpI1.data() + (nvalid - 1));
+	d_slotPtr.resize((size_t)nSlots + 1); d_slotBlk.resize(nSlots); d_slotStage.resize(nSlots);
+	d_sEa.resize(nvalid); d_sEb.resize(nvalid); d_sLm.resize(nvalid);
+	topo::launch_stage_slots(d_k64b.data(), d_v32b.data(), d_tmpI1.data(), nvalid, d_prodEa.data(), d_prodEb.data(), d_prodLm.data(),
+		d_slotPtr.data(), d_slotBlk.data(), d_slotStage.data(), d_sEa.data(), d_sEb.data(), d_sLm.data(), stream);
+	d_stagePtr.resize((size_t)nStages + 1); d_stageLm.resize((size_t)nStages + 1);
+	topo::launch_segment_ptr(d_slotStage.data(), nSlots, nStages, d_stagePtr.data(), stream);
+	topo::launch_stage_landmarks(d_lmptr.data(), lo, hi, g.e_begin, nStages, d_stageLm.data(), stream);
+	// second pass: the slots of every block, in stage order (a stable sort of the (stage, block)-ordered slots by block)
+	const size_t ns = (size_t)nSlots;
+	d_k32a.resize(std::max(ns, d_k32a.size())); d_k32b.resize(std::max(ns, d_k32b.size()));
+	d_v32a.resize(std::max(ns, d_v32a.size())); d_v32b.resize(std::max(ns, d_v32b.size()));
+	d_tmpI0.resize(std::max(ns, d_tmpI0.size()));
+	sortTemp(ns);
+	topo::launch_copy_int_to_u32(d_slotBlk.data(), d_k32a.data(), nSlots, stream);
+	topo::launch_iota_u32(d_v32a.data(), ns, stream);
+	HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), ns, bitsFor(nblk), stream));
+	d_blkSlots.resize(ns); d_blkSlotPtr.resize((size_t)nblk + 1);
+	topo::launch_copy_u32_to_int(d_v32b.data(), d_blkSlots.data(), nSlots, stream);
+	topo::launch_copy_u32_to_int(d_k32b.data(), d_tmpI0.data(), nSlots, stream);
+	topo::launch_segment_ptr(d_tmpI0.data(), nSlots, nblk, d_blkSlotPtr.data(), stream);
+	d_partial.resize((size_t)36 * ns);
+	st.staged = 1; st.nStages = nStages; st.nSlots = nSlots;
+	st.stage_lm = d_stageLm.data(); st.stage_ptr = d_stagePtr.data(); st.slot_ptr = d_slotPtr.data();
+	st.s_ea = d_sEa.data(); st.s_eb = d_sEb.data(); st.s_lm = d_sLm.data(); st.partial = d_partial.data();
+	st.blk_slot_ptr = d_blkSlotPtr.data(); st.blk_slots = d_blkSlots.data();
+	if (std::getenv("CUBA_HIP_DEBUG"))
+		std::fprintf(stderr, "[cuba_hip] staged block pass: %d stages, %d slots for %zu products (%.1f per slot), %.1f MB of partial blocks\n",
+			nStages, nSlots, nvalid, (double)nvalid / nSlots, 288.0 * nSlots / 1e6);
 }
 
 void cuba_hip_solver::fillProdLm()
 {
 	d_prodLm.resize(d_prodEa.size());
 	topo::launch_gather_int(d_prodEa.data(), d_elm.data(), d_prodEa.size(), d_prodLm.data(), stream);
+}
+
+void cuba_hip_solver::computeLandmarkOrder()
+{
+	d_lmFirst.resize(Lt); d_lmLast.resize(Lt); d_lmMap.resize(Lt); d_rawEl.resize(E);
+	d_k64a.resize(std::max((size_t)Lf, d_k64a.size())); d_k64b.resize(std::max((size_t)Lf, d_k64b.size()));
+	d_v32a.resize(std::max((size_t)Lf, d_v32a.size())); d_v32b.resize(std::max((size_t)Lf, d_v32b.size()));
+	sortTemp((size_t)Lf);
+	topo::launch_lm_first_last(d_rawEp.data(), d_rawElCaller.data(), E, Lt, d_lmFirst.data(), d_lmLast.data(), stream);
+	topo::launch_lm_order_keys(d_lmFirst.data(), d_lmLast.data(), Lf, d_k64a.data(), d_v32a.data(), stream);
+	HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), d_topoTemp.size(), d_k64a.data(), d_k64b.data(), d_v32a.data(), d_v32b.data(), (size_t)Lf, 64, stream));
+	topo::launch_lm_order_map(d_v32b.data(), Lf, Lt, d_lmMap.data(), stream);
+	topo::launch_remap_landmarks(d_rawElCaller.data(), d_lmMap.data(), E, d_rawEl.data(), stream);
+	lmOrderActive = true;
+	dropSnapshots();
+}
+
+void cuba_hip_solver::switchLandmarkOrder(bool on)
+{
+	if (on == lmOrderActive || !devTopology || E == 0 || d_rawElCaller.size() != (size_t)E) return;
+	Scalar* X = d_state.data() + 7 * (size_t)Pt;
+	if (lmOrderActive) landmarkRowsInPlace(X, Lt, 3, false);
+	if (on) { computeLandmarkOrder(); landmarkRowsInPlace(X, Lt, 3, true); }
+	else resetLandmarkOrder();
+	runDeviceEdgeSort();
+	sync();
+	haveStructure = false; hostTopoValid = false; hostPatternValid = false;
+}
+
+void cuba_hip_solver::resetLandmarkOrder()
+{
+	d_rawEl.resize(E);
+	if (E) HIP_TRY(hipMemcpyAsync(d_rawEl.data(), d_rawElCaller.data(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, stream));
+	if (lmOrderActive) dropSnapshots();
+	lmOrderActive = false;
+}
+
+void cuba_hip_solver::landmarkRowsInPlace(Scalar* rows, int nrows, int width, bool toInternal)
+{
+	const size_t n = (size_t)nrows * width;
+	if (!n) return;
+	d_rowTmp.resize(std::max(n, d_rowTmp.size()));
+	HIP_TRY(hipMemcpyAsync(d_rowTmp.data(), rows, sizeof(Scalar) * n, hipMemcpyDeviceToDevice, stream));
+	topo::launch_permute_rows(d_rowTmp.data(), rows, d_lmMap.data(), nrows, width, toInternal, stream);
+}
+
+const Scalar* cuba_hip_solver::landmarkRowsForCaller(const Scalar* rows, int nrows, int width)
+{
+	if (!lmOrderActive || nrows == 0) return rows;
+	d_rowTmp.resize(std::max((size_t)nrows * width, d_rowTmp.size()));
+	topo::launch_permute_rows(rows, d_rowTmp.data(), d_lmMap.data(), nrows, width, false, stream);
+	return d_rowTmp.data();
 }
 
 void cuba_hip_solver::resetPoseOrder()
@@ -831,6 +942,13 @@ void cuba_hip_solver::applyPoseOrder(const std::vector<int>& newOfOld)
 	d_state.upload(state, stream); d_cam.upload(camv, stream);
 	d_poseMap.upload(poseNewOfOld, stream);
 	topo::launch_remap_poses(d_rawEpCaller.data(), d_poseMap.data(), E, Pf, d_rawEp.data(), stream);
+	if (lmOrderActive || landmarkOrderAllowed())
+	{
+		// (the landmark rows just went up in the order that ends here)
+		if (lmOrderActive) landmarkRowsInPlace(d_state.data() + 7 * (size_t)Pt, Lt, 3, false);
+		computeLandmarkOrder();
+		landmarkRowsInPlace(d_state.data() + 7 * (size_t)Pt, Lt, 3, true);
+	}
 	runDeviceEdgeSort();
 	sync();          // the host vectors above go out of scope
 	dropSnapshots(); // (round-3 advisor: a snapshot taken in the previous order would assign pose rows to the wrong poses)

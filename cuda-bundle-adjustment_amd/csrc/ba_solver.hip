@@ -139,6 +139,8 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
 		else if (k == "device_lm_decision") s->deviceDecision = value != 0;
+		else if (k == "landmark_reorder") s->lmReorder = value != 0;         // (takes effect with the next cuba_hip_set_graph)
+		else if (k == "schur_staged") { s->schurStaged = (int)value; s->haveStructure = false; }
 		else if (k == "spmv_upper") { s->spmvUpper = (int)value; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
@@ -267,7 +269,7 @@ int cuba_hip_get_solution(cuba_hip_solver* s, double* q, double* t, double* Xw)
 		const Scalar* base = s->d_state.data();
 		if (q) { s->downloadAsDouble(base, q, (size_t)4 * s->Pt); s->permutePoseArray(q, 4, false); }
 		if (t) { s->downloadAsDouble(base + 4 * (size_t)s->Pt, t, (size_t)3 * s->Pt); s->permutePoseArray(t, 3, false); }
-		if (Xw) s->downloadAsDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
+		if (Xw) s->downloadAsDouble(s->landmarkRowsForCaller(base + 7 * (size_t)s->Pt, s->Lt, 3), Xw, (size_t)3 * s->Lt);
 	});
 }
 
@@ -279,7 +281,11 @@ int cuba_hip_set_solution(cuba_hip_solver* s, const double* q, const double* t, 
 		Scalar* base = s->d_state.data();
 		if (q) { std::vector<double> v(q, q + (size_t)4 * s->Pt); s->permutePoseArray(v.data(), 4, true); s->uploadFromDouble(base, v.data(), v.size()); }
 		if (t) { std::vector<double> v(t, t + (size_t)3 * s->Pt); s->permutePoseArray(v.data(), 3, true); s->uploadFromDouble(base + 4 * (size_t)s->Pt, v.data(), v.size()); }
-		if (Xw) s->uploadFromDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
+		if (Xw)
+		{
+			s->uploadFromDouble(base + 7 * (size_t)s->Pt, Xw, (size_t)3 * s->Lt);
+			if (s->lmOrderActive) s->landmarkRowsInPlace(base + 7 * (size_t)s->Pt, s->Lt, 3, true);
+		}
 	});
 }
 
@@ -385,6 +391,9 @@ int cuba_hip_get_array(cuba_hip_solver* s, int which, double* out, size_t* count
 		if (count) *count = n;
 		if (out && n)
 		{
+			// (landmark-indexed arrays: back to the caller's landmark numbering)
+			if (which == CUBA_HIP_ARRAY_XL) src = s->landmarkRowsForCaller(src, s->Lf, 3);
+			else if (which == CUBA_HIP_ARRAY_LM_SYS) src = s->landmarkRowsForCaller(src, s->Lf, 9);
 			s->downloadAsDouble(src, out, n);
 			if (s->reorderActive)
 			{
@@ -423,11 +432,15 @@ int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_
 		{
 			if (s->partHi >= 0) s->haveStructure = false;
 			s->partLo = 0; s->partHi = -1;
+			s->switchLandmarkOrder(s->landmarkOrderAllowed());      // (back to the internal landmark order a partition had ended)
 			return;
 		}
 		if (landmark_begin < 0 || landmark_end > s->Lt || landmark_begin > landmark_end) throw ArgError{ "bad landmark range" };
 		s->partLo = landmark_begin; s->partHi = landmark_end;
 		s->haveStructure = false;
+		// the range is in the caller's landmark numbering: unless it is the whole range, the internal landmark order ends here (rows of the
+		// estimates back to the caller's order, edges sorted again)
+		s->switchLandmarkOrder(s->landmarkOrderAllowed());
 	});
 }
 

@@ -454,6 +454,138 @@ void launch_pattern_entries(const int* lm_ptr, const int* e_pose, const int* e_l
 	if (n > 0) hipLaunchKernelGGL(pattern_entries_kernel, grid_for(n), dim3(T), 0, s, lm_ptr, e_pose, e_lm, nfree, pairBase, E, Lf, Pf, keys, vals);
 }
 
+namespace
+{
+__global__ __launch_bounds__(T) void stage_keys_kernel(const int* __restrict__ prod_ptr, const int* __restrict__ prod_beg, const int* __restrict__ prod_end, int nblk,
+	const int* __restrict__ prod_lm, const int* __restrict__ lm_ptr, int e_begin, size_t nprod, uint64_t* keys, uint32_t* vals, int* counters)
+{
+	const size_t p = (size_t)blockIdx.x * T + threadIdx.x;
+	if (p >= nprod) return;
+	int lo = 0, hi = nblk;                 // block b with prod_ptr[b] <= p < prod_ptr[b + 1]
+	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((size_t)prod_ptr[mid] <= p) lo = mid; else hi = mid; }
+	const int b = lo;
+	const bool valid = p >= (size_t)prod_beg[b] && p < (size_t)prod_end[b];
+	if (!valid) { keys[p] = ~0ULL; vals[p] = (uint32_t)p; atomicAdd(&counters[CNT_BAD], 1); return; }
+	const int stage = (lm_ptr[prod_lm[p]] - e_begin) / STAGE_RECORDS;
+	keys[p] = ((uint64_t)(uint32_t)stage << 32) | (uint32_t)b;
+	vals[p] = (uint32_t)p;
+}
+
+__global__ __launch_bounds__(T) void stage_slots_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ order, const int* __restrict__ slotOf, size_t nvalid,
+	const int* __restrict__ prod_ea, const int* __restrict__ prod_eb, const int* __restrict__ prod_lm,
+	int* slot_ptr, int* slot_blk, int* slot_stage, int* s_ea, int* s_eb, int* s_lm)
+{
+	const size_t i = (size_t)blockIdx.x * T + threadIdx.x;
+	if (i >= nvalid) return;
+	const uint32_t p = order[i];
+	s_ea[i] = prod_ea[p]; s_eb[i] = prod_eb[p]; s_lm[i] = prod_lm[p];
+	const int slot = slotOf[i] - 1;
+	if (i == 0 || keys[i] != keys[i - 1])
+	{
+		slot_ptr[slot] = (int)i; slot_blk[slot] = (int)(uint32_t)keys[i]; slot_stage[slot] = (int)(keys[i] >> 32);
+	}
+	if (i == nvalid - 1) slot_ptr[slot + 1] = (int)nvalid;
+}
+
+__global__ __launch_bounds__(T) void stage_landmarks_kernel(const int* __restrict__ lm_ptr, int lo, int hi, int e_begin, int nStages, int* stage_lm)
+{
+	const int k = blockIdx.x * T + threadIdx.x;
+	if (k > nStages) return;
+	const long long target = (long long)e_begin + (long long)k * STAGE_RECORDS;
+	int a = lo, b = hi;                    // first landmark l in [lo, hi] with lm_ptr[l] >= target (lm_ptr[hi] = end of the range)
+	while (a < b) { const int mid = (a + b) >> 1; if (lm_ptr[mid] >= target) b = mid; else a = mid + 1; }
+	stage_lm[k] = a;
+}
+
+__global__ __launch_bounds__(T) void iota_u32_kernel(uint32_t* v, size_t n) { const size_t i = (size_t)blockIdx.x * T + threadIdx.x; if (i < n) v[i] = (uint32_t)i; }
+__global__ __launch_bounds__(T) void copy_int_u32_kernel(const int* in, uint32_t* out, int n) { const int i = blockIdx.x * T + threadIdx.x; if (i < n) out[i] = (uint32_t)in[i]; }
+}
+
+namespace
+{
+__global__ __launch_bounds__(T) void lm_first_last_init_kernel(int Lt, int* first, int* last)
+{
+	const int l = blockIdx.x * T + threadIdx.x;
+	if (l < Lt) { first[l] = 0x7fffffff; last[l] = -1; }
+}
+__global__ __launch_bounds__(T) void lm_first_last_kernel(const int* __restrict__ ep, const int* __restrict__ el, int E, int* first, int* last)
+{
+	const int e = blockIdx.x * T + threadIdx.x;
+	if (e >= E) return;
+	atomicMin(&first[el[e]], ep[e]);          // (integer min / max: the result does not depend on the order of the atomics)
+	atomicMax(&last[el[e]], ep[e]);
+}
+__global__ __launch_bounds__(T) void lm_order_keys_kernel(const int* first, const int* last, int Lf, uint64_t* keys, uint32_t* vals)
+{
+	const int l = blockIdx.x * T + threadIdx.x;
+	if (l >= Lf) return;
+	keys[l] = ((uint64_t)(uint32_t)first[l] << 32) | (uint32_t)(last[l] + 1);
+	vals[l] = (uint32_t)l;
+}
+__global__ __launch_bounds__(T) void lm_order_map_kernel(const uint32_t* order, int Lf, int Lt, int* newOfOld)
+{
+	const int r = blockIdx.x * T + threadIdx.x;
+	if (r < Lf) newOfOld[order[r]] = r;
+	else if (r < Lt) newOfOld[r] = r;
+}
+__global__ __launch_bounds__(T) void remap_landmarks_kernel(const int* __restrict__ elIn, const int* __restrict__ newOfOld, int E, int* elOut)
+{
+	const int e = blockIdx.x * T + threadIdx.x;
+	if (e < E) elOut[e] = newOfOld[elIn[e]];
+}
+__global__ __launch_bounds__(T) void permute_rows_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, const int* __restrict__ newOfOld, size_t total, int width, int toInternal)
+{
+	const size_t i = (size_t)blockIdx.x * T + threadIdx.x;
+	if (i >= total) return;
+	const size_t l = i / width; const int k = (int)(i - l * width);
+	const size_t m = (size_t)newOfOld[l];
+	if (toInternal) dst[m * width + k] = src[i]; else dst[i] = src[m * width + k];
+}
+}
+
+void launch_lm_first_last(const int* ep, const int* el, int E, int Lt, int* first, int* last, hipStream_t s)
+{
+	if (Lt > 0) hipLaunchKernelGGL(lm_first_last_init_kernel, grid_for((size_t)Lt), dim3(T), 0, s, Lt, first, last);
+	if (E > 0) hipLaunchKernelGGL(lm_first_last_kernel, grid_for((size_t)E), dim3(T), 0, s, ep, el, E, first, last);
+}
+void launch_lm_order_keys(const int* first, const int* last, int Lf, uint64_t* keys, uint32_t* vals, hipStream_t s)
+{
+	if (Lf > 0) hipLaunchKernelGGL(lm_order_keys_kernel, grid_for((size_t)Lf), dim3(T), 0, s, first, last, Lf, keys, vals);
+}
+void launch_lm_order_map(const uint32_t* order, int Lf, int Lt, int* newOfOld, hipStream_t s)
+{
+	if (Lt > 0) hipLaunchKernelGGL(lm_order_map_kernel, grid_for((size_t)Lt), dim3(T), 0, s, order, Lf, Lt, newOfOld);
+}
+void launch_remap_landmarks(const int* elIn, const int* newOfOld, int E, int* elOut, hipStream_t s)
+{
+	if (E > 0) hipLaunchKernelGGL(remap_landmarks_kernel, grid_for((size_t)E), dim3(T), 0, s, elIn, newOfOld, E, elOut);
+}
+void launch_permute_rows(const Scalar* src, Scalar* dst, const int* newOfOld, int nrows, int width, bool toInternal, hipStream_t s)
+{
+	const size_t total = (size_t)nrows * width;
+	if (total) hipLaunchKernelGGL(permute_rows_kernel, grid_for(total), dim3(T), 0, s, src, dst, newOfOld, total, width, toInternal ? 1 : 0);
+}
+
+void launch_stage_keys(const int* prod_ptr, const int* prod_beg, const int* prod_end, int nblk, const int* prod_lm, const int* lm_ptr, int e_begin,
+	size_t nprod, uint64_t* keys, uint32_t* vals, int* counters, hipStream_t s)
+{
+	if (nprod) hipLaunchKernelGGL(stage_keys_kernel, grid_for(nprod), dim3(T), 0, s, prod_ptr, prod_beg, prod_end, nblk, prod_lm, lm_ptr, e_begin, nprod, keys, vals, counters);
+}
+
+void launch_stage_slots(const uint64_t* keys, const uint32_t* order, const int* slotOf, size_t nvalid, const int* prod_ea, const int* prod_eb, const int* prod_lm,
+	int* slot_ptr, int* slot_blk, int* slot_stage, int* s_ea, int* s_eb, int* s_lm, hipStream_t s)
+{
+	if (nvalid) hipLaunchKernelGGL(stage_slots_kernel, grid_for(nvalid), dim3(T), 0, s, keys, order, slotOf, nvalid, prod_ea, prod_eb, prod_lm, slot_ptr, slot_blk, slot_stage, s_ea, s_eb, s_lm);
+}
+
+void launch_stage_landmarks(const int* lm_ptr, int lo, int hi, int e_begin, int nStages, int* stage_lm, hipStream_t s)
+{
+	hipLaunchKernelGGL(stage_landmarks_kernel, grid_for((size_t)nStages + 1), dim3(T), 0, s, lm_ptr, lo, hi, e_begin, nStages, stage_lm);
+}
+
+void launch_iota_u32(uint32_t* v, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(iota_u32_kernel, grid_for(n), dim3(T), 0, s, v, n); }
+void launch_copy_int_to_u32(const int* in, uint32_t* out, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(copy_int_u32_kernel, grid_for((size_t)n), dim3(T), 0, s, in, out, n); }
+
 void launch_entry_heads(const uint64_t* keys, size_t n, int* head, hipStream_t s)
 {
 	if (n > 0) hipLaunchKernelGGL(entry_heads_kernel, grid_for(n), dim3(T), 0, s, keys, n, head);

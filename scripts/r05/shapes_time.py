@@ -11,7 +11,17 @@ from cuba_amd.synth import synth_named
 RK = ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815))))
 shape = sys.argv[1]
 opts = {k: float(v) for k, v in (a.split("=") for a in sys.argv[2:] if "=" in a)}
-fp = flatten(synth_named(shape))
+g = synth_named(shape)
+if "sortlm" in sys.argv:
+    # landmark ids re-assigned in the order of the first (then the last) pose that observes them: what creation-ordered map points look like
+    lut = np.zeros(int(g.lm_ids.max()) + 1, dtype=np.int64); lut[g.lm_ids] = np.arange(g.nlandmarks)
+    vl = lut[np.concatenate([g.mono_vl, g.stereo_vl])]; vp = np.concatenate([g.mono_vp, g.stereo_vp])
+    first = np.full(g.nlandmarks, 1 << 40); np.minimum.at(first, vl, vp)
+    last = np.zeros(g.nlandmarks, dtype=np.int64); np.maximum.at(last, vl, vp)
+    rank = np.empty(g.nlandmarks, dtype=np.int64); rank[np.lexsort((last, first))] = np.arange(g.nlandmarks)
+    new_ids = int(g.lm_ids.min()) + rank
+    g.mono_vl = new_ids[lut[g.mono_vl]]; g.stereo_vl = new_ids[lut[g.stereo_vl]]; g.lm_ids = new_ids
+fp = flatten(g)
 h = HipSolver(fp, RK, **opts)
 chi = h.optimize(10)["chi2"]
 h.set_state(fp.q, fp.t, fp.Xw); h.optimize(1)

@@ -468,8 +468,8 @@ def test_device_and_host_setup_agree(solvers, small_graph):
              flatten(with_fixed(small_graph, fixed_lm_rows=range(small_graph.nlandmarks))),          # pose-only: no landmark is free
              flatten(shuffled_pose_ids(g_big, seed=3)), flatten(g_big)]
     for fp in cases:
-        # (pose_reorder = 0: the internal renumbering of badly ordered poses exists in the device pipeline only)
-        a = HipSolver(fp, RK_HUBER, pose_reorder=0); b = HipSolver(fp, RK_HUBER, device_setup=0)
+        # (pose_reorder = 0, landmark_reorder = 0: the internal renumberings of poses and landmarks exist in the device pipeline only)
+        a = HipSolver(fp, RK_HUBER, pose_reorder=0, landmark_reorder=0); b = HipSolver(fp, RK_HUBER, device_setup=0)
         ra, rb = a.optimize(6)["chi2"], b.optimize(6)["chi2"]
         if fp.Pf and fp.Lf:
             (rpa, cia), (rpb, cib) = a.hsc_structure(), b.hsc_structure()
@@ -524,7 +524,7 @@ def test_sparse_covisibility_every_product_its_own_block(solvers):
     fp = flatten(pairwise_graph(64, 1900, seed=3))
     assert fp.E == 2 * fp.Lt
     o = OracleSolver(fp, RK_HUBER); r = o.optimize(6)
-    a = HipSolver(fp, RK_HUBER, pose_reorder=0); b = HipSolver(fp, RK_HUBER, device_setup=0)
+    a = HipSolver(fp, RK_HUBER, pose_reorder=0, landmark_reorder=0); b = HipSolver(fp, RK_HUBER, device_setup=0)
     ra, rb = a.optimize(6)["chi2"], b.optimize(6)["chi2"]
     c = a.counters()
     assert 2 * c["hsc_blocks"] - fp.Pf > fp.E > fp.Pf + fp.Lt                                # the shape the finding is about
@@ -594,7 +594,7 @@ def test_random_graphs_device_setup_host_setup_oracle(solvers, seed):
     for name in ("eP", "eL", "eDim", "omega", "meas", "edge_src"):
         setattr(fp, name, np.ascontiguousarray(getattr(fp, name)[keep]))
     o = OracleSolver(fp, RK_HUBER); r = o.optimize(5)
-    a = HipSolver(fp, RK_HUBER); b = HipSolver(fp, RK_HUBER, device_setup=0)
+    a = HipSolver(fp, RK_HUBER, landmark_reorder=0); b = HipSolver(fp, RK_HUBER, device_setup=0)      # (the landmark renumbering is the device pipeline's)
     ra, rb = a.optimize(5)["chi2"], b.optimize(5)["chi2"]
     assert np.array_equal(ra, rb)
     assert all(np.array_equal(x, y) for x, y in zip(a.state(), b.state()))
