@@ -826,7 +826,7 @@ def test_internal_landmark_order_is_invisible_at_the_boundary(solvers):
     b.snapshot_state(); r1 = b.optimize(3)["chi2"]; b.restore_state(); r2 = b.optimize(3)["chi2"]
     assert rel(r1, r2) < 1e-10                       # (not bit-identical: the second run starts with the first one's coarse inverse)
     # a second upload of the same graph keeps the order and the results; a landmark partition ends it
-    b.set_graph(fp); assert np.array_equal(b.optimize(8)["chi2"], rb)
+    b.set_graph(fp); assert rel(b.optimize(8)["chi2"], rb) < 1e-10      # (same order, same run up to the first solve's carried-over coarse inverse)
     b.set_graph(fp); b.set_partition(0, fp.Lt // 2)
     c = HipSolver(fp, RK_HUBER, landmark_reorder=0, pcg_tol=1e-11); c.set_partition(0, fp.Lt // 2)
     for x, y in zip(b.state(), c.state()):
