@@ -73,17 +73,6 @@ struct DeviceStructure
 	int nCb = 0;                       // non-empty coarse blocks
 	int *cb_I = nullptr, *cb_J = nullptr, *cb_ptr = nullptr, *cb_blk = nullptr;   // cb_blk: adjacency-style id (bit 31 = transposed)
 	Scalar *cb_wi = nullptr, *cb_wj = nullptr;                                    // weights of the fine (row, column) poses of every list entry in the linear coarse functions
-	// staged block pass (round 5; ba_linearize.hip: schur_stage_body): the off-diagonal blocks from stages of ~256 consecutive records whose
-	// operands are staged in LDS once, partial blocks per (stage, block) slot, then one fixed-order sum per block
-	int staged = 0;
-	int nStages = 0, nSlots = 0;
-	int* stage_lm = nullptr;           // [nStages + 1] first landmark of every stage
-	int* stage_ptr = nullptr;          // [nStages + 1] slots of every stage
-	int* slot_ptr = nullptr;           // [nSlots + 1] products of every slot, in s_ea / s_eb / s_lm (sorted by (stage, block), landmark order inside)
-	int *s_ea = nullptr, *s_eb = nullptr, *s_lm = nullptr;
-	Scalar* partial = nullptr;         // [36 * nSlots] partial blocks, layout of an Hsc block
-	int* blk_slot_ptr = nullptr;       // [nblk + 1] slots of every block ...
-	int* blk_slots = nullptr;          // [nSlots] ... in stage order
 	Scalar* e_rec = nullptr;           // [8*E] per-edge linearisation record {Xc[3], w' (sign bit = stereo), r[3], landmark (integer bits)}
 	int mixed = 0;                     // fp64 library only: 1 = records and the per-edge arithmetic of the pose / block passes in fp32
 };

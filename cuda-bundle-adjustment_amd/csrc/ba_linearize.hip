@@ -6,7 +6,6 @@
 //   schur_pass_kernel = the two in ONE launch; pose_maxdiag_kernel (maxDiagonal :877-904).
 
 #include "ba_device.hpp"
-#include "ba_structure.hpp"
 
 namespace cubahip
 {
@@ -513,130 +512,6 @@ __global__ __launch_bounds__(256) void block_pass_kernel(DeviceGraph g, DeviceSt
 	block_pass_body<ET>(g, st, sys, blockIdx.x);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Staged block pass (round 5).  The destination-major pass above gathers three 64-byte sectors per product from all over the record
-// array (5-9 x the algorithmic bytes, the vector L1 stalled on pending misses for 70 % of the launch) and rebuilds each record's
-// camera-frame operand once per product.  Here a workgroup takes a STAGE -- the landmarks whose first sorted edge lies in one window of 256
-// records: <= 319 consecutive records, loaded coalesced --, turns every record into its operand (X, M: 12 numbers) ONCE, in LDS, and forms the
-// stage's products from LDS: for every block the stage touches (a "slot": four lanes, products in landmark order) a partial 6 x 6 block,
-// written once.  schur_reduce_kernel then adds the partial blocks of every block in stage order.  No atomics, fixed orders: bit-reproducible
-// like the pass above (but a different association of the same sums: results agree to rounding, not bit for bit).
-// Needs: no landmark with more than 64 observations (st.nBig == 0), no duplicate observations (st.nDiagProd == 0); else the pass above runs.
-// ---------------------------------------------------------------------------------------------------
-constexpr int STG_MAXREC = topo::STAGE_RECORDS + 64;       // records a stage can hold
-constexpr int STG_LANES = 4;                               // lanes per slot
-
-template <typename ET>
-__device__ __forceinline__ void schur_stage_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int stage)
-{
-	__shared__ ET opX[STG_MAXREC][3];
-	__shared__ ET opM[STG_MAXREC][9];
-	__shared__ ET linv[STG_MAXREC][6];
-	const int tid = threadIdx.x;
-	const int l0 = st.stage_lm[stage], l1 = st.stage_lm[stage + 1];
-	const int sl0 = st.stage_ptr[stage], sl1 = st.stage_ptr[stage + 1];
-	if (sl0 == sl1) return;                                  // (no product in this stage: nothing to stage either)
-	const int e0 = g.lm_ptr[l0], e1 = g.lm_ptr[l1];
-	const ET* recs = reinterpret_cast<const ET*>(st.e_rec);
-	for (int t = tid; t < e1 - e0; t += 256)
-	{
-		const int pe = g.e_pose[e0 + t] & ~STEREO_BIT;
-		if (pe < g.Pf)                                        // (edges of fixed poses take part in no product)
-		{
-			ET q[4], cam[5];
-			load_pose_as<ET>(g, pe, q, cam);
-			const Rot3T<ET> R = quat_to_rot(q[0], q[1], q[2], q[3]);
-			ProductOperand<ET> o;
-			product_operand<ET>(recs + REC * (size_t)(e0 + t), R, cam, o);
-#pragma unroll
-			for (int k = 0; k < 3; k++) opX[t][k] = o.X[k];
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-#pragma unroll
-				for (int k = 0; k < 3; k++) opM[t][3 * i + k] = o.M[i][k];
-		}
-	}
-	for (int t = tid; t < l1 - l0; t += 256)
-	{
-		const int il = l0 + t;
-		if (il < g.Lf)
-		{
-			const Scalar* li = st.inv_rows8 ? sys.lm_inv + 8 * (size_t)il : sys.lm_sys + 9 * (size_t)il;
-#pragma unroll
-			for (int k = 0; k < 6; k++) linv[t][k] = (ET)li[k];
-		}
-	}
-	__syncthreads();
-	const int gi = tid / STG_LANES, gl = tid % STG_LANES;
-	for (int base = sl0; base < sl1; base += 256 / STG_LANES)          // (trip count uniform over the workgroup: shuffles below)
-	{
-		const int slot = base + gi;
-		const bool on = slot < sl1;
-		ET T[6][6];
-#pragma unroll
-		for (int r = 0; r < 6; r++)
-#pragma unroll
-			for (int c = 0; c < 6; c++) T[r][c] = 0;
-		const int p1 = on ? st.slot_ptr[slot + 1] : 0;
-		for (int p = (on ? st.slot_ptr[slot] : 0) + gl; p < p1; p += STG_LANES)
-		{
-			const int ia = st.s_ea[p] - e0, ib = st.s_eb[p] - e0, il = st.s_lm[p] - l0;
-			ProductOperand<ET> A, B;
-			ET inv[6];
-#pragma unroll
-			for (int k = 0; k < 3; k++) { A.X[k] = opX[ia][k]; B.X[k] = opX[ib][k]; }
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-#pragma unroll
-				for (int k = 0; k < 3; k++) { A.M[i][k] = opM[ia][3 * i + k]; B.M[i][k] = opM[ib][3 * i + k]; }
-#pragma unroll
-			for (int k = 0; k < 6; k++) inv[k] = linv[il][k];
-			product_accumulate<ET>(A, B, inv, T);
-		}
-		// sum over the slot's lanes (in Scalar), then the partial block in the layout of an Hsc block: element (r, c) at c * 6 + r
-		Scalar* dst = st.partial + 36 * (size_t)(on ? slot : sl0);
-#pragma unroll
-		for (int c = 0; c < 6; c++)
-#pragma unroll
-			for (int r = 0; r < 6; r++)
-			{
-				Scalar v = (Scalar)T[r][c];
-				v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
-				if (on && (c * 6 + r) % STG_LANES == gl) dst[c * 6 + r] = v;
-			}
-	}
-}
-
-// hsc block = - sum of its partial blocks, in stage order (blocks without a slot are left alone: diagonal blocks belong to the pose pass, and
-// a landmark partition zeroes the reduction buffer beforehand)
-__global__ __launch_bounds__(256) void schur_reduce_kernel(DeviceStructure st, DeviceSystem sys)
-{
-	const int b = blockIdx.x * 7 + (int)threadIdx.x / 36, e = (int)threadIdx.x % 36;
-	if (threadIdx.x >= 252 || b >= st.nblk) return;
-	const int s0 = st.blk_slot_ptr[b], s1 = st.blk_slot_ptr[b + 1];
-	if (s0 == s1) return;
-	Scalar acc = 0;
-	for (int k = s0; k < s1; k += 8)
-	{
-		int sl[8]; Scalar v[8];
-#pragma unroll
-		for (int m = 0; m < 8; m++) sl[m] = st.blk_slots[min(k + m, s1 - 1)];
-#pragma unroll
-		for (int m = 0; m < 8; m++) v[m] = st.partial[36 * (size_t)sl[m] + e];
-#pragma unroll
-		for (int m = 0; m < 8; m++) acc += k + m < s1 ? v[m] : Scalar(0);
-	}
-	sys.hsc[36 * (size_t)b + e] = -acc;
-}
-
-// pose pass + stages in one launch (the pose workgroups first, as in schur_pass_kernel)
-template <typename ET>
-__global__ __launch_bounds__(256) void schur_staged_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int nPoseGroups)
-{
-	if ((int)blockIdx.x < nPoseGroups) pose_pass_body<1, ET>(g, st, sys, blockIdx.x);
-	else schur_stage_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
-}
-
 // Pose pass and block pass in one launch: they write disjoint parts of the reduced system (diagonal blocks / bp / bsc vs the
 // off-diagonal blocks) from the same records.  The pose workgroups come first (one wave per pose: 7 dependent trips at KITTI-00)
 // and run under the block workgroups.
@@ -664,13 +539,6 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 	{
 		if (mode == 0) hipLaunchKernelGGL((big_lm_pass_kernel<0, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
 		else hipLaunchKernelGGL((big_lm_pass_kernel<1, ET>), dim3(st.nBig), dim3(256), 0, s, g, st, sys, lambda);
-	}
-	if (mode == 1 && st.staged && g.Pf > 0)
-	{
-		const int np = (g.Pf + 3) / 4;
-		hipLaunchKernelGGL((schur_staged_kernel<ET>), dim3(np + st.nStages), dim3(256), 0, s, g, st, sys, np);
-		if (st.nSlots > 0) hipLaunchKernelGGL(schur_reduce_kernel, dim3((st.nblk + 6) / 7), dim3(256), 0, s, st, sys);
-		return;
 	}
 	const int nbp = block_pass_groups(st.nOd, st.nHeavy);
 	if (mode == 1 && g.Pf > 0 && st.nOd > 0 && st.nDiagProd == 0)     // (duplicate observations: the block pass updates diagonal blocks after the pose pass)

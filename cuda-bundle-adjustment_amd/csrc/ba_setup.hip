@@ -723,62 +723,7 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	sys.spmv_rows = spmvRows;
 	sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 	sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
-	buildStagedSchur(nblk, nBig);
 	haveStructure = true;
-}
-
-// Lists of the staged block pass (ba_linearize.hip: schur_stage_body), from device arrays only: product positions sorted by (stage, block)
-// -> slots; slots sorted by block -> the lists of the second pass.  Two host synchronisations (valid products, slots).
-void cuba_hip_solver::buildStagedSchur(int nblk, int nBig)
-{
-	st.staged = 0; st.nStages = 0; st.nSlots = 0;
-	const size_t np = d_prodEa.size();
-	if (schurStaged == 0 || np == 0 || nblk == 0 || nBig > 0 || diagProdBlocks > 0 || Pf == 0) return;
-	const int lo = std::max(0, partLo), hi = partHi < 0 ? Lt : std::min(Lt, partHi);
-	const int nStages = (g.e_end - g.e_begin + topo::STAGE_RECORDS - 1) / topo::STAGE_RECORDS;
-	if (nStages <= 0) return;
-	d_k64a.resize(std::max(np, d_k64a.size())); d_k64b.resize(std::max(np, d_k64b.size()));
-	d_v32a.resize(std::max(np, d_v32a.size())); d_v32b.resize(std::max(np, d_v32b.size()));
-	d_tmpI0.resize(std::max(np, d_tmpI0.size())); d_tmpI1.resize(std::max(np, d_tmpI1.size()));
-	d_counters.resize(topo::CNT_COUNT);
-	d_counters.zero(stream);
-	sortTemp(np);
-	topo::launch_stage_keys(d_prodPtr.data(), st.prod_beg, st.prod_end, nblk, d_prodLm.data(), d_lmptr.data(), g.e_begin, np, d_k64a.data(), d_v32a.data(), d_counters.data(), stream);
-	HIP_TRY(topo::sort_u64_u32(d_topoTemp.data(), d_topoTemp.size(), d_k64a.data(), d_k64b.data(), d_v32a.data(), d_v32b.data(), np, 32 + bitsFor(nStages), stream));
-	const int nInvalid = readBack(d_counters.data() + topo::CNT_BAD);
-	const size_t nvalid = np - (size_t)nInvalid;
-	if (nvalid == 0) return;
-	topo::launch_entry_heads(d_k64b.data(), nvalid, d_tmpI0.data(), stream);
-	HIP_TRY(topo::inclusive_scan_i32(d_topoTemp.data(), d_topoTemp.size(), d_tmpI0.data(), d_tmpI1.data(), nvalid, stream));
-	const int nSlots = readBack(d_tmpI1.data() + (nvalid - 1));
-	d_slotPtr.resize((size_t)nSlots + 1); d_slotBlk.resize(nSlots); d_slotStage.resize(nSlots);
-	d_sEa.resize(nvalid); d_sEb.resize(nvalid); d_sLm.resize(nvalid);
-	topo::launch_stage_slots(d_k64b.data(), d_v32b.data(), d_tmpI1.data(), nvalid, d_prodEa.data(), d_prodEb.data(), d_prodLm.data(),
-		d_slotPtr.data(), d_slotBlk.data(), d_slotStage.data(), d_sEa.data(), d_sEb.data(), d_sLm.data(), stream);
-	d_stagePtr.resize((size_t)nStages + 1); d_stageLm.resize((size_t)nStages + 1);
-	topo::launch_segment_ptr(d_slotStage.data(), nSlots, nStages, d_stagePtr.data(), stream);
-	topo::launch_stage_landmarks(d_lmptr.data(), lo, hi, g.e_begin, nStages, d_stageLm.data(), stream);
-	// second pass: the slots of every block, in stage order (a stable sort of the (stage, block)-ordered slots by block)
-	const size_t ns = (size_t)nSlots;
-	d_k32a.resize(std::max(ns, d_k32a.size())); d_k32b.resize(std::max(ns, d_k32b.size()));
-	d_v32a.resize(std::max(ns, d_v32a.size())); d_v32b.resize(std::max(ns, d_v32b.size()));
-	d_tmpI0.resize(std::max(ns, d_tmpI0.size()));
-	sortTemp(ns);
-	topo::launch_copy_int_to_u32(d_slotBlk.data(), d_k32a.data(), nSlots, stream);
-	topo::launch_iota_u32(d_v32a.data(), ns, stream);
-	HIP_TRY(topo::sort_u32_u32(d_topoTemp.data(), d_topoTemp.size(), d_k32a.data(), d_k32b.data(), d_v32a.data(), d_v32b.data(), ns, bitsFor(nblk), stream));
-	d_blkSlots.resize(ns); d_blkSlotPtr.resize((size_t)nblk + 1);
-	topo::launch_copy_u32_to_int(d_v32b.data(), d_blkSlots.data(), nSlots, stream);
-	topo::launch_copy_u32_to_int(d_k32b.data(), d_tmpI0.data(), nSlots, stream);
-	topo::launch_segment_ptr(d_tmpI0.data(), nSlots, nblk, d_blkSlotPtr.data(), stream);
-	d_partial.resize((size_t)36 * ns);
-	st.staged = 1; st.nStages = nStages; st.nSlots = nSlots;
-	st.stage_lm = d_stageLm.data(); st.stage_ptr = d_stagePtr.data(); st.slot_ptr = d_slotPtr.data();
-	st.s_ea = d_sEa.data(); st.s_eb = d_sEb.data(); st.s_lm = d_sLm.data(); st.partial = d_partial.data();
-	st.blk_slot_ptr = d_blkSlotPtr.data(); st.blk_slots = d_blkSlots.data();
-	if (std::getenv("CUBA_HIP_DEBUG"))
-		std::fprintf(stderr, "[cuba_hip] staged block pass: %d stages, %d slots for %zu products (%.1f per slot), %.1f MB of partial blocks\n",
-			nStages, nSlots, nvalid, (double)nvalid / nSlots, 288.0 * nSlots / 1e6);
 }
 
 void cuba_hip_solver::fillProdLm()

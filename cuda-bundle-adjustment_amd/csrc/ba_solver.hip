@@ -140,7 +140,6 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
 		else if (k == "device_lm_decision") s->deviceDecision = value != 0;
 		else if (k == "landmark_reorder") s->lmReorder = value != 0;         // (takes effect with the next cuba_hip_set_graph)
-		else if (k == "schur_staged") { s->schurStaged = (int)value; s->haveStructure = false; }
 		else if (k == "spmv_upper") { s->spmvUpper = (int)value; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;

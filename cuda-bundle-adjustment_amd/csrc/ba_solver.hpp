@@ -147,7 +147,7 @@ struct cuba_hip_solver
 	std::vector<int> poseNewOfOld, poseOldOfNew;     // free poses only; identity unless reorderActive
 	DevBuf<int> d_rawEpCaller, d_poseMap;
 	// Internal landmark order (round 5).  Edges are sorted by (landmark, pose), and everything landmark-major -- the records the Schur passes
-	// gather, the per-landmark systems, the staged block pass -- inherits the locality of the landmark numbering.  The caller's order follows
+	// gather, the per-landmark systems -- inherits the locality of the landmark numbering.  The caller's order follows
 	// the vertex ids; map points of a SLAM system are numbered in creation order (neighbouring ids see the same keyframes), arbitrary ids
 	// are not (the synthetic benchmark graphs draw every track's first frame at random: with ids in creation order G4M's linearise + Schur
 	// takes 670 instead of 771 us, the evaluation 40 instead of 57 us, back-substitution 89 instead of 120 us: profiles/r05q_*).  So the free
@@ -456,11 +456,6 @@ struct cuba_hip_solver
 	int diagProdBlocks = 0;      // diagonal blocks with products (duplicate observations), set by the structure builders
 	int heavyBlocks = 0;         // blocks with more than BP_HEAVY products (the first ones of d_odBlocks), set by the structure builders
 	void publishStructure(int nblk, int nWaves, int nBig, int nOd, int nCb, int ellM, int ellOver, const CoarseCfg& c);
-	// staged Schur block pass (DeviceStructure::staged): lists built on the device from the destination-major product lists, whoever built those
-	int schurStaged = -1;              // option "schur_staged": -1 automatic (on when the graph allows it), 0 / 1
-	DevBuf<int> d_stageLm, d_stagePtr, d_slotPtr, d_slotBlk, d_slotStage, d_sEa, d_sEb, d_sLm, d_blkSlotPtr, d_blkSlots;
-	DevBuf<Scalar> d_partial;
-	void buildStagedSchur(int nblk, int nBig);
 	bool hostPatternValid = false;     // h_rowptr / h_colind describe the current structure (the device-built one downloads them on demand)
 	void fillProdLm();
 

@@ -456,53 +456,6 @@ void launch_pattern_entries(const int* lm_ptr, const int* e_pose, const int* e_l
 
 namespace
 {
-__global__ __launch_bounds__(T) void stage_keys_kernel(const int* __restrict__ prod_ptr, const int* __restrict__ prod_beg, const int* __restrict__ prod_end, int nblk,
-	const int* __restrict__ prod_lm, const int* __restrict__ lm_ptr, int e_begin, size_t nprod, uint64_t* keys, uint32_t* vals, int* counters)
-{
-	const size_t p = (size_t)blockIdx.x * T + threadIdx.x;
-	if (p >= nprod) return;
-	int lo = 0, hi = nblk;                 // block b with prod_ptr[b] <= p < prod_ptr[b + 1]
-	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((size_t)prod_ptr[mid] <= p) lo = mid; else hi = mid; }
-	const int b = lo;
-	const bool valid = p >= (size_t)prod_beg[b] && p < (size_t)prod_end[b];
-	if (!valid) { keys[p] = ~0ULL; vals[p] = (uint32_t)p; atomicAdd(&counters[CNT_BAD], 1); return; }
-	const int stage = (lm_ptr[prod_lm[p]] - e_begin) / STAGE_RECORDS;
-	keys[p] = ((uint64_t)(uint32_t)stage << 32) | (uint32_t)b;
-	vals[p] = (uint32_t)p;
-}
-
-__global__ __launch_bounds__(T) void stage_slots_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ order, const int* __restrict__ slotOf, size_t nvalid,
-	const int* __restrict__ prod_ea, const int* __restrict__ prod_eb, const int* __restrict__ prod_lm,
-	int* slot_ptr, int* slot_blk, int* slot_stage, int* s_ea, int* s_eb, int* s_lm)
-{
-	const size_t i = (size_t)blockIdx.x * T + threadIdx.x;
-	if (i >= nvalid) return;
-	const uint32_t p = order[i];
-	s_ea[i] = prod_ea[p]; s_eb[i] = prod_eb[p]; s_lm[i] = prod_lm[p];
-	const int slot = slotOf[i] - 1;
-	if (i == 0 || keys[i] != keys[i - 1])
-	{
-		slot_ptr[slot] = (int)i; slot_blk[slot] = (int)(uint32_t)keys[i]; slot_stage[slot] = (int)(keys[i] >> 32);
-	}
-	if (i == nvalid - 1) slot_ptr[slot + 1] = (int)nvalid;
-}
-
-__global__ __launch_bounds__(T) void stage_landmarks_kernel(const int* __restrict__ lm_ptr, int lo, int hi, int e_begin, int nStages, int* stage_lm)
-{
-	const int k = blockIdx.x * T + threadIdx.x;
-	if (k > nStages) return;
-	const long long target = (long long)e_begin + (long long)k * STAGE_RECORDS;
-	int a = lo, b = hi;                    // first landmark l in [lo, hi] with lm_ptr[l] >= target (lm_ptr[hi] = end of the range)
-	while (a < b) { const int mid = (a + b) >> 1; if (lm_ptr[mid] >= target) b = mid; else a = mid + 1; }
-	stage_lm[k] = a;
-}
-
-__global__ __launch_bounds__(T) void iota_u32_kernel(uint32_t* v, size_t n) { const size_t i = (size_t)blockIdx.x * T + threadIdx.x; if (i < n) v[i] = (uint32_t)i; }
-__global__ __launch_bounds__(T) void copy_int_u32_kernel(const int* in, uint32_t* out, int n) { const int i = blockIdx.x * T + threadIdx.x; if (i < n) out[i] = (uint32_t)in[i]; }
-}
-
-namespace
-{
 __global__ __launch_bounds__(T) void lm_first_last_init_kernel(int Lt, int* first, int* last)
 {
 	const int l = blockIdx.x * T + threadIdx.x;
@@ -565,26 +518,6 @@ void launch_permute_rows(const Scalar* src, Scalar* dst, const int* newOfOld, in
 	const size_t total = (size_t)nrows * width;
 	if (total) hipLaunchKernelGGL(permute_rows_kernel, grid_for(total), dim3(T), 0, s, src, dst, newOfOld, total, width, toInternal ? 1 : 0);
 }
-
-void launch_stage_keys(const int* prod_ptr, const int* prod_beg, const int* prod_end, int nblk, const int* prod_lm, const int* lm_ptr, int e_begin,
-	size_t nprod, uint64_t* keys, uint32_t* vals, int* counters, hipStream_t s)
-{
-	if (nprod) hipLaunchKernelGGL(stage_keys_kernel, grid_for(nprod), dim3(T), 0, s, prod_ptr, prod_beg, prod_end, nblk, prod_lm, lm_ptr, e_begin, nprod, keys, vals, counters);
-}
-
-void launch_stage_slots(const uint64_t* keys, const uint32_t* order, const int* slotOf, size_t nvalid, const int* prod_ea, const int* prod_eb, const int* prod_lm,
-	int* slot_ptr, int* slot_blk, int* slot_stage, int* s_ea, int* s_eb, int* s_lm, hipStream_t s)
-{
-	if (nvalid) hipLaunchKernelGGL(stage_slots_kernel, grid_for(nvalid), dim3(T), 0, s, keys, order, slotOf, nvalid, prod_ea, prod_eb, prod_lm, slot_ptr, slot_blk, slot_stage, s_ea, s_eb, s_lm);
-}
-
-void launch_stage_landmarks(const int* lm_ptr, int lo, int hi, int e_begin, int nStages, int* stage_lm, hipStream_t s)
-{
-	hipLaunchKernelGGL(stage_landmarks_kernel, grid_for((size_t)nStages + 1), dim3(T), 0, s, lm_ptr, lo, hi, e_begin, nStages, stage_lm);
-}
-
-void launch_iota_u32(uint32_t* v, size_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(iota_u32_kernel, grid_for(n), dim3(T), 0, s, v, n); }
-void launch_copy_int_to_u32(const int* in, uint32_t* out, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(copy_int_u32_kernel, grid_for((size_t)n), dim3(T), 0, s, in, out, n); }
 
 void launch_entry_heads(const uint64_t* keys, size_t n, int* head, hipStream_t s)
 {

@@ -101,24 +101,6 @@ void launch_remap_landmarks(const int* elIn, const int* newOfOld, int E, int* el
 // rows of `width` numbers: toInternal: dst[newOfOld[l]] = src[l]; else dst[l] = src[newOfOld[l]]  (l < nrows; src != dst)
 void launch_permute_rows(const Scalar* src, Scalar* dst, const int* newOfOld, int nrows, int width, bool toInternal, hipStream_t s);
 
-// ---- C. staged Schur block pass (ba_linearize.hip: schur_stage_body) ------------------------------------------------------
-// A stage = the landmarks whose first sorted edge lies in one window of STAGE_RECORDS records (so a stage holds at most
-// STAGE_RECORDS + 63 records: whole landmarks of at most 64 observations).  keys[p] = stage << 32 | block for product position p of the
-// destination-major lists (block found by bisection of prod_ptr; products outside [prod_beg, prod_end) of their block -- another rank's
-// landmarks -- get the largest key and counters[CNT_BAD] counts them), vals[p] = p.
-constexpr int STAGE_RECORDS = 256;
-void launch_stage_keys(const int* prod_ptr, const int* prod_beg, const int* prod_end, int nblk, const int* prod_lm, const int* lm_ptr, int e_begin,
-	size_t nprod, uint64_t* keys, uint32_t* vals, int* counters, hipStream_t s);
-// slots (= runs of equal keys among the first nvalid sorted entries): slotOf = inclusive scan of the head flags; fills slot_ptr[slot] (first
-// sorted entry), slot_blk, slot_stage, and the sorted product arrays s_ea / s_eb / s_lm (indices relative to the stage's first record / landmark
-// are formed in the kernel that uses them)
-void launch_stage_slots(const uint64_t* keys, const uint32_t* order, const int* slotOf, size_t nvalid, const int* prod_ea, const int* prod_eb, const int* prod_lm,
-	int* slot_ptr, int* slot_blk, int* slot_stage, int* s_ea, int* s_eb, int* s_lm, hipStream_t s);
-// stage_lm[k] = first landmark whose first sorted edge is >= e_begin + k * STAGE_RECORDS, k = 0..nStages (bisection of lm_ptr over [lo, hi])
-void launch_stage_landmarks(const int* lm_ptr, int lo, int hi, int e_begin, int nStages, int* stage_lm, hipStream_t s);
-void launch_iota_u32(uint32_t* v, size_t n, hipStream_t s);
-void launch_copy_int_to_u32(const int* in, uint32_t* out, int n, hipStream_t s);
-
 // per-edge values from sorted order back to the caller's order
 void launch_unsort(const uint32_t* perm, const Scalar* sorted, int E, double* callerOrder, hipStream_t s);
 

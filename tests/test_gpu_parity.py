@@ -746,58 +746,6 @@ def test_device_resident_lm_decision_is_bit_identical(solvers):
     assert saw_rejection
 
 
-@pytest.mark.parametrize("case", ["huber", "fixed_vertices", "mono_only", "mixed_precision", "kitti07"])
-def test_staged_block_pass_matches_the_destination_major_pass(solvers, case):
-    """Option schur_staged (automatic: on unless a landmark has more than 64 observations or one pose observes a landmark twice): the
-    off-diagonal blocks of Hsc from stages of ~256 consecutive records staged in LDS once + a fixed-order second pass over partial blocks,
-    instead of three 64-byte gathers per product (replaces computeHschureKernel, /root/reference/src/cuda_block_solver.cu:964-977).  Same
-    sums in another association: the reduced system agrees to rounding, the LM trajectories to the solver tolerance, runs stay
-    bit-reproducible."""
-    HipSolver, OracleSolver = solvers
-    opts = {}
-    if case == "kitti07":
-        fp = flatten(synth_named("kitti07"))
-    else:
-        g = synth_ba(200, 8000, 32000, seed=13, stereo_frac=0.0 if case == "mono_only" else 0.85)
-        if case == "fixed_vertices":
-            g = with_fixed(g, fixed_pose_rows=[3, 4, 20, 21, 22, 150], fixed_lm_rows=list(range(0, 4000, 7)))
-        fp = flatten(g)
-    if case == "mixed_precision":
-        opts["mixed_precision"] = 1
-    a = HipSolver(fp, RK_HUBER, schur_staged=0, **opts); b = HipSolver(fp, RK_HUBER, schur_staged=1, **opts)
-    lam = 1e-5 * a.max_diagonal(); b.max_diagonal()
-    a.set_lambda(lam); b.set_lambda(lam); a.schur(); b.schur()
-    tol = 2e-5 if case == "mixed_precision" else 1e-12
-    for name in ("hsc", "bsc", "bp"):
-        x, y = a.array(name), b.array(name)
-        assert np.abs(x - y).max() <= tol * np.abs(x).max(), (case, name, np.abs(x - y).max() / np.abs(x).max())
-    ra = a.optimize(8)["chi2"]; rb = b.optimize(8)["chi2"]
-    assert len(ra) == len(rb) and rel(ra, rb) < (1e-6 if case == "mixed_precision" else 1e-9), (case, rel(ra, rb))
-    ro = OracleSolver(fp, RK_HUBER).optimize(8)["chi2"]
-    assert rel(rb, ro) < 1e-6
-    b3 = HipSolver(fp, RK_HUBER, schur_staged=1, **opts)
-    assert np.array_equal(b3.optimize(8)["chi2"], HipSolver(fp, RK_HUBER, schur_staged=1, **opts).optimize(8)["chi2"])
-
-
-def test_staged_block_pass_landmark_partition(solvers):
-    """the staged pass on landmark partitions: the ranks' contributions add up to the whole-graph reduced system"""
-    HipSolver, _ = solvers
-    from cuba_amd.dist import landmark_ranges
-    fp = flatten(synth_ba(120, 6000, 24000, seed=9))
-    whole = HipSolver(fp, RK_HUBER, pose_reorder=0, schur_staged=0)
-    lam = 1e-5 * whole.max_diagonal()
-    whole.set_lambda(lam); whole.schur()
-    want = {k: whole.array(k) for k in ("hsc", "bsc", "bp")}
-    total = {k: np.zeros_like(v) for k, v in want.items()}
-    for lo, hi in landmark_ranges(fp.eL, fp.Lt, 3):
-        h = HipSolver(fp, RK_HUBER, pose_reorder=0, schur_staged=1)
-        h.set_partition(lo, hi); h.set_lambda(lam); h.schur()
-        for k in want:
-            total[k] += h.array(k)
-    for k in want:
-        assert np.abs(total[k] - want[k]).max() <= 1e-11 * np.abs(want[k]).max(), k
-
-
 def test_internal_landmark_order_is_invisible_at_the_boundary(solvers):
     """Option landmark_reorder (default 1): the free landmarks are renumbered internally by (first, last) observing pose, so that
     landmark-major data inherit the trajectory's locality whatever the caller's vertex ids are.  Every host-pointer entry point keeps the
