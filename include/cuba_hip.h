@@ -95,7 +95,7 @@ void cuba_hip_host_free(void* p);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Options (21).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
+/* Options (22).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
    "direct_fallback" (default 1: a reduced solve whose PCG uses up its iteration budget, breaks down, or follows such a solve in the
    same Levenberg-Marquardt run is solved EXACTLY on the device -- dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip, the
@@ -124,6 +124,10 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    "spmv_upper" (default -1 = automatic: on beyond 1536 free poses, where the PCG kernels are bound by bytes; 1 / 0 = on / off: the
    PCG iteration as three launches straight from the upper-triangular BSR storage -- SpMV with the transposed products parked per
    block, row updates + P^T r per aggregate, preconditioner -- instead of two launches on a row-ordered copy of both triangles).
+   "landmark_reorder" (default 1, takes effect with the next cuba_hip_set_graph: the free landmarks are renumbered internally by (first, last)
+   observing pose of the internal pose order, so that landmark-major data inherit the trajectory's locality whatever the caller's ids are;
+   every host-pointer entry point keeps the caller's landmark numbering; a landmark partition other than the whole range, and the host
+   pipeline, use the caller's order),
    "device_lm_decision" (default 1: cuba_hip_optimize takes the decision of every trial -- gain ratio, acceptance, next damping -- on
    the device and enqueues the next trial without having seen it, a rejected trial being undone by a conditional restore launch: one
    host look per trial instead of two, results bit-identical to the host-side decision = 0; control flow of
