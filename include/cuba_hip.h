@@ -349,7 +349,8 @@ int cuba_hip_debug_dense_solve(int device, int n, const double* A, const double*
 
 /* A driver that runs the Levenberg-Marquardt loop itself through the stage calls announces the start of a run (a new lambda_0):
    the coarse inverse of the two-level preconditioner and the iteration-count predictions of the previous run are dropped, as
-   cuba_hip_optimize does at its start.  Optional (they would be refreshed after one slow solve anyway). */
+   cuba_hip_optimize does at its start; a hand-over to the exact reduced solve that an earlier run made (option "direct_fallback")
+   is forgotten as well, so the new run starts with PCG again.  Optional (they would be refreshed after one slow solve anyway). */
 int cuba_hip_begin_run(cuba_hip_solver* s);
 
 /* The HIP stream the handle enqueues on (a collective library must order its operations with the solver's kernels). */
