@@ -479,7 +479,13 @@ def main():
     partitioned = args.partition and world > 1
     seed = SHAPES[args.shape]["seed"] if (world == 1 or partitioned) else 100 + rank
     fp = flatten(synth_named(args.shape, seed=seed))
-    solver = HipSolver(fp, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
+    if partitioned:
+        # (the rank's upload: index arrays and estimates whole, measurements / information of its own landmarks' edges only)
+        from cuba_amd.dist import landmark_ranges
+        solver = HipSolver(None, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
+        solver.set_graph(fp, landmark_range=landmark_ranges(fp.eL, fp.Lt, world)[rank])
+    else:
+        solver = HipSolver(fp, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
     comm = None
     native = None
     if partitioned:
@@ -779,11 +785,12 @@ def partition_leg(args, dist, backend, rank, world, device_index, rk):
     (libcuba_hip_dist.so) restricts it to its landmark range and all-reduces [Hsc | bsc | bp] once per LM trial."""
     import torch
     from cuba_amd.capi import HipSolver
-    from cuba_amd.dist import NativeDist, TorchComm, rccl_unique_id
+    from cuba_amd.dist import NativeDist, TorchComm, landmark_ranges, rccl_unique_id
     from cuba_amd.graph import flatten
     from cuba_amd.synth import synth_named
     fp = flatten(synth_named(args.shape))
-    h = HipSolver(fp, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
+    h = HipSolver(None, rk, device=device_index, stream=torch.cuda.current_stream().cuda_stream)
+    h.set_graph(fp, landmark_range=landmark_ranges(fp.eL, fp.Lt, world)[rank])      # values of the rank's own landmarks' edges only
     if backend == "nccl":
         ids = [rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -843,7 +850,8 @@ def partition_leg(args, dist, backend, rank, world, device_index, rk):
                        f"{'RCCL' if backend == 'nccl' else backend} all-reduce of [Hsc|bsc|bp] per trial), {LM_RUN}-iteration LM runs",
            "scaling": "strong", "wall_ms_10iter": dt * 1e3 / runs, "value": fp.E * LM_RUN * runs / dt, "unit": "edges/s",
            "final_chi2": float(chi2[-1]), "iterations_done": int(len(chi2)), "chi2_max_rel_diff_vs_golden": par,
-           "allreduce_elements_per_trial": c["large_elements"] // max(c["large_allreduces"], 1), "time_shares": share}
+           "allreduce_elements_per_trial": int(h.reduction_buffer()[1]), "reduction_parts": d.reduction_parts()[0],
+           "value_bytes_uploaded_rank0": h.counter("value_bytes_uploaded"), "value_bytes_whole_graph": 32 * int(fp.E), "time_shares": share}
     d.close(); h.close()
     return res
 

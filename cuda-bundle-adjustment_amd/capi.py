@@ -72,6 +72,7 @@ def load_library(precision="f64"):
         "cuba_hip_set_graph": [H, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _ip, _u8p, _dp, _dp],
         "cuba_hip_set_graph_begin": [H, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _ip, _u8p, _dp, _dp],
         "cuba_hip_set_graph_end": [H],
+        "cuba_hip_set_graph_partition": [H, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, _ip, _u8p, _dp, _dp, C.c_int, C.c_int],
         "cuba_hip_set_robust_kernel": [H, C.c_int, C.c_int, C.c_double],
         "cuba_hip_build_structure": [H],
         "cuba_hip_compute_errors": [H, _dp],
@@ -80,6 +81,8 @@ def load_library(precision="f64"):
         "cuba_hip_set_lambda": [H, C.c_double],
         "cuba_hip_restore_diagonal": [H],
         "cuba_hip_schur": [H],
+        "cuba_hip_schur_parts": [H, C.POINTER(C.c_int)],
+        "cuba_hip_schur_part": [H, C.c_int, C.POINTER(C.c_size_t)],
         "cuba_hip_solve_reduced": [H, C.POINTER(C.c_int)],
         "cuba_hip_back_substitute": [H],
         "cuba_hip_solve": [H, C.POINTER(C.c_int)],
@@ -217,9 +220,11 @@ class HipSolver:
         """promise about the NEXT set_graph call only (cuba_hip_hint_unchanged)"""
         self._ck(self.lib.cuba_hip_hint_unchanged(self.h, int(bool(same_edges)), int(bool(same_values))))
 
-    def set_graph(self, fp, two_step=False):
+    def set_graph(self, fp, two_step=False, landmark_range=None):
         """two_step: cuba_hip_set_graph_begin + cuba_hip_build_structure + cuba_hip_set_graph_end (what the C++ layer does: the
-        measurements cross PCIe on a second stream while the structure analysis runs)"""
+        measurements cross PCIe on a second stream while the structure analysis runs).
+        landmark_range = (begin, end): cuba_hip_set_graph_partition -- the upload of one rank of a landmark partition, which sends the
+        measurements and information of its own landmarks' edges only."""
         self.fp = fp
         q, t, cam, Xw = (np.ascontiguousarray(a, dtype=np.float64) for a in (fp.q, fp.t, fp.cam, fp.Xw))
         eP = np.ascontiguousarray(fp.eP, dtype=np.int32)
@@ -227,6 +232,11 @@ class HipSolver:
         eD = np.ascontiguousarray(fp.eDim, dtype=np.uint8)
         meas = np.ascontiguousarray(fp.meas, dtype=np.float64)
         om = np.ascontiguousarray(fp.omega, dtype=np.float64)
+        if landmark_range is not None:
+            self._ck(self.lib.cuba_hip_set_graph_partition(self.h, fp.Pt, fp.Pf, fp.Lt, fp.Lf, _d(q), _d(t), _d(cam), _d(Xw), len(eP),
+                     eP.ctypes.data_as(_ip), eL.ctypes.data_as(_ip), eD.ctypes.data_as(_u8p), _d(meas), _d(om),
+                     int(landmark_range[0]), int(landmark_range[1])))
+            return
         fn = self.lib.cuba_hip_set_graph_begin if two_step else self.lib.cuba_hip_set_graph
         self._ck(fn(self.h, fp.Pt, fp.Pf, fp.Lt, fp.Lf, _d(q), _d(t), _d(cam), _d(Xw), len(eP),
                     eP.ctypes.data_as(_ip), eL.ctypes.data_as(_ip), eD.ctypes.data_as(_u8p), _d(meas), _d(om)))
@@ -254,6 +264,17 @@ class HipSolver:
     def set_lambda(self, lam): self._ck(self.lib.cuba_hip_set_lambda(self.h, float(lam)))
     def restore_diagonal(self): self._ck(self.lib.cuba_hip_restore_diagonal(self.h))
     def schur(self): self._ck(self.lib.cuba_hip_schur(self.h))
+
+    def schur_parts(self):
+        n = C.c_int()
+        self._ck(self.lib.cuba_hip_schur_parts(self.h, C.byref(n)))
+        return n.value
+
+    def schur_part(self, part):
+        """Part `part` of schur(); returns ((offset, count), (offset, count)): the ranges of the reduction buffer it completes."""
+        r = (C.c_size_t * 4)()
+        self._ck(self.lib.cuba_hip_schur_part(self.h, int(part), r))
+        return (int(r[0]), int(r[1])), (int(r[2]), int(r[3]))
 
     def solve_reduced(self):
         ok = C.c_int()

@@ -50,24 +50,65 @@ struct cuba_hip_dist
 	long long nLarge = 0, nSmall = 0, largeElems = 0, nTrials = 0;
 	std::string lastError;
 	bool partitionSet = false;
+	// reduction in parts (cuba_hip_schur_part): the sum of part c runs on `commStream` while the solver's stream computes part c + 1
+	int nParts = 1;
+	hipStream_t commStream = nullptr;
+	hipEvent_t evPart = nullptr, evSummed = nullptr;
+	long long nOverlapped = 0;
 
 	// (also the failure path of create(): whatever bind() already acquired is released)
 	~cuba_hip_dist()
 	{
 		if (ownComm && comm) (void)ncclCommDestroy(comm);
 		if (hostScalars) (void)hipHostFree(hostScalars);
+		if (evPart) (void)hipEventDestroy(evPart);
+		if (evSummed) (void)hipEventDestroy(evSummed);
+		if (commStream) (void)hipStreamDestroy(commStream);
 	}
 
-	void allreduce(void* buf, size_t count, bool max)
+	void allreduce(void* buf, size_t count, bool max) { allreduceOn(stream, buf, count, max); }
+
+	void allreduceOn(hipStream_t on, void* buf, size_t count, bool max)
 	{
-		if (world == 1) return;
+		if (world == 1 || count == 0) return;
 		if (custom)
 		{
-			const int rc = (max ? ops.allreduce_max : ops.allreduce_sum)(ops.ctx, buf, count, scalarSize, (void*)stream);
+			const int rc = (max ? ops.allreduce_max : ops.allreduce_sum)(ops.ctx, buf, count, scalarSize, (void*)on);
 			if (rc != 0) throw Fail{ CUBA_HIP_ERR_RUNTIME, "custom all-reduce failed" };
 			return;
 		}
-		NCCL_TRY(ncclAllReduce(buf, buf, count, scalarSize == 8 ? ncclDouble : ncclFloat, max ? ncclMax : ncclSum, comm, stream));
+		NCCL_TRY(ncclAllReduce(buf, buf, count, scalarSize == 8 ? ncclDouble : ncclFloat, max ? ncclMax : ncclSum, comm, on));
+	}
+
+	// cuba_hip_schur + the sum of the reduction buffer over the ranks.  One part: the pass, then one all-reduce in-stream.  Several parts:
+	// part c's ranges are summed on the second stream behind an event, while the solver's stream goes on with part c + 1; the solver's
+	// stream then waits for the last sum.  (Collectives of one communicator are issued in the same order on every rank: the cuts are
+	// functions of the global block pattern.)
+	void schurAndSum()
+	{
+		if (nParts <= 1 || world == 1)
+		{
+			if (cuba_hip_schur(s) != CUBA_HIP_OK) throw Fail{ CUBA_HIP_ERR_RUNTIME, std::string("cuba_hip_schur: ") + cuba_hip_last_error(s) };
+			allreduce(red, redCount, false); nLarge++; largeElems += (long long)redCount;
+			return;
+		}
+		char* base = (char*)red;
+		for (int c = 0; c < nParts; c++)
+		{
+			size_t r[4] = { 0, 0, 0, 0 };
+			if (cuba_hip_schur_part(s, c, r) != CUBA_HIP_OK) throw Fail{ CUBA_HIP_ERR_RUNTIME, std::string("cuba_hip_schur_part: ") + cuba_hip_last_error(s) };
+			HIP_TRY(hipEventRecord(evPart, stream));
+			HIP_TRY(hipStreamWaitEvent(commStream, evPart, 0));
+			for (int k = 0; k < 4; k += 2)
+			{
+				if (!r[k + 1]) continue;
+				allreduceOn(commStream, base + r[k] * (size_t)scalarSize, r[k + 1], false);
+				nLarge++; largeElems += (long long)r[k + 1];
+				if (c + 1 < nParts) nOverlapped++;
+			}
+		}
+		HIP_TRY(hipEventRecord(evSummed, commStream));
+		HIP_TRY(hipStreamWaitEvent(stream, evSummed, 0));
 	}
 
 	// read `n` device scalars back (one stream synchronisation)
@@ -97,6 +138,13 @@ void bind(cuba_hip_dist* d, cuba_hip_solver* s, int rank, int world, int lb, int
 	d->partitionSet = true;
 	SOLVER_TRY(cuba_hip_build_structure(s));
 	SOLVER_TRY(cuba_hip_reduction_buffer(s, &d->red, &d->redCount));
+	SOLVER_TRY(cuba_hip_schur_parts(s, &d->nParts));
+	if (d->nParts > 1 && world > 1)
+	{
+		HIP_TRY(hipStreamCreateWithFlags(&d->commStream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&d->evPart, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&d->evSummed, hipEventDisableTiming));
+	}
 	HIP_TRY(hipHostMalloc((void**)&d->hostScalars, 64, hipHostMallocDefault));
 	// fault injection for tests/test_dist.py: a failure AFTER the handle was bound (what a refused ncclCommInitRank looks like)
 	if (std::getenv("CUBA_HIP_DIST_TEST_FAIL_AFTER_BIND")) throw Fail{ CUBA_HIP_ERR_RUNTIME, "injected failure after bind" };
@@ -221,8 +269,7 @@ int cuba_hip_dist_optimize(cuba_hip_dist* d, int niterations, double* chi2_per_i
 				d->nTrials++;
 				SOLVER_TRY(cuba_hip_push(d->s));
 				SOLVER_TRY(cuba_hip_set_lambda(d->s, lam));
-				SOLVER_TRY(cuba_hip_schur(d->s));
-				d->allreduce(d->red, d->redCount, false); d->nLarge++; d->largeElems += (long long)d->redCount;   // the one large exchange of the trial
+				d->schurAndSum();                                     // the one large exchange of the trial (in parts: under the pass itself)
 				int ok = 0;
 				SOLVER_TRY(cuba_hip_solve_reduced(d->s, &ok));       // replicated; bit-identical on every rank
 				if (ok)
@@ -277,6 +324,11 @@ int cuba_hip_dist_complete_solution(cuba_hip_dist* d)
 int cuba_hip_dist_get_counters(cuba_hip_dist* d, long long c[4])
 {
 	return guarded(d, [&] { c[0] = d->nLarge; c[1] = d->nSmall; c[2] = d->largeElems; c[3] = d->nTrials; });
+}
+
+int cuba_hip_dist_reduction_parts(cuba_hip_dist* d, int* n_parts, long long* overlapped)
+{
+	return guarded(d, [&] { if (n_parts) *n_parts = d->world > 1 ? d->nParts : 1; if (overlapped) *overlapped = d->nOverlapped; });
 }
 
 const char* cuba_hip_dist_last_error(const cuba_hip_dist* d) { return d ? d->lastError.c_str() : "null driver handle"; }

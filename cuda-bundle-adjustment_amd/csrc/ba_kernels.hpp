@@ -144,8 +144,12 @@ void launch_residual_chi2(const DeviceGraph& g, Scalar* parts, Scalar* slots, Sc
 // launch_linearize_dm: destination-major, atomic-free and bitwise reproducible:
 //   landmark pass (Hll/bl, inverse, per-edge record) -> pose pass (diagonal blocks, bp, bsc) -> block pass (off-diagonal blocks)
 // backupSrc != nullptr: the landmark pass's launch also copies backupCount numbers backupSrc -> backupDst (the LM loop's push())
+// range != nullptr (landmark partitions whose reduction is cut into parts, ba_setup.hip: cutReductionParts): the block pass covers the
+// entries [begin, end) of st.od_blocks only, the first `heavy` of them with a whole wave each; launch_block_pass runs a further range
+struct BlockPassRange { int begin, end, heavy; };
 void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
-	const Scalar* backupSrc = nullptr, Scalar* backupDst = nullptr, size_t backupCount = 0);
+	const Scalar* backupSrc = nullptr, Scalar* backupDst = nullptr, size_t backupCount = 0, const BlockPassRange* range = nullptr);
+void launch_block_pass(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const BlockPassRange& range, hipStream_t s);
 
 // max over the diagonal of the diagonal blocks of hsc (Hpp after an assemble pass) folded into sys.maxdiag
 void launch_pose_maxdiag(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s);

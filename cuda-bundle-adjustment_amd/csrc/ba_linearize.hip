@@ -522,10 +522,19 @@ __global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceSt
 	else block_pass_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
 }
 
-template <typename ET>
-static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
-	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
+static DeviceStructure block_pass_view(const DeviceStructure& st, const BlockPassRange& r)
 {
+	DeviceStructure v = st;
+	v.od_blocks = st.od_blocks + r.begin; v.nOd = r.end - r.begin; v.nHeavy = r.heavy;
+	return v;
+}
+
+template <typename ET>
+static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& stAll, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
+	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount, const BlockPassRange* range)
+{
+	// (the landmark and pose passes read nothing of the block list: one view serves the whole launch sequence)
+	const DeviceStructure st = range ? block_pass_view(stAll, *range) : stAll;
 	if (st.nWaves > 0)
 	{
 		const unsigned grid = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
@@ -557,10 +566,19 @@ static void launch_linearize_dm_t(const DeviceGraph& g, const DeviceStructure& s
 }
 
 void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int mode, Scalar lambda, hipStream_t s,
-	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount)
+	const Scalar* backupSrc, Scalar* backupDst, size_t backupCount, const BlockPassRange* range)
 {
-	if (st.mixed && sizeof(Scalar) == 8) launch_linearize_dm_t<float>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount);
-	else launch_linearize_dm_t<Scalar>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount);
+	if (st.mixed && sizeof(Scalar) == 8) launch_linearize_dm_t<float>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount, range);
+	else launch_linearize_dm_t<Scalar>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount, range);
+}
+
+void launch_block_pass(const DeviceGraph& g, const DeviceStructure& stAll, const DeviceSystem& sys, const BlockPassRange& range, hipStream_t s)
+{
+	if (range.end <= range.begin) return;
+	const DeviceStructure st = block_pass_view(stAll, range);
+	const int nbp = block_pass_groups(st.nOd, st.nHeavy);
+	if (st.mixed && sizeof(Scalar) == 8) hipLaunchKernelGGL((block_pass_kernel<float>), dim3(nbp), dim3(256), 0, s, g, st, sys);
+	else hipLaunchKernelGGL((block_pass_kernel<Scalar>), dim3(nbp), dim3(256), 0, s, g, st, sys);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -150,7 +150,34 @@ double cuba_hip_solver::computeErrors()
 void cuba_hip_solver::linearize(int mode, double lam, bool withBackup)
 {
 	waitAssembled();            // an overlapped coarse assembly may still be reading the previous reduced matrix
-	launch_linearize_dm(g, st, sys, mode, lam, stream, withBackup ? d_state.data() : nullptr, d_backup.data(), d_state.size());
+	const bool parts = mode == 1 && !redParts.empty();
+	launch_linearize_dm(g, st, sys, mode, lam, stream, withBackup ? d_state.data() : nullptr, d_backup.data(), d_state.size(), parts ? &redParts[0].od : nullptr);
+	if (parts && !partsByCaller)
+		for (size_t c = 1; c < redParts.size(); c++) launch_block_pass(g, st, sys, redParts[c].od, stream);
+}
+
+void cuba_hip_solver::schurPart(int part, size_t ranges[4])
+{
+	need();
+	if (part < 0 || part >= schurParts()) throw ArgError{ "cuba_hip_schur_part: no such part" };
+	if (part == 0)
+	{
+		StageTimer tm(this, 4);
+		zeroReduced();
+		partsByCaller = true;
+		try { linearize(1, lambda, false); } catch (...) { partsByCaller = false; throw; }
+		partsByCaller = false;
+	}
+	else
+	{
+		StageTimer tm(this, 4);
+		launch_block_pass(g, st, sys, redParts[part].od, stream);
+	}
+	const size_t nblk = (size_t)st.nblk;
+	ranges[0] = redParts.empty() ? 0 : 36 * redParts[part].blkBegin;
+	ranges[1] = redParts.empty() ? 36 * nblk : 36 * (redParts[part].blkEnd - redParts[part].blkBegin);
+	ranges[2] = part == 0 ? 36 * nblk : 0;
+	ranges[3] = part == 0 ? d_red.size() - 36 * nblk : 0;
 }
 
 void cuba_hip_solver::assemble()
@@ -807,6 +834,7 @@ void cuba_hip_solver::timeKernels(int reps, double* msOut)
 void cuba_hip_solver::chiSquares(double* out, bool wait)
 {
 	need();
+	if (partHi >= 0) d_perEdge.zero(stream);          // (a landmark partition evaluates its own edges only: the others report 0)
 	launch_residual_chi2(g, d_parts.data(), slotsDev + 2 * NSLOT, d_perEdge.data(), stream);
 	if (devTopology)
 	{

@@ -16,8 +16,11 @@ void cuba_hip_solver::finishValues()
 }
 
 void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,
-	int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega, bool deferValues)
+	int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega, bool deferValues, int ownLo, int ownHi)
 {
+	const bool ranged = ownHi >= 0;
+	if (ranged && (ownLo < 0 || ownHi > Lt_ || ownLo > ownHi)) throw ArgError{ "bad landmark range" };
+	if (ranged) deferValues = false;
 	// (a begin without its end: the old upload must not outlive its arrays' replacement, and the sorted measurement / information arrays
 	// it was going to fill were never gathered -- a "same values" promise for THIS call must not keep them: round-4 advisor)
 	if (valuesPending) { HIP_TRY(hipStreamSynchronize(upStream)); valuesPending = false; sortedValuesValid = false; }
@@ -29,10 +32,12 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 	if ((Pt_ && (!q || !t || !cam)) || (Lt_ && !Xw) || (E_ && (!ep || !el || !edim || !meas || !omega))) throw ArgError{ "null array" };
 	const auto t0 = Clock::now();
 	static const bool noCache = std::getenv("CUBA_HIP_NO_STRUCTURE_CACHE") != nullptr;   // A/B knob for set-up timings
-	const bool sameCounts = !noCache && haveStructure && partHi < 0 && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_;
+	const bool sameCounts = !noCache && !ranged && haveStructure && partHi < 0 && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_;
 	// the very same index arrays as in the previous call (re-initialisation of an unchanged graph): the sort, the
 	// permutation and the sorted index arrays on the host and on the device are all still valid
 	bool sameInput = !noCache && haveGraph && Pt == Pt_ && Pf == Pf_ && Lt == Lt_ && Lf == Lf_ && E == E_ && (int)h_inEp.size() == E_;
+	// (a ranged upload changes what the handle evaluates: nothing of the previous call is reused, and the sort runs in the caller's landmark order)
+	if (ranged) sameInput = false;
 	const bool promisedEdges = sameInput && hintSameEdges, promisedValues = promisedEdges && hintSameValues;
 	hintSameEdges = hintSameValues = false;          // (a promise covers one call)
 	if (sameInput && !promisedEdges)
@@ -58,6 +63,7 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 	haveGraph = false;
 	haveStructure = false;
 	Pt = Pt_; Pf = Pf_; Lt = Lt_; Lf = Lf_; E = E_;
+	if (ranged) { partLo = ownLo; partHi = ownHi; }          // (before the sort: the internal landmark order is for whole-range handles)
 	lap(nullptr);
 	// the estimates and cameras go up straight from the caller's arrays when they need neither a conversion (fp64 build) nor a
 	// row permutation (internal pose order): no staging copy, and page-locked caller memory (cuba_hip_host_alloc) moves by DMA
@@ -93,7 +99,26 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 		const bool defer = deferValues && !keepValues && E > 0;
 		deferredUpload = defer;          // (enqueued LAST, below: the copy engine serves its queue in order, and the small uploads of this call must not wait behind 18 MB)
 		if (defer) { d_rawMeas.resize((size_t)3 * E); d_rawOmega.resize(E); }
-		else if (!keepValues) { d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream); }
+		else if (ranged)
+		{
+			// the values of the rank's own edges only: ids + {u, v, r, omega} packed by the host, spread into the caller-order arrays by a kernel
+			// (the other edges' slots read as zeros; no kernel of a partitioned handle looks at them)
+			h_ownIds.clear();
+			for (int e = 0; e < E; e++) if (el[e] >= ownLo && el[e] < ownHi) h_ownIds.push_back(e);
+			const int n = (int)h_ownIds.size();
+			h_ownVals.resize((size_t)4 * n);
+			parallelFor(n, [&](int i) {
+				const size_t e = (size_t)h_ownIds[i];
+				h_ownVals[4 * (size_t)i] = meas[3 * e]; h_ownVals[4 * (size_t)i + 1] = meas[3 * e + 1]; h_ownVals[4 * (size_t)i + 2] = meas[3 * e + 2];
+				h_ownVals[4 * (size_t)i + 3] = omega[e];
+			});
+			d_ownIds.upload(h_ownIds, stream); d_ownVals.upload(h_ownVals, stream);
+			d_rawMeas.resize((size_t)3 * E); d_rawOmega.resize(E);
+			d_rawMeas.zero(stream); d_rawOmega.zero(stream);
+			topo::launch_scatter_values(d_ownIds.data(), d_ownVals.data(), n, d_rawMeas.data(), d_rawOmega.data(), stream);
+			cntValueBytes += (int64_t)n * 36;
+		}
+		else if (!keepValues) { d_rawMeas.uploadRaw(meas, (size_t)3 * E, stream); d_rawOmega.uploadRaw(omega, E, stream); cntValueBytes += (int64_t)E * 32; }
 		lap("set_graph: raw uploads enqueued");
 		if (!keepValues) sortedValuesValid = false;
 		if (!reuseSort) runDeviceEdgeSort(!defer);
@@ -161,6 +186,7 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 	lap("set_graph: gather sorted arrays");
 	if (!sameInput || devTopology) { d_epose.upload(sPose, stream); d_elm.upload(sLm, stream); d_lmptr.upload(h_lmptr, stream); }
 	d_mu.upload(mu, stream); d_mv.upload(mv, stream); d_mr.upload(mr, stream); d_w.upload(w, stream);
+	cntValueBytes += (int64_t)E * 4 * (int64_t)sizeof(Scalar);
 	devTopology = false; hostTopoValid = true;
 	}
 	const size_t nState = (size_t)7 * Pt + (size_t)3 * Lt;
@@ -207,6 +233,7 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 		HIP_TRY(hipMemcpyAsync(d_rawMeas.data(), meas, sizeof(double) * 3 * (size_t)E, hipMemcpyHostToDevice, upStream));
 		HIP_TRY(hipMemcpyAsync(d_rawOmega.data(), omega, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, upStream));
 		HIP_TRY(hipEventRecord(evValues, upStream));
+		cntValueBytes += (int64_t)E * 32;
 		deferredUpload = false;
 	}
 	sync(); expectedTicket = 0; ((volatile int*)((char*)h_pinned + 1024))[3] = 0;
@@ -221,7 +248,7 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 	g.e_mu = d_mu.data(); g.e_mv = d_mv.data(); g.e_mr = d_mr.data(); g.e_w = d_w.data();
 	g.rk[0] = rk[0]; g.rk[1] = rk[1];
 	g.e_begin = 0; g.e_end = E;
-	partLo = 0; partHi = -1;
+	partLo = ranged ? ownLo : 0; partHi = ranged ? ownHi : -1;
 	if (sameTopology)
 	{
 		// the captured PCG graphs carry the DeviceGraph by value: they stay usable only if no buffer moved
@@ -723,7 +750,54 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	sys.spmv_rows = spmvRows;
 	sys.agg = agg; sys.nc = nc; sys.cl = agg > 0 ? cl : 1; sys.inv_agg = agg > 0 ? Scalar(1) / Scalar(agg) : Scalar(0); sys.acinv = d_coarse[0].data(); sys.rc = d_rc.data(); sys.r2 = d_r2.data();
 	sys.acinv32 = fp32Inverse() && agg > 0 ? d_coarse32[0].data() : nullptr;
+	cutReductionParts();
 	haveStructure = true;
+}
+
+// Landmark partitions: cut the reduced matrix at block rows into at most `redChunks` ranges of about equal size and group the block list
+// of the Schur pass by range.  The cuts depend on the (global) block pattern only, so every rank of a partitioned run makes the same
+// ones; inside a range the list keeps its order and its whole-wave blocks stay in front, so every block is computed exactly as in
+// one pass.
+void cuba_hip_solver::cutReductionParts()
+{
+	redParts.clear();
+	if (partHi < 0 || st.nblk <= 0 || st.nOd <= 0 || Pf <= 0) return;
+	const size_t matrixBytes = (size_t)36 * st.nblk * sizeof(Scalar);
+	const int want = redChunks > 0 ? redChunks : (int)std::min<size_t>(8, matrixBytes >> 23);
+	if (want <= 1) return;
+	std::vector<int> rowptr((size_t)Pf + 1), od((size_t)st.nOd);
+	HIP_TRY(hipMemcpyAsync(rowptr.data(), d_rowptr.data(), sizeof(int) * rowptr.size(), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(od.data(), d_odBlocks.data(), sizeof(int) * od.size(), hipMemcpyDeviceToHost, stream));
+	sync();
+	std::vector<int> cut{ 0 };            // first block of every range
+	for (int c = 1; c < want; c++)
+	{
+		const int target = (int)((long long)st.nblk * c / want);
+		const int b = *std::lower_bound(rowptr.begin(), rowptr.end(), target);
+		if (b > cut.back() && b < st.nblk) cut.push_back(b);
+	}
+	if (cut.size() < 2) return;
+	cut.push_back(st.nblk);
+	const int C = (int)cut.size() - 1;
+	std::vector<std::vector<int>> lists(C);
+	std::vector<int> heavy(C, 0);
+	int c = 0;                            // (an unused slot of an XCD-aware order, -1, stays with the entry before it)
+	for (int i = 0; i < st.nOd; i++)
+	{
+		if (od[i] >= 0) c = (int)(std::upper_bound(cut.begin() + 1, cut.end(), od[i]) - (cut.begin() + 1));
+		lists[c].push_back(od[i]);
+		if (i < st.nHeavy) heavy[c]++;
+	}
+	od.clear();
+	for (int k = 0; k < C; k++)
+	{
+		RedPart p;
+		p.od.begin = (int)od.size(); od.insert(od.end(), lists[k].begin(), lists[k].end()); p.od.end = (int)od.size(); p.od.heavy = heavy[k];
+		p.blkBegin = (size_t)cut[k]; p.blkEnd = (size_t)cut[k + 1];
+		redParts.push_back(p);
+	}
+	d_odBlocks.upload(od, stream);
+	sync();          // `od` is a local
 }
 
 void cuba_hip_solver::fillProdLm()

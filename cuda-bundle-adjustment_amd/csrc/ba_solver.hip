@@ -140,6 +140,11 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
 		else if (k == "device_lm_decision") s->deviceDecision = value != 0;
 		else if (k == "landmark_reorder") s->lmReorder = value != 0;         // (takes effect with the next cuba_hip_set_graph)
+		else if (k == "reduction_chunks")
+		{
+			if (value < 0 || value > 64) throw ArgError{ "reduction_chunks must lie in 0 .. 64" };
+			s->redChunks = (int)value; s->haveStructure = false;
+		}
 		else if (k == "spmv_upper") { s->spmvUpper = (int)value; s->haveStructure = false; s->dropPcgGraph(); }
 		else if (k == "pcg_graph") { s->useGraph = value != 0; s->dropPcgGraph(); }
 		else if (k == "profile") s->profile = value != 0;
@@ -165,6 +170,17 @@ int cuba_hip_set_graph_begin(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
 	const double* meas, const double* omega)
 {
 	return guarded(s, [&] { s->setGraph(Pt, Pf, Lt, Lf, q, t, cam, Xw, E, edge_pose, edge_landmark, edge_dim, meas, omega, true); });
+}
+
+int cuba_hip_set_graph_partition(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
+	const double* q, const double* t, const double* cam, const double* Xw,
+	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
+	const double* meas, const double* omega, int landmark_begin, int landmark_end)
+{
+	return guarded(s, [&] {
+		if (landmark_end < 0) throw ArgError{ "bad landmark range" };
+		s->setGraph(Pt, Pf, Lt, Lf, q, t, cam, Xw, E, edge_pose, edge_landmark, edge_dim, meas, omega, false, landmark_begin, landmark_end);
+	});
 }
 
 int cuba_hip_set_graph_end(cuba_hip_solver* s)
@@ -202,6 +218,16 @@ int cuba_hip_set_lambda(cuba_hip_solver* s, double lambda) { return guarded(s, [
 int cuba_hip_restore_diagonal(cuba_hip_solver* s) { return guarded(s, [&] { s->lambda = 0; }); }
 
 int cuba_hip_schur(cuba_hip_solver* s) { return guarded(s, [&] { s->schur(); }); }
+
+int cuba_hip_schur_parts(cuba_hip_solver* s, int* n_parts)
+{
+	return guarded(s, [&] { s->need(); if (n_parts) *n_parts = s->schurParts(); });
+}
+
+int cuba_hip_schur_part(cuba_hip_solver* s, int part, size_t ranges[4])
+{
+	return guarded(s, [&] { size_t r[4]; s->schurPart(part, r); if (ranges) std::copy(r, r + 4, ranges); });
+}
 
 int cuba_hip_solve_reduced(cuba_hip_solver* s, int* ok)
 {
@@ -335,6 +361,7 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
 		else if (k == "exact_solve_fallbacks") *value = s->cntDirect;
 		else if (k == "exact_solve_failures") *value = s->cntDirectFailed;
 		else if (k == "graph_uploads") *value = s->cntUploads;
+		else if (k == "value_bytes_uploaded") *value = s->cntValueBytes;
 		else throw ArgError{ "unknown counter: " + k };
 	});
 }
@@ -435,6 +462,7 @@ int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_
 			return;
 		}
 		if (landmark_begin < 0 || landmark_end > s->Lt || landmark_begin > landmark_end) throw ArgError{ "bad landmark range" };
+		if (s->partHi >= 0 && landmark_begin == s->partLo && landmark_end == s->partHi) return;      // (cuba_hip_set_graph_partition set it already)
 		s->partLo = landmark_begin; s->partHi = landmark_end;
 		s->haveStructure = false;
 		// the range is in the caller's landmark numbering: unless it is the whole range, the internal landmark order ends here (rows of the

@@ -132,6 +132,10 @@ struct cuba_hip_solver
 	DevBuf<int> d_rawEp, d_rawEl, d_counters, d_tmpI0, d_tmpI1, d_adjRow, d_lowerPtr, d_chunk;
 	DevBuf<uint8_t> d_rawDim;
 	DevBuf<double> d_rawMeas, d_rawOmega, d_chiCaller;
+	// upload for one rank of a landmark partition (cuba_hip_set_graph_partition): ids + packed {meas, omega} of the edges the rank owns
+	DevBuf<int> d_ownIds; DevBuf<double> d_ownVals;
+	std::vector<int> h_ownIds; std::vector<double> h_ownVals;
+	int64_t cntValueBytes = 0;   // bytes of measurements + information that crossed PCIe (all uploads of this handle)
 	DevBuf<uint32_t> d_perm, d_k32a, d_k32b, d_v32a, d_v32b;
 	DevBuf<uint64_t> d_k64a, d_k64b, d_v64a, d_v64b;
 	DevBuf<unsigned char> d_topoTemp;
@@ -171,6 +175,18 @@ struct cuba_hip_solver
 	int Pt = 0, Pf = 0, Lt = 0, Lf = 0, E = 0;
 	bool haveGraph = false, haveStructure = false;
 	int partLo = 0, partHi = -1; // landmark range [partLo, partHi) this handle evaluates (-1 = all): multi-GPU partition
+	// Reduction in parts (landmark partitions, option "reduction_chunks"): the reduced matrix is cut at block rows into ranges of about
+	// equal size, the block list of the Schur pass is grouped by range (order inside a range kept), and the pass runs range by range --
+	// a multi-GPU driver starts summing a finished range over the ranks while the next one is computed (cuba_hip_schur_part).
+	struct RedPart { BlockPassRange od; size_t blkBegin, blkEnd; };
+	int redChunks = 0;           // 0 = automatic (one part per 8 MiB of the reduced matrix, at most 8), n = that many parts at most
+	std::vector<RedPart> redParts;   // empty: one part, the block list as the structure builders left it
+	void cutReductionParts();
+	int schurParts() const { return redParts.empty() ? 1 : (int)redParts.size(); }
+	// part 0: landmark pass, pose pass and the blocks of range 0; part c: the blocks of range c.  ranges = {offset, count} of the part's
+	// block range in the reduction buffer, then {offset, count} of [bsc | bp] (part 0) or {0, 0}
+	void schurPart(int part, size_t ranges[4]);
+	bool partsByCaller = false;  // (schurPart(0) in flight: linearize() leaves the further ranges to the caller)
 	std::vector<int> perm;       // sorted position -> caller edge index
 	std::vector<int> h_lmptr, h_epose;   // sorted, e_pose without the stereo bit
 	RobustKernel rk[2] = { { 0, 0 }, { 0, 0 } };
@@ -424,7 +440,8 @@ struct cuba_hip_solver
 	int* h_tileStage = nullptr; size_t tileStageCap = 0; hipEvent_t evTileInputs = nullptr;     // page-locked staging of the tile-order inputs
 	void finishValues();
 	void setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double* q, const double* t, const double* cam, const double* Xw,
-		int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega, bool deferValues = false);
+		int E_, const int32_t* ep, const int32_t* el, const uint8_t* edim, const double* meas, const double* omega, bool deferValues = false,
+		int ownLo = 0, int ownHi = -1);      // ownHi >= 0: the handle is restricted to the landmarks [ownLo, ownHi) and reads the values of their edges only
 
 	// ---------------------------------------------------------------------------------------------
 	// Symbolic structure: Hsc pattern from landmark co-visibility (ref: HschurSparseBlockMatrix::

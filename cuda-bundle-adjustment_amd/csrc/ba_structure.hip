@@ -92,6 +92,15 @@ __global__ __launch_bounds__(T) void gather_edges_kernel(const uint32_t* perm, c
 	w[i] = (Scalar)omega[e];
 }
 
+__global__ __launch_bounds__(T) void scatter_values_kernel(const int* ids, const double* packed, int n, double* meas, double* omega)
+{
+	const int i = blockIdx.x * T + threadIdx.x;
+	if (i >= n) return;
+	const size_t e = ids[i];
+	meas[3 * e] = packed[4 * (size_t)i]; meas[3 * e + 1] = packed[4 * (size_t)i + 1]; meas[3 * e + 2] = packed[4 * (size_t)i + 2];
+	omega[e] = packed[4 * (size_t)i + 3];
+}
+
 __global__ __launch_bounds__(T) void segment_ptr_kernel(const int* keys, int n, int nSeg, int* ptr)
 {
 	const int i = blockIdx.x * T + threadIdx.x;
@@ -414,6 +423,11 @@ void launch_gather_edges(const uint32_t* perm, const int* ep, const int* el, con
 	int* e_pose, int* e_lm, Scalar* mu, Scalar* mv, Scalar* mr, Scalar* w, hipStream_t s)
 {
 	if (E > 0) hipLaunchKernelGGL(gather_edges_kernel, grid_for(E), dim3(T), 0, s, perm, ep, el, dim, meas, omega, E, e_pose, e_lm, mu, mv, mr, w);
+}
+
+void launch_scatter_values(const int* ids, const double* packed, int n, double* meas, double* omega, hipStream_t s)
+{
+	if (n > 0) hipLaunchKernelGGL(scatter_values_kernel, grid_for(n), dim3(T), 0, s, ids, packed, n, meas, omega);
 }
 
 void launch_segment_ptr(const int* keys, int n, int nSeg, int* ptr, hipStream_t s)

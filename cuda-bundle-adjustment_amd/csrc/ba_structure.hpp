@@ -40,6 +40,8 @@ void launch_edge_keys(const int* ep, const int* el, const uint8_t* dim, int E, i
 // sorted edge arrays from the caller-order ones through the sort permutation
 void launch_gather_edges(const uint32_t* perm, const int* ep, const int* el, const uint8_t* dim, const double* meas, const double* omega, int E,
 	int* e_pose, int* e_lm, Scalar* mu, Scalar* mv, Scalar* mr, Scalar* w, hipStream_t s);
+// values of a subset of the edges into the caller-order arrays: meas[3 * ids[i] ..] = packed[4 * i .. + 2], omega[ids[i]] = packed[4 * i + 3]
+void launch_scatter_values(const int* ids, const double* packed, int n, double* meas, double* omega, hipStream_t s);
 // ptr[k] = first position i with keys[i] >= k, k = 0..nSeg (keys ascending; ptr[nSeg] counts the keys < nSeg)
 void launch_segment_ptr(const int* keys, int n, int nSeg, int* ptr, hipStream_t s);
 

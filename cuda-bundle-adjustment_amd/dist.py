@@ -301,6 +301,7 @@ def load_dist_library(precision="f64"):
     lib.cuba_hip_dist_optimize.argtypes = [D, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.cuba_hip_dist_complete_solution.argtypes = [D]
     lib.cuba_hip_dist_get_counters.argtypes = [D, C.POINTER(C.c_longlong)]
+    lib.cuba_hip_dist_reduction_parts.argtypes = [D, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     lib.cuba_hip_dist_destroy.argtypes = [D]
     lib.cuba_hip_dist_last_error.argtypes = [D]
     lib.cuba_hip_dist_last_error.restype = C.c_char_p
@@ -384,6 +385,13 @@ class NativeDist:
         c = (C.c_longlong * 4)()
         self._ck(self.lib.cuba_hip_dist_get_counters(self.h, c))
         return dict(large_allreduces=int(c[0]), small_allreduces=int(c[1]), large_elements=int(c[2]), lm_trials=int(c[3]))
+
+    def reduction_parts(self):
+        """(parts the per-trial sum is issued in, all-reduces issued under a later part of the Schur pass so far)"""
+        import ctypes as C
+        n, k = C.c_int(), C.c_longlong()
+        self._ck(self.lib.cuba_hip_dist_reduction_parts(self.h, C.byref(n), C.byref(k)))
+        return n.value, int(k.value)
 
     def close(self):
         if getattr(self, "h", None):

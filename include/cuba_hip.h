@@ -124,6 +124,8 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    "spmv_upper" (default -1 = automatic: on beyond 1536 free poses, where the PCG kernels are bound by bytes; 1 / 0 = on / off: the
    PCG iteration as three launches straight from the upper-triangular BSR storage -- SpMV with the transposed products parked per
    block, row updates + P^T r per aggregate, preconditioner -- instead of two launches on a row-ordered copy of both triangles).
+   "reduction_chunks" (default 0 = automatic; landmark partitions only: number of block-row ranges the reduced matrix is produced -- and,
+   by the multi-GPU driver, summed -- in, see cuba_hip_schur_part),
    "landmark_reorder" (default 1, takes effect with the next cuba_hip_set_graph: the free landmarks are renumbered internally by (first, last)
    observing pose of the internal pose order, so that landmark-major data inherit the trajectory's locality whatever the caller's ids are;
    every host-pointer entry point keeps the caller's landmark numbering; a landmark partition other than the whole range, and the host
@@ -286,7 +288,9 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
    PCG batches + the LM decisions it had to see), "pcg_iterations_plain_launches" (iterations enqueued as plain launches although graphs
    are on: graph not instantiated yet), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
    life of the handle, never reset: a caller that keeps state about "what the device holds" -- the promises of cuba_hip_hint_unchanged --
-   stores this number with it and distrusts its state when the two differ).  Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
+   stores this number with it and distrusts its state when the two differ), "value_bytes_uploaded" (bytes of measurements and
+   information that crossed PCIe in the life of the handle: 32 per edge and full upload, 36 per OWNED edge for cuba_hip_set_graph_partition).
+   Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
 int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);
 
 /* PCG iteration count of every reduced solve since cuba_hip_set_graph, oldest first (at most `capacity` are written,
@@ -325,6 +329,16 @@ int cuba_hip_time_kernels(cuba_hip_solver* s, int reps, double ms_per_launch[CUB
    cuba_hip_solve_reduced; chi2 and the landmark parts of max-diagonal / scale are reduced as scalars. */
 /* (landmark_begin, landmark_end) = (0, -1) removes the restriction again. */
 int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_end);
+/* cuba_hip_set_graph and cuba_hip_set_partition in one call, for a rank that knows its range when it uploads: the index arrays and the
+   estimates go up whole (the block pattern and the pose order are global), but meas / omega are READ ONLY for the edges whose landmark lies
+   in [landmark_begin, landmark_end) -- 36 bytes per owned edge cross PCIe instead of 32 per edge of the graph, i.e. about 1 / N of the
+   value arrays on each of N ranks -- and need not hold anything meaningful elsewhere.  The other edges' values read as zeros on the
+   device; no stage of a partitioned handle looks at them (cuba_hip_chi_squares reports 0 for them).  Lifting the partition afterwards
+   (cuba_hip_set_partition(s, 0, -1)) therefore needs a new upload.  With the option "device_setup" = 0 the whole arrays are read. */
+int cuba_hip_set_graph_partition(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
+	const double* q, const double* t, const double* cam, const double* Xw,
+	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,
+	const double* meas, const double* omega, int landmark_begin, int landmark_end);
 /* First half of cuba_hip_max_diagonal: accumulate Hpp (diagonal blocks of the reduction buffer), bp, Hll. */
 int cuba_hip_assemble(cuba_hip_solver* s);
 /* Second half: max diag of the (externally summed) Hpp and of this rank's Hll. */
@@ -361,6 +375,19 @@ int cuba_hip_get_stream(cuba_hip_solver* s, void** hip_stream);
      [0] robust chi2 of the local edges, [1] landmark part of sum x (lambda x + b) from the last cuba_hip_back_substitute,
      [2] pose part (only if with_scale != 0).  A multi-GPU driver sums [0..1] over the ranks in-stream. */
 int cuba_hip_evaluate_device(cuba_hip_solver* s, double lambda, int with_scale, void** device_scalars3);
+
+/* cuba_hip_schur in parts, for a driver that overlaps the sum over the ranks with the pass that produces it.  A landmark-partitioned
+   handle cuts its reduced matrix at block rows into ranges of about equal size (option "reduction_chunks": 0 = automatic, one range
+   per 8 MiB of matrix values and at most 8 -- a single part below 16 MiB --, n = at most n ranges; the cuts follow from the block
+   pattern alone, so all ranks make the same ones) and runs the off-diagonal block pass range by range.  cuba_hip_schur_parts reports
+   the number of parts (1 without a partition).  cuba_hip_schur_part(part) enqueues part 0 = linearisation, landmark pass, pose pass
+   (all diagonal blocks, bsc, bp) and the off-diagonal blocks of range 0, or part c > 0 = the off-diagonal blocks of range c; parts
+   must be run in the order 0 .. n - 1, all of them.  Once the work of part c is complete in stream order, the elements
+   [ranges[0], ranges[0] + ranges[1]) of cuba_hip_reduction_buffer -- the blocks of range c -- and [ranges[2], ranges[2] + ranges[3])
+   -- [bsc | bp] for part 0, empty otherwise -- hold this rank's final contribution.  The results are those of cuba_hip_schur bit for
+   bit (which, on such a handle, simply runs all parts). */
+int cuba_hip_schur_parts(cuba_hip_solver* s, int* n_parts);
+int cuba_hip_schur_part(cuba_hip_solver* s, int part, size_t ranges[4]);
 
 /* Device address + length (in doubles) of the contiguous buffer [Hsc values | bsc | bp] that a
    landmark-partitioned multi-GPU driver must sum across ranks between cuba_hip_schur and

@@ -8,7 +8,10 @@
  *
  * Per LM trial every rank
  *   1. linearises and Schur-reduces ITS landmarks        cuba_hip_schur                      (local)
- *   2. sums the reduction buffer [Hsc | bsc | bp]        ONE large all-reduce, in-stream     (xGMI)
+ *   2. sums the reduction buffer [Hsc | bsc | bp]        ONE large all-reduce, in-stream     (xGMI) -- or, for a reduced matrix of
+ *                                                        16 MiB and more (option "reduction_chunks" of the solver handle), one
+ *                                                        all-reduce per block-row range, issued on a second stream as soon as the
+ *                                                        range is complete, under the block pass of the next range (cuba_hip_schur_part)
  *   3. solves the reduced system                         cuba_hip_solve_reduced              (replicated: identical inputs and
  *                                                        fixed summation orders give bit-identical increments on every rank,
  *                                                        so nothing is broadcast)
@@ -68,6 +71,9 @@ int cuba_hip_dist_complete_solution(cuba_hip_dist* d);
 
 /* [0] large all-reduces, [1] small all-reduces, [2] elements moved by the large ones, [3] LM trials */
 int cuba_hip_dist_get_counters(cuba_hip_dist* d, long long counters[4]);
+/* Parts the per-trial sum of the reduction buffer is issued in (1 = one all-reduce behind the whole Schur pass), and the number of
+   all-reduces so far that were issued while a later part of the pass was still to be enqueued (0 with one part). */
+int cuba_hip_dist_reduction_parts(cuba_hip_dist* d, int* n_parts, long long* overlapped);
 
 const char* cuba_hip_dist_last_error(const cuba_hip_dist* d);
 int cuba_hip_dist_destroy(cuba_hip_dist* d);

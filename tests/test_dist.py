@@ -101,7 +101,19 @@ def test_native_driver_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
-def _run_native_ranks(fp, world, iters, make_comm_args, precision="f64"):
+def _values_only_inside(fp, rng):
+    """A copy of the graph whose measurements / information are NaN for every edge outside the landmark range: what a rank that holds
+    only its own observations could pass to cuba_hip_set_graph_partition."""
+    import copy
+    lo, hi = rng
+    own = (fp.eL >= lo) & (fp.eL < hi)
+    g = copy.copy(fp)
+    g.meas = np.where(own[:, None], fp.meas.reshape(len(own), -1), np.nan).reshape(fp.meas.shape)
+    g.omega = np.where(own, fp.omega, np.nan)
+    return g
+
+
+def _run_native_ranks(fp, world, iters, make_comm_args, precision="f64", parts_out=None, ranged=False, **options):
     """Ranks as host threads on one GPU, each with its own solver handle + native driver over an in-process communicator."""
     from cuba_amd.capi import HipSolver
     from cuba_amd.dist import NativeDist
@@ -110,9 +122,15 @@ def _run_native_ranks(fp, world, iters, make_comm_args, precision="f64"):
 
     def work(c):
         try:
-            h = HipSolver(fp, RK_HUBER, precision=precision)
+            if ranged:
+                h = HipSolver(None, RK_HUBER, precision=precision, **options)
+                h.set_graph(_values_only_inside(fp, landmark_ranges(fp.eL, fp.Lt, world)[c.rank]), landmark_range=landmark_ranges(fp.eL, fp.Lt, world)[c.rank])
+            else:
+                h = HipSolver(fp, RK_HUBER, precision=precision, **options)
             d = NativeDist(h, fp, c.rank, world, comm=c, precision=precision)
             chi2 = d.optimize(iters)
+            if parts_out is not None:
+                parts_out[c.rank] = d.reduction_parts()
             out[c.rank] = (chi2, d.complete_solution(), d.counters())
             d.close()
         except Exception as e:   # pragma: no cover
@@ -142,6 +160,114 @@ def test_native_driver_emulated_ranks(world):
         assert c["small_allreduces"] == c["lm_trials"] + 1 + 1          # evaluation per trial + first F + max-diagonal
     assert all(np.array_equal(out[0][0], o[0]) for o in out[1:])
     assert all(np.array_equal(a, b) for o in out[1:] for a, b in zip(out[0][1], o[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_setup", [1, 0])
+def test_schur_in_parts_is_the_schur_pass_bit_for_bit(device_setup):
+    """cuba_hip_schur_part (include/cuba_hip.h): a landmark-partitioned handle cuts its reduced matrix at block rows into ranges and runs
+    the block pass range by range.  The ranges tile the matrix part of the reduction buffer, part 0 also reports [bsc | bp]; every
+    reported range is final when its part has run (the later parts do not touch it), and the whole buffer equals the one-pass result
+    of a handle without the cut bit for bit -- for both structure builders, on every rank."""
+    import torch
+    from cuba_amd.capi import HipSolver
+    fp = flatten(synth_ba(120, 6000, 24000, seed=9))
+    whole = HipSolver(fp, RK_HUBER)
+    lam = 1e-5 * whole.max_diagonal()
+    for lo, hi in landmark_ranges(fp.eL, fp.Lt, 3):
+        one = HipSolver(fp, RK_HUBER, reduction_chunks=1, device_setup=device_setup)
+        one.set_partition(lo, hi)
+        assert one.schur_parts() == 1
+        one.set_lambda(lam); one.schur()
+        want = {k: one.array(k) for k in ("hsc", "bsc", "bp")}
+        h = HipSolver(fp, RK_HUBER, reduction_chunks=5, device_setup=device_setup)
+        h.set_partition(lo, hi)
+        nparts = h.schur_parts()
+        assert 2 <= nparts <= 5
+        h.set_lambda(lam)
+        nhsc = want["hsc"].size
+        covered, snaps = 0, []
+        for c in range(nparts):
+            (o0, n0), (o1, n1) = h.schur_part(c)
+            assert o0 == covered and n0 > 0 and n0 % 36 == 0
+            covered += n0
+            assert (o1, n1) == ((nhsc, want["bsc"].size + want["bp"].size) if c == 0 else (0, 0))
+            snaps.append((o0, n0, h.array("hsc")[o0:o0 + n0].copy()))
+            if c == 0:
+                assert np.array_equal(h.array("bsc"), want["bsc"]) and np.array_equal(h.array("bp"), want["bp"])
+        assert covered == nhsc
+        got = h.array("hsc")
+        assert np.array_equal(got, want["hsc"])
+        for o0, n0, part in snaps:
+            assert np.array_equal(part, got[o0:o0 + n0])
+        # the one-call stage of such a handle runs all parts
+        h.set_lambda(2 * lam); h.schur(); one.set_lambda(2 * lam); one.schur()
+        assert np.array_equal(h.array("hsc"), one.array("hsc")) and np.array_equal(h.array("bsc"), one.array("bsc"))
+        with pytest.raises(Exception):
+            h.schur_part(nparts)
+    assert whole.schur_parts() == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_native_driver_sums_the_reduction_in_parts(precision):
+    """The native driver with the reduction cut into parts: one all-reduce per block-row range, issued behind
+    the block pass of that range on a second stream, plus one for [bsc | bp]: same trajectory and estimates as with one all-reduce per
+    trial, bit for bit, on every rank; the counters count the parts."""
+    fp = flatten(synth_ba(120, 6000, 24000, seed=9))
+    world, iters = 3, 6
+    base = _run_native_ranks(fp, world, iters, None, precision=precision, reduction_chunks=1)
+    parts = [None] * world
+    out = _run_native_ranks(fp, world, iters, None, precision=precision, parts_out=parts, reduction_chunks=4)
+    nparts = parts[0][0]
+    assert 2 <= nparts <= 4 and all(p[0] == nparts for p in parts)
+    for (chi2, sol, c), (chi2b, solb, cb) in zip(out, base):
+        assert np.array_equal(chi2, chi2b)
+        assert all(np.array_equal(a, b) for a, b in zip(sol, solb))
+        assert c["lm_trials"] == cb["lm_trials"] and c["small_allreduces"] == cb["small_allreduces"]
+        assert c["large_allreduces"] == c["lm_trials"] * (nparts + 1) + 1 + 1          # per trial: ranges + [bsc | bp]; lambda_0; complete_solution
+        assert c["large_elements"] == cb["large_elements"]
+    for p, (_, _, c) in zip(parts, out):
+        assert p[1] == c["lm_trials"] * nparts                                           # all but the last range's sum went out under a later part
+
+
+@pytest.mark.gpu
+def test_rank_upload_sends_only_its_own_values():
+    """cuba_hip_set_graph_partition (include/cuba_hip.h): a rank uploads the index arrays whole and the
+    measurements / information of its own landmarks' edges only -- here the other edges' values are NaN on the host, so anything that read
+    them would show.  Same reduced-system contribution, chi2 and per-edge chi2 as whole upload + cuba_hip_set_partition, bit for bit;
+    36 bytes per owned edge cross PCIe; the native driver on such handles walks the trajectory of fully loaded ones."""
+    from cuba_amd.capi import HipSolver
+    fp = flatten(synth_ba(120, 6000, 24000, seed=9))
+    whole = HipSolver(fp, RK_HUBER)
+    lam = 1e-5 * whole.max_diagonal()
+    world, sent = 3, 0
+    for lo, hi in landmark_ranges(fp.eL, fp.Lt, world):
+        a = HipSolver(fp, RK_HUBER)
+        a.set_partition(lo, hi)
+        b = HipSolver(None, RK_HUBER)
+        b.set_graph(_values_only_inside(fp, (lo, hi)), landmark_range=(lo, hi))
+        own = (fp.eL >= lo) & (fp.eL < hi)
+        assert b.counter("value_bytes_uploaded") == 36 * int(own.sum()) and a.counter("value_bytes_uploaded") == 32 * fp.E
+        sent += b.counter("value_bytes_uploaded")
+        assert a.compute_errors() == b.compute_errors()
+        ca, cb = a.chi_squares(), b.chi_squares()
+        assert np.array_equal(ca, cb) and np.all(cb[~own] == 0) and np.all(cb[own] > 0)
+        for h in (a, b):
+            h.set_lambda(lam); h.schur()
+        for k in ("hsc", "bsc", "bp"):
+            assert np.array_equal(a.array(k), b.array(k)), k
+        assert b.solve_reduced() and a.solve_reduced()
+        assert np.array_equal(a.array("xp"), b.array("xp"))
+    assert sent == 36 * fp.E
+    base = _run_native_ranks(fp, world, 6, None)
+    out = _run_native_ranks(fp, world, 6, None, ranged=True)
+    for (chi2, sol, c), (chi2b, solb, cb) in zip(out, base):
+        assert np.array_equal(chi2, chi2b) and all(np.array_equal(x, y) for x, y in zip(sol, solb)) and c == cb
+    # a bad range is refused before the previous graph is touched
+    with pytest.raises(Exception):
+        whole.set_graph(fp, landmark_range=(5, fp.Lt + 1))
+    assert whole.compute_errors() > 0
 
 
 @pytest.mark.gpu
