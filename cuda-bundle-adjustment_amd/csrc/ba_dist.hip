@@ -337,6 +337,7 @@ int cuba_hip_dist_destroy(cuba_hip_dist* d)
 {
 	if (!d) return CUBA_HIP_ERR_INVALID_ARGUMENT;
 	if (d->stream) (void)hipStreamSynchronize(d->stream);
+	if (d->commStream) (void)hipStreamSynchronize(d->commStream);
 	delete d;            // (the destructor releases the communicator and the pinned block; the solver handle is the caller's)
 	return CUBA_HIP_OK;
 }
