@@ -52,6 +52,8 @@ struct cuba_hip_dist
 	bool partitionSet = false;
 	// reduction in parts (cuba_hip_schur_part): the sum of part c runs on `commStream` while the solver's stream computes part c + 1
 	int nParts = 1;
+	bool exchange = false;           // collectives are issued: more than one rank (or a 1-rank RCCL communicator under CUBA_HIP_DIST_SINGLE_RANK_COLLECTIVES,
+	                                 // which lets a one-GPU box run the stream / event choreography of the parts over the real library)
 	hipStream_t commStream = nullptr;
 	hipEvent_t evPart = nullptr, evSummed = nullptr;
 	long long nOverlapped = 0;
@@ -70,7 +72,7 @@ struct cuba_hip_dist
 
 	void allreduceOn(hipStream_t on, void* buf, size_t count, bool max)
 	{
-		if (world == 1 || count == 0) return;
+		if (!exchange || count == 0) return;
 		if (custom)
 		{
 			const int rc = (max ? ops.allreduce_max : ops.allreduce_sum)(ops.ctx, buf, count, scalarSize, (void*)on);
@@ -86,7 +88,7 @@ struct cuba_hip_dist
 	// functions of the global block pattern.)
 	void schurAndSum()
 	{
-		if (nParts <= 1 || world == 1)
+		if (nParts <= 1 || !exchange)
 		{
 			if (cuba_hip_schur(s) != CUBA_HIP_OK) throw Fail{ CUBA_HIP_ERR_RUNTIME, std::string("cuba_hip_schur: ") + cuba_hip_last_error(s) };
 			allreduce(red, redCount, false); nLarge++; largeElems += (long long)redCount;
@@ -139,7 +141,8 @@ void bind(cuba_hip_dist* d, cuba_hip_solver* s, int rank, int world, int lb, int
 	SOLVER_TRY(cuba_hip_build_structure(s));
 	SOLVER_TRY(cuba_hip_reduction_buffer(s, &d->red, &d->redCount));
 	SOLVER_TRY(cuba_hip_schur_parts(s, &d->nParts));
-	if (d->nParts > 1 && world > 1)
+	d->exchange = world > 1 || std::getenv("CUBA_HIP_DIST_SINGLE_RANK_COLLECTIVES") != nullptr;
+	if (d->nParts > 1 && d->exchange)
 	{
 		HIP_TRY(hipStreamCreateWithFlags(&d->commStream, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&d->evPart, hipEventDisableTiming));
@@ -328,7 +331,7 @@ int cuba_hip_dist_get_counters(cuba_hip_dist* d, long long c[4])
 
 int cuba_hip_dist_reduction_parts(cuba_hip_dist* d, int* n_parts, long long* overlapped)
 {
-	return guarded(d, [&] { if (n_parts) *n_parts = d->world > 1 ? d->nParts : 1; if (overlapped) *overlapped = d->nOverlapped; });
+	return guarded(d, [&] { if (n_parts) *n_parts = d->exchange ? d->nParts : 1; if (overlapped) *overlapped = d->nOverlapped; });
 }
 
 const char* cuba_hip_dist_last_error(const cuba_hip_dist* d) { return d ? d->lastError.c_str() : "null driver handle"; }

@@ -419,6 +419,28 @@ def test_native_driver_over_a_real_rccl_communicator_single_rank():
     d.close()
 
 
+@pytest.mark.gpu
+def test_reduction_in_parts_over_a_real_rccl_communicator_single_rank(monkeypatch):
+    """The stream / event choreography of the reduction in parts over the real library, as far as one GPU allows: a 1-rank RCCL
+    communicator whose collectives are issued anyway (CUBA_HIP_DIST_SINGLE_RANK_COLLECTIVES), ncclAllReduce of every block-row range on the
+    driver's second stream behind an event of the solver's stream.  Same trajectory as one all-reduce per trial, bit for bit."""
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.dist import NativeDist, rccl_unique_id
+    fp = flatten(synth_ba(120, 6000, 24000, seed=9))
+    monkeypatch.setenv("CUBA_HIP_DIST_SINGLE_RANK_COLLECTIVES", "1")
+    runs = []
+    for chunks in (1, 4):
+        h = HipSolver(fp, RK_HUBER, reduction_chunks=chunks)
+        d = NativeDist(h, fp, 0, 1, unique_id=rccl_unique_id())
+        chi2 = d.optimize(6)
+        runs.append((chi2, h.state(), d.counters(), d.reduction_parts()))
+        d.close()
+    (c1, s1, k1, p1), (c4, s4, k4, p4) = runs
+    assert p1 == (1, 0) and 2 <= p4[0] <= 4 and p4[1] == k4["lm_trials"] * p4[0]
+    assert np.array_equal(c1, c4) and all(np.array_equal(a, b) for a, b in zip(s1, s4))
+    assert k4["large_allreduces"] == k4["lm_trials"] * (p4[0] + 1) + 1 and k1["large_allreduces"] == k1["lm_trials"] + 1
+
+
 def _gpu_count():
     try:
         import torch
