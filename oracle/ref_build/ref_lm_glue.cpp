@@ -5,11 +5,17 @@
 // with only the closed-source cuSOLVER step replaced (ref_linear_solver.cpp).  tests/test_ref_lm.py requires the CPU
 // oracle's and the HIP path's LM TRAJECTORIES (chi2 per iteration, final estimates, per-edge chi2) to follow it -- the
 // LM-level pin "from the reference itself" next to the stage-level pin of ref_glue.cpp.
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <vector>
 
 #include "cuda_bundle_adjustment.h"     // the reference's public header (-I/root/reference/include)
+
+// the reference's own stage timers (CudaBundleAdjustment::timeProfile, keys "0: Initialize Optimizer" .. "7: Update Solution", seconds) of
+// the LAST initialize() + optimize() of the last ref_lm_run, then the host wall of that initialize() and of that optimize()
+static double g_lastProfile[10];
+extern "C" void ref_lm_last_profile(double out[10]) { for (int i = 0; i < 10; i++) out[i] = g_lastProfile[i]; }
 
 extern "C" int ref_lm_run(
 	int P, const int* pose_id, const uint8_t* pose_fixed, const double* q, const double* t, const double* cam5,
@@ -51,8 +57,17 @@ extern "C" int ref_lm_run(
 	// nruns > 1: the samples' protocol -- initialize() + optimize() again from the estimates the previous run wrote back
 	for (int run = 0; run < nruns; run++)
 	{
+		const auto t0 = std::chrono::steady_clock::now();
 		ba->initialize();
+		const auto t1 = std::chrono::steady_clock::now();
 		ba->optimize(niterations);
+		const auto t2 = std::chrono::steady_clock::now();
+		g_lastProfile[8] = std::chrono::duration<double>(t1 - t0).count();
+		g_lastProfile[9] = std::chrono::duration<double>(t2 - t1).count();
+	}
+	{
+		int k = 0;
+		for (const auto& item : ba->timeProfile()) if (k < 8) g_lastProfile[k++] = item.second;      // (a std::map: keys sort by their leading digit)
 	}
 	const auto& stats = ba->batchStatistics();
 	*n_done = (int)stats.size();

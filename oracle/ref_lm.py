@@ -15,13 +15,19 @@ LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libcuba_
 _dp, _ip, _bp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
 
 
+# the reference's CudaBundleAdjustment::timeProfile() keys (src/cuda_bundle_adjustment.cpp:545-562), seconds of the last initialize() + optimize()
+PROFILE_KEYS = ("0: Initialize Optimizer", "1: Build Structure", "2: Compute Error", "3: Build System", "4: Schur Complement",
+                "5: Symbolic Decomposition", "6: Numerical Decomposition", "7: Update Solution")
+
+
 def available():
     return os.path.exists(LIB)
 
 
 def run(g, robust, niterations, nruns=1):
     """initialize() + optimize(niterations), `nruns` times in a row, on a cuba_amd.graph.Graph (user-level ids).
-    Returns dict(chi2 of the LAST run, q, t, Xw in the graph's row order, per-edge chi2 mono / stereo)."""
+    Returns dict(chi2 of the LAST run, q, t, Xw in the graph's row order, per-edge chi2 mono / stereo, and the reference's own stage
+    timers + the host wall of the last initialize() / optimize())."""
     lib = C.CDLL(LIB)
     f = lambda a: np.ascontiguousarray(a, dtype=np.float64)   # noqa: E731
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)   # noqa: E731
@@ -45,4 +51,7 @@ def run(g, robust, niterations, nruns=1):
                         d(chi2), C.byref(n), d(qo), d(to), d(Xo), d(cm), d(cs))
     if rc != 0:
         raise RuntimeError(f"reference optimiser returned {rc}")
-    return dict(chi2=chi2[:n.value], q=qo, t=to, Xw=Xo, chi_mono=cm[:E2], chi_stereo=cs[:E3])
+    prof = np.zeros(10)
+    lib.ref_lm_last_profile(d(prof))
+    return dict(chi2=chi2[:n.value], q=qo, t=to, Xw=Xo, chi_mono=cm[:E2], chi_stereo=cs[:E3],
+                profile=dict(zip(PROFILE_KEYS, prof[:8].tolist())), wall_initialize=float(prof[8]), wall_optimize=float(prof[9]))
