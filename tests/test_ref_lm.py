@@ -131,7 +131,7 @@ def test_warm_start_protocol_follows_the_reference():
     assert len(got) == len(ref2["chi2"]) and np.all(np.abs(got - ref2["chi2"]) <= HIP_TOL * ref2["chi2"])
 
 
-@pytest.mark.parametrize("name", ["kitti07_full", "kitti00_full"])
+@pytest.mark.parametrize("name", ["kitti07_full", "kitti00_full", "s2m_full"])
 def test_reference_stage_times_on_this_gpu(name):
     """The reference's own kernels, compiled for gfx950 as they are (CUDA -> HIP name shim), timed by the reference's own stage timers
     (CudaBundleAdjustment::timeProfile, src/cuda_bundle_adjustment.cpp:545-562) on this GPU, beside the HIP path's stage timers of the same
