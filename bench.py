@@ -140,6 +140,30 @@ def newest_profile(pattern):
     return files[-1] if files else None
 
 
+def reference_kernels_citation():
+    """NOT measured by this run: the committed record of the reference's own kernels (its CUDA sources compiled for gfx950 as they are) timed by
+    the reference's own stage timers on an MI355X beside this library's stage timers (tests/test_ref_lm.py::test_reference_stage_times_on_this_gpu
+    writes it; bench.py only quotes the file)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*reference_kernels_on_mi355x_stage_times.txt")))
+    if not files:
+        return None
+    out = {"source": os.path.relpath(files[-1], ROOT), "measured_by_this_run": False,
+           "what": "stages 2 Compute Error + 3 Build System + 4 Schur Complement + 7 Update Solution of initialize() + optimize(10), ms: "
+                   "the reference's kernels on the MI355X | this library (stage timers on)"}
+    shape = None
+    for ln in open(files[-1]):
+        m = re.match(r"\[(\w+)\]", ln)
+        if m:
+            shape = m.group(1)
+        m = re.match(r"\s*kernel stages 2 \+ 3 \+ 4 \+ 7\s+([\d.]+) ms \|\s+([\d.]+) ms", ln)
+        if m and shape:
+            out[shape] = {"reference_kernels_ms": float(m.group(1)), "this_library_ms": float(m.group(2)),
+                          "ratio": float(m.group(1)) / max(float(m.group(2)), 1e-9)}
+    return out
+
+
 def profile_evidence(shape, keys):
     """What the committed rocprofv3 outputs of this shape say about the bench line's kernels: HBM-side traffic per launch (PMC
     FETCH_SIZE / WRITE_SIZE, separate passes, profiles/*_<shape>_pmc_traffic.json: raw and fetch-doubled as MI355X_MICROARCH.md
@@ -689,6 +713,7 @@ def main():
                          "ms_per_step_min": min(block_ms) / args.steps, "ms_per_step_max": max(block_ms) / args.steps,
                          "value_median": E * args.steps * graphs / (float(np.median(block_ms)) * 1e-3)} if block_ms else None),
             "roofline": roof,
+            "reference_kernels_on_mi355x": reference_kernels_citation() if world == 1 else None,
         }
         # the GPU side of the parity leg, then this handle goes: several live handles share the runtime's few hardware queues and
         # slow each other down (a KITTI-07-sized graph runs at half speed as the second handle of a process)
