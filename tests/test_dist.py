@@ -573,7 +573,8 @@ def test_bench_independent_graphs_two_ranks_share_one_gpu_over_gloo():
 
 @pytest.mark.gpu
 def test_degenerate_inputs_do_not_crash():
-    """Empty edge list, a single free pose, a single landmark: every entry point returns (status or result), nothing hangs."""
+    """Empty edge list, a single free pose, a single landmark, a rank upload with an empty / the whole range: every entry point returns
+    (status or result), nothing hangs."""
     from cuba_amd.capi import CubaHipError, HipSolver
     from cuba_amd.graph import FlatProblem
     g = synth_ba(40, 600, 2400, seed=1)
@@ -600,3 +601,20 @@ def test_degenerate_inputs_do_not_crash():
     ref = OracleSolver(one, RK_HUBER).optimize(4)["chi2"]
     got = HipSolver(one, RK_HUBER).optimize(4)["chi2"]
     assert len(got) == len(ref) and np.all(np.abs(got - ref) <= 1e-6 * ref)
+    # a rank upload with an empty range, with no edges, and more reduction ranges asked for than the matrix has block rows
+    h = HipSolver(None, RK_HUBER, reduction_chunks=64)
+    h.set_graph(fp, landmark_range=(7, 7))
+    assert h.counter("value_bytes_uploaded") == 0 and h.compute_errors() == 0.0
+    h.set_lambda(1.0); h.schur()
+    assert 1 <= h.schur_parts() <= 64
+    h.set_graph(fp, landmark_range=(0, fp.Lt))                           # the whole range: every value goes up, 36 bytes each
+    assert h.counter("value_bytes_uploaded") == 36 * fp.E
+    want = HipSolver(fp, RK_HUBER)
+    assert h.compute_errors() == want.compute_errors()
+    parts = h.schur_parts()
+    lam = 1e-5 * want.max_diagonal()
+    h.set_lambda(lam); want.set_lambda(lam); h.schur(); want.schur()
+    assert parts >= 2 and np.array_equal(h.array("hsc"), want.array("hsc")) and np.array_equal(h.array("bsc"), want.array("bsc"))
+    e = HipSolver(None, RK_HUBER)
+    e.set_graph(empty, landmark_range=(0, 1))
+    assert e.compute_errors() == 0.0 and e.schur_parts() == 1
