@@ -95,7 +95,7 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 			// internal landmark order from the pose numbering in force (the caller's here; applyPoseOrder renews it under a new one)
 			if (landmarkOrderAllowed()) computeLandmarkOrder(); else resetLandmarkOrder();
 		}
-		const bool keepValues = promisedValues && reuseSort && sortedValuesValid && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
+		const bool keepValues = promisedValues && reuseSort && sortedValuesValid && !valuesPartial && d_mu.size() == (size_t)E && d_w.size() == (size_t)E;   // (sorted measurement / information arrays of the previous call)
 		const bool defer = deferValues && !keepValues && E > 0;
 		deferredUpload = defer;          // (enqueued LAST, below: the copy engine serves its queue in order, and the small uploads of this call must not wait behind 18 MB)
 		if (defer) { d_rawMeas.resize((size_t)3 * E); d_rawOmega.resize(E); }
@@ -249,6 +249,7 @@ void cuba_hip_solver::setGraph(int Pt_, int Pf_, int Lt_, int Lf_, const double*
 	g.rk[0] = rk[0]; g.rk[1] = rk[1];
 	g.e_begin = 0; g.e_end = E;
 	partLo = ranged ? ownLo : 0; partHi = ranged ? ownHi : -1;
+	valuesPartial = ranged && useDev;          // (the host pipeline reads the whole arrays)
 	if (sameTopology)
 	{
 		// the captured PCG graphs carry the DeviceGraph by value: they stay usable only if no buffer moved

@@ -454,6 +454,9 @@ int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_
 {
 	return guarded(s, [&] {
 		if (!s->haveGraph) throw StateError{ "set_graph must be called first" };
+		// (after a rank's upload the device holds the values of that rank's landmarks only: any other range would silently evaluate zeros)
+		if (s->valuesPartial && (landmark_end < 0 || landmark_begin < s->partLo || landmark_end > s->partHi))
+			throw StateError{ "cuba_hip_set_graph_partition uploaded this range's values only: a wider range needs a new upload" };
 		if (landmark_begin == 0 && landmark_end == -1)          // remove the restriction: the handle evaluates the whole graph again
 		{
 			if (s->partHi >= 0) s->haveStructure = false;

@@ -136,6 +136,7 @@ struct cuba_hip_solver
 	DevBuf<int> d_ownIds; DevBuf<double> d_ownVals;
 	std::vector<int> h_ownIds; std::vector<double> h_ownVals;
 	int64_t cntValueBytes = 0;   // bytes of measurements + information that crossed PCIe (all uploads of this handle)
+	bool valuesPartial = false;  // the last upload was a rank's (cuba_hip_set_graph_partition): only its landmark range has values on the device
 	DevBuf<uint32_t> d_perm, d_k32a, d_k32b, d_v32a, d_v32b;
 	DevBuf<uint64_t> d_k64a, d_k64b, d_v64a, d_v64b;
 	DevBuf<unsigned char> d_topoTemp;

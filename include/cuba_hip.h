@@ -333,8 +333,9 @@ int cuba_hip_set_partition(cuba_hip_solver* s, int landmark_begin, int landmark_
    estimates go up whole (the block pattern and the pose order are global), but meas / omega are READ ONLY for the edges whose landmark lies
    in [landmark_begin, landmark_end) -- 36 bytes per owned edge cross PCIe instead of 32 per edge of the graph, i.e. about 1 / N of the
    value arrays on each of N ranks -- and need not hold anything meaningful elsewhere.  The other edges' values read as zeros on the
-   device; no stage of a partitioned handle looks at them (cuba_hip_chi_squares reports 0 for them).  Lifting the partition afterwards
-   (cuba_hip_set_partition(s, 0, -1)) therefore needs a new upload.  With the option "device_setup" = 0 the whole arrays are read. */
+   device; no stage of a partitioned handle looks at them (cuba_hip_chi_squares reports 0 for them).  Until the next upload the handle
+   therefore refuses a cuba_hip_set_partition beyond this range (CUBA_HIP_ERR_STATE; lifting the restriction included) and ignores a
+   "same values" promise (cuba_hip_hint_unchanged).  With the option "device_setup" = 0 the whole arrays are read. */
 int cuba_hip_set_graph_partition(cuba_hip_solver* s, int Pt, int Pf, int Lt, int Lf,
 	const double* q, const double* t, const double* cam, const double* Xw,
 	int E, const int32_t* edge_pose, const int32_t* edge_landmark, const uint8_t* edge_dim,

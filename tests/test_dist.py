@@ -259,6 +259,9 @@ def test_rank_upload_sends_only_its_own_values():
             assert np.array_equal(a.array(k), b.array(k)), k
         assert b.solve_reduced() and a.solve_reduced()
         assert np.array_equal(a.array("xp"), b.array("xp"))
+        with pytest.raises(Exception):          # the other landmarks' values never reached the device: no wider range without a new upload
+            b.set_partition(0, -1)
+        b.set_partition(lo, (lo + hi) // 2)     # (a narrower one is fine)
     assert sent == 36 * fp.E
     base = _run_native_ranks(fp, world, 6, None)
     out = _run_native_ranks(fp, world, 6, None, ranged=True)
