@@ -131,6 +131,11 @@ def load_library(precision="f64"):
     lib.cuba_hip_debug_dense_inverse.restype = C.c_int
     lib.cuba_hip_debug_dense_solve.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int)]
     lib.cuba_hip_debug_dense_solve.restype = C.c_int
+    lib.cuba_hip_debug_sparse_solve.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int32)]
+    lib.cuba_hip_debug_sparse_solve.restype = C.c_int
+    lib.cuba_hip_debug_sparse_plan.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                               C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.cuba_hip_debug_sparse_plan.restype = C.c_int
     lib.cuba_hip_last_error.argtypes = [H]
     lib.cuba_hip_last_error.restype = C.c_char_p
     lib.cuba_hip_version.restype = C.c_char_p
@@ -164,17 +169,46 @@ def _close_all():
         s.close()
 
 
-def dense_solve(A, b, precision="f64", device=0):
-    """The library's exact reduced solve (dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip) applied to a symmetric
-    matrix whose order is a multiple of 6: test hook.  Returns (x, not_positive_definite)."""
+def dense_solve(A, b, precision="f64", device=0, slack=-1, with_stats=False):
+    """The library's exact reduced solve (sparse tile Cholesky on the matrix cores, csrc/ba_direct.hip) applied to a symmetric
+    matrix whose order is a multiple of 6 (6 x 6 blocks that are identically zero stay out of the pattern): test hook.
+    Returns (x, not_positive_definite[, {tile columns, tiles, levels, slack}])."""
     A = np.asfortranarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros_like(b)
     flag = C.c_int()
-    rc = load_library(precision).cuba_hip_debug_dense_solve(int(device), A.shape[0], _d(A), _d(b), _d(x), C.byref(flag))
+    stats = (C.c_int32 * 4)()
+    rc = load_library(precision).cuba_hip_debug_sparse_solve(int(device), A.shape[0], _d(A), _d(b), _d(x), C.byref(flag), int(slack), stats)
     if rc != 0:
-        raise CubaHipError(f"cuba_hip_debug_dense_solve failed with status {rc}")
+        raise CubaHipError(f"cuba_hip_debug_sparse_solve failed with status {rc}")
+    if with_stats:
+        return x, bool(flag.value), dict(zip(("tile_columns", "tiles", "levels", "slack"), (int(v) for v in stats)))
     return x, bool(flag.value)
+
+
+SPARSE_PLAN_ARRAYS = ("header", "posOfSeg", "colPtr", "rowIdx", "gPtr", "gather", "lvlPtr", "lvlTiles", "lvlColPtr", "lvlCols", "blkTile")
+
+
+def sparse_plan(row_ptr, col_ind, slack=-1, precision="f64"):
+    """Symbolic phase of the exact reduced solve for an upper-triangular block pattern (host only, no device): dict of the plan's arrays
+    (SparseCholPlan in csrc/ba_kernels.hpp)."""
+    lib = load_library(precision)
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int32); ci = np.ascontiguousarray(col_ind, dtype=np.int32)
+    ip = C.POINTER(C.c_int32)
+    out = {}
+    for which, name in enumerate(SPARSE_PLAN_ARRAYS):
+        n = C.c_size_t()
+        rc = lib.cuba_hip_debug_sparse_plan(len(rp) - 1, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), int(slack), which, None, 0, C.byref(n))
+        if rc != 0:
+            raise CubaHipError(f"cuba_hip_debug_sparse_plan failed with status {rc}")
+        a = np.zeros(n.value, dtype=np.int32)
+        rc = lib.cuba_hip_debug_sparse_plan(len(rp) - 1, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), int(slack), which, a.ctypes.data_as(ip), n.value, C.byref(n))
+        if rc != 0:
+            raise CubaHipError(f"cuba_hip_debug_sparse_plan failed with status {rc}")
+        out[name] = a
+    h = out.pop("header")
+    out.update(T=int(h[0]), nTiles=int(h[1]), nLevels=int(h[2]), slack=int(h[3]), entries=int(h[4]), nblk=int(h[5]))
+    return out
 
 
 class HipSolver:

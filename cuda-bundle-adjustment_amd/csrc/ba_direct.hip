@@ -1,360 +1,524 @@
-// ba_direct.hip -- the EXACT reduced solve: Hsc dxp = bsc by a dense blocked Cholesky factorisation on the matrix cores
-// (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32) plus the two triangular solves.  It stands where the reference calls cuSOLVER's
+// ba_direct.hip -- the EXACT reduced solve: Hsc dxp = bsc by a SPARSE tile Cholesky factorisation (tile products on the matrix cores,
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32) plus the two triangular solves.  It stands where the reference calls cuSOLVER's
 // sparse Cholesky (/root/reference/src/cuda_linear_solver.cpp:386-415: solve() is exact for any positive-definite Hsc and reports
 // failure only on a non-positive pivot, :406-410, which CudaBundleAdjustmentImpl::optimize turns into rho = -1,
-// /root/reference/src/cuda_bundle_adjustment.cpp:824-830) for the systems the block PCG of ba_pcg.hip is the wrong tool for: a nearly
-// singular reduced matrix (most observations of many poses at zero robust weight) needs thousands of CG iterations or never gets there.
-// ba_lm.hip hands a solve over to this file when the PCG has used up its iteration budget, broke down, or an earlier solve of the same
-// Levenberg-Marquardt run already had to come here.
+// /root/reference/src/cuda_bundle_adjustment.cpp:824-830), with the three phases of that solver:
+//   ordering + symbolic analysis, once per structure  (ref: cuda_linear_solver.cpp:278-348 METIS / csrcholAnalysis)  -> sparse_chol_plan (host)
+//   numeric factorisation, per solve                  (ref: :147-190 csrcholFactor)                                   -> schol_factor_level_kernel
+//   triangular solves                                 (ref: :192-232 csrcholSolve)                                    -> folded into the factorisation (forward) /
+//                                                                                                                        schol_back_level_kernel (backward)
 //
-// Layout: A is [(N + 160) x N] column-major with N = 6 Pf rounded up to 128; only the tiles on and below the diagonal are read or written.
-// Row N carries the right-hand side: the factorisation of the bordered matrix [A b; b^T .] leaves L^-1 b in that row, so the forward
-// substitution costs nothing extra (the row is simply one more tile row of every kernel below).  Rows N + 1 .. N + 127 are zero padding
-// of the right-hand side's macro row, the last 32 rows keep the column stride off the powers of two.  Unknowns n .. N - 1 are identity
-// padding.
+// Granularity: SC_TP = 5 consecutive free poses of the internal (trajectory) order form a SEGMENT = one 32 x 32 tile row / column of the
+// matrix (30 unknowns + 2 identity-padded ones).  The symbolic phase eliminates the segment graph by minimum degree with multiple
+// elimination -- every round removes an independent set of segments whose degree is within `slack` of the minimum --, which keeps the
+// fill of a trajectory with loop closures at band level (KITTI-00 shape: 2.5 k tiles = 21 MB, 10 000-pose graph: 19 k tiles = 154 MB)
+// and, unlike a band order, leaves a SHALLOW elimination tree (45 / 94 levels instead of 267 / 2000 tile columns).  Columns of one level
+// do not depend on one another: the numeric phase is ONE launch per level.
 //
-// Right-looking, two-level blocking (panel = 128 columns = 4 tile columns of 32):
-//   for every tile column k of the panel:   chol_panel_kernel  X_k = chol(A_kk)^-1 (every workgroup, in LDS: one sweep of 32 dependent steps
-//                                                              that eliminates A_kk and the identity beside it), A_ik <- A_ik X_k^T (matrix cores)
-//                                           chol_upd32_kernel  A_ij -= A_ik A_jk^T for the remaining tile columns j of the panel
-//   once per panel:                         chol_trail_kernel  A_IJ -= W_I W_J^T over 128 x 128 macro tiles, k = 128 (where the flops are:
-//                                                              n^3 / 3 in total, C read and written once per panel instead of once per tile column)
-//   at the end, per tile column k = T-1..0: chol_back_kernel   x_k = X_k^T y_k, then y_j -= L_kj^T x_k for every j < k (one workgroup per j)
+// Numeric phase, left-looking: the workgroup of tile (i, j) gathers A_ij - sum_k L_ik L_jk^T over the finished columns k that reach both
+// rows (a fixed list in ascending k: no atomics, one writer per tile, results reproducible bit for bit) and, redundantly per workgroup
+// of the column, the same for the diagonal tile; one wave then runs the 32-step elimination of the diagonal tile in REGISTERS (lane =
+// row, pivot columns broadcast with v_readlane: no LDS round trips, no barriers) and the triangular solve of its own tile against it.  The
+// diagonal tile's workgroup also carries the right-hand side (its gather doubles as the forward substitution).  The backward
+// substitution walks the levels in reverse, one workgroup per column.
 // Every sum has a fixed order: the solve is reproducible bit for bit like the rest of the path.
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
 
 #include "ba_mfma.hpp"
 
 namespace cubahip
 {
 
-constexpr int CH_T = 32;       // tile edge
-constexpr int CH_P = 128;      // panel width = macro tile edge
-constexpr int CH_PAD = 160;    // rows below the matrix (right-hand-side macro row + 32)
-
-size_t dense_cholesky_elems(int n, int* N, int* ld)
+// =====================================================================================================================================
+// symbolic phase (host)
+// =====================================================================================================================================
+namespace
 {
-	const int NN = (n + CH_P - 1) / CH_P * CH_P;
-	if (N) *N = NN;
-	if (ld) *ld = NN + CH_PAD;
-	return (size_t)(NN + CH_PAD) * NN;
+
+struct Elimination
+{
+	std::vector<int> order;                  // segment eliminated k-th
+	std::vector<std::vector<int>> nbrs;      // its neighbours (segments) at that moment = the rows of tile column k
+};
+
+// Minimum degree on an explicit bit-matrix of the elimination graph (T <= a few thousand segments: T^2 / 8 bytes), multiple elimination:
+// per round every segment whose degree is <= minimum + slack and that is not adjacent to a segment eliminated earlier in the round.
+void eliminate_min_degree(int T, const std::vector<uint64_t>& adj0, int W, int slack, Elimination& out)
+{
+	std::vector<uint64_t> adj(adj0), blocked((size_t)W);
+	std::vector<int> deg((size_t)T);
+	std::vector<uint8_t> alive((size_t)T, 1);
+	for (int v = 0; v < T; v++)
+	{
+		int d = 0;
+		for (int w = 0; w < W; w++) d += __builtin_popcountll(adj[(size_t)v * W + w]);
+		deg[v] = d;
+	}
+	out.order.clear(); out.nbrs.clear();
+	out.order.reserve(T); out.nbrs.reserve(T);
+	std::vector<int> nb;
+	int left = T;
+	while (left > 0)
+	{
+		int m = INT_MAX;
+		for (int v = 0; v < T; v++) if (alive[v]) m = std::min(m, deg[v]);
+		std::fill(blocked.begin(), blocked.end(), 0);
+		for (int v = 0; v < T; v++)
+		{
+			if (!alive[v] || deg[v] > m + slack || ((blocked[v >> 6] >> (v & 63)) & 1)) continue;
+			const uint64_t* rv = &adj[(size_t)v * W];
+			nb.clear();
+			for (int w = 0; w < W; w++)
+				for (uint64_t x = rv[w]; x; x &= x - 1) nb.push_back(64 * w + __builtin_ctzll(x));
+			out.order.push_back(v); out.nbrs.push_back(nb);
+			alive[v] = 0; left--;
+			for (int w = 0; w < W; w++) blocked[w] |= rv[w];
+			for (int u : nb)
+			{
+				uint64_t* ru = &adj[(size_t)u * W];
+				for (int w = 0; w < W; w++) ru[w] |= rv[w];
+				ru[u >> 6] &= ~(1ULL << (u & 63));
+				ru[v >> 6] &= ~(1ULL << (v & 63));
+				int d = 0;
+				for (int w = 0; w < W; w++) d += __builtin_popcountll(ru[w]);
+				deg[u] = d;
+			}
+		}
+	}
 }
 
-// upper-triangular BSR (damped, diagonal blocks full) -> lower triangle of the dense matrix
-__global__ __launch_bounds__(256) void dense_fill_kernel(DeviceStructure st, DeviceSystem sys, DenseCholesky d)
+// tile (row position r, column position c) in column c's sorted row list; -1 if it is not part of the factor's pattern
+inline int find_tile(const SparseCholPlan& p, int r, int c)
+{
+	const int* b = p.rowIdx.data() + p.colPtr[c] + 1;
+	const int* e = p.rowIdx.data() + p.colPtr[c + 1];
+	const int* it = std::lower_bound(b, e, r);
+	return it != e && *it == r ? (int)(it - p.rowIdx.data()) : -1;
+}
+
+bool build_plan(int Pf, const int* rowptr, const int* colind, const Elimination& el, int slack, size_t maxTiles, SparseCholPlan& p)
+{
+	const int T = (int)el.order.size();
+	p = SparseCholPlan();
+	p.Pf = Pf; p.T = T; p.slack = slack;
+	p.segOfPos = el.order;
+	p.posOfSeg.assign(T, 0);
+	for (int k = 0; k < T; k++) p.posOfSeg[el.order[k]] = k;
+	p.colPtr.assign((size_t)T + 1, 0);
+	size_t nTiles = 0;
+	for (int k = 0; k < T; k++) { p.colPtr[k] = (int)nTiles; nTiles += 1 + el.nbrs[k].size(); if (nTiles > maxTiles) return false; }
+	p.colPtr[T] = (int)nTiles; p.nTiles = (int)nTiles;
+	p.rowIdx.resize(nTiles); p.colOfTile.resize(nTiles);
+	for (int k = 0; k < T; k++)
+	{
+		int* r = p.rowIdx.data() + p.colPtr[k];
+		r[0] = k;
+		for (size_t a = 0; a < el.nbrs[k].size(); a++) r[1 + a] = p.posOfSeg[el.nbrs[k][a]];
+		std::sort(r + 1, r + 1 + el.nbrs[k].size());
+		for (int t = p.colPtr[k]; t < p.colPtr[k + 1]; t++) p.colOfTile[t] = k;
+	}
+	// row lists: the finished columns k < j that reach row j, ascending, with the tile (j, k); levels of the elimination tree
+	std::vector<int> rowCnt((size_t)T + 1, 0);
+	for (int k = 0; k < T; k++)
+		for (int t = p.colPtr[k] + 1; t < p.colPtr[k + 1]; t++) rowCnt[p.rowIdx[t] + 1]++;
+	for (int j = 0; j < T; j++) rowCnt[j + 1] += rowCnt[j];
+	std::vector<int> rowTile((size_t)rowCnt[T]), fillPos(rowCnt.begin(), rowCnt.end() - 1);
+	for (int k = 0; k < T; k++)
+		for (int t = p.colPtr[k] + 1; t < p.colPtr[k + 1]; t++) rowTile[fillPos[p.rowIdx[t]]++] = t;
+	std::vector<int> level((size_t)T, 0);
+	int nLevels = T > 0 ? 1 : 0;
+	for (int j = 0; j < T; j++)
+	{
+		int l = 0;
+		for (int e = rowCnt[j]; e < rowCnt[j + 1]; e++) l = std::max(l, level[p.colOfTile[rowTile[e]]] + 1);
+		level[j] = l; nLevels = std::max(nLevels, l + 1);
+	}
+	p.nLevels = nLevels;
+	// gather lists
+	const int zeroTile = p.nTiles;
+	p.gPtr.assign(nTiles + 1, 0);
+	size_t total = 0;
+	for (int j = 0; j < T; j++)
+	{
+		const size_t len = ((size_t)(rowCnt[j + 1] - rowCnt[j]) + 1) & ~(size_t)1;       // (even: the kernel takes two entries per trip)
+		for (int t = p.colPtr[j]; t < p.colPtr[j + 1]; t++) { p.gPtr[t] = (int)total; total += len; }
+		if (total > ((size_t)1 << 29)) return false;
+	}
+	p.gPtr[nTiles] = (int)total;
+	p.gather.assign(4 * total, 0);
+	p.entries = 0;
+	for (int j = 0; j < T; j++)
+		for (int t = p.colPtr[j]; t < p.colPtr[j + 1]; t++)
+		{
+			int* g = p.gather.data() + 4 * (size_t)p.gPtr[t];
+			const int i = p.rowIdx[t];
+			int n = 0;
+			for (int e = rowCnt[j]; e < rowCnt[j + 1]; e++, n++)
+			{
+				const int tb = rowTile[e], k = p.colOfTile[tb];
+				const int ta = i == j ? tb : find_tile(p, i, k);
+				g[4 * n] = ta >= 0 ? ta : zeroTile; g[4 * n + 1] = tb; g[4 * n + 2] = k; g[4 * n + 3] = 0;
+				p.entries += ta >= 0 ? 2 : 1;
+			}
+			for (; n < p.gPtr[t + 1] - p.gPtr[t]; n++) { g[4 * n] = zeroTile; g[4 * n + 1] = zeroTile; g[4 * n + 2] = 0; g[4 * n + 3] = 0; }
+		}
+	// work lists by level (stable: tiles / columns in ascending order inside a level)
+	p.lvlPtr.assign((size_t)nLevels + 1, 0); p.lvlColPtr.assign((size_t)nLevels + 1, 0);
+	for (int j = 0; j < T; j++) { p.lvlPtr[level[j] + 1] += p.colPtr[j + 1] - p.colPtr[j]; p.lvlColPtr[level[j] + 1]++; }
+	for (int l = 0; l < nLevels; l++) { p.lvlPtr[l + 1] += p.lvlPtr[l]; p.lvlColPtr[l + 1] += p.lvlColPtr[l]; }
+	p.lvlTiles.resize(nTiles); p.lvlCols.resize(T);
+	{
+		std::vector<int> a(p.lvlPtr.begin(), p.lvlPtr.end() - 1), b(p.lvlColPtr.begin(), p.lvlColPtr.end() - 1);
+		for (int j = 0; j < T; j++)
+		{
+			p.lvlCols[b[level[j]]++] = j;
+			for (int t = p.colPtr[j]; t < p.colPtr[j + 1]; t++) p.lvlTiles[a[level[j]]++] = t;
+		}
+	}
+	// destination of every block of the upper-triangular BSR storage
+	p.blkTile.resize(rowptr[Pf]);
+	for (int bi = 0; bi < Pf; bi++)
+		for (int b = rowptr[bi]; b < rowptr[bi + 1]; b++)
+		{
+			const int bj = colind[b];
+			const int pi = p.posOfSeg[bi / SC_TP], pj = p.posOfSeg[bj / SC_TP];
+			int tile, tr = 0;
+			if (pi == pj) tile = p.colPtr[pi];
+			else if (pj > pi) tile = find_tile(p, pj, pi);
+			else { tile = find_tile(p, pi, pj); tr = 1; }
+			if (tile < 0) return false;          // (cannot happen: the factor's pattern contains the matrix's)
+			p.blkTile[b] = tile | (tr << 30);
+		}
+	return true;
+}
+
+}  // namespace
+
+double SparseCholPlan::secondsEstimate() const
+{
+	// ~11 us per level of the factorisation + ~6 us per level of the backward substitution (dependent launches), the gathered tile
+	// products at the rate the memory-side cache feeds them, the fill
+	return 17e-6 * nLevels + (double)entries * 1.5 * sizeof(Scalar) * SC_TT / 2.5e12 + (double)nTiles * sizeof(Scalar) * SC_TT / 3e12 + 20e-6;
+}
+
+bool sparse_chol_plan(int Pf, const int* rowptr, const int* colind, int slack, size_t maxTiles, SparseCholPlan& out)
+{
+	const int T = (Pf + SC_TP - 1) / SC_TP;
+	if (T <= 0) { out = SparseCholPlan(); return true; }
+	const int W = (T + 63) / 64;
+	std::vector<uint64_t> adj((size_t)T * W, 0);
+	for (int bi = 0; bi < Pf; bi++)
+		for (int b = rowptr[bi]; b < rowptr[bi + 1]; b++)
+		{
+			const int a = bi / SC_TP, c = colind[b] / SC_TP;
+			if (a == c) continue;
+			adj[(size_t)a * W + (c >> 6)] |= 1ULL << (c & 63);
+			adj[(size_t)c * W + (a >> 6)] |= 1ULL << (a & 63);
+		}
+	Elimination el;
+	if (slack >= 0)
+	{
+		eliminate_min_degree(T, adj, W, slack, el);
+		return build_plan(Pf, rowptr, colind, el, slack, maxTiles, out);
+	}
+	// automatic: a larger slack trades fill for a shallower tree; the cost model picks (deterministic: a function of the pattern only)
+	bool have = false;
+	static const int candidates[] = { 0, 2, 4, 8 };
+	for (int s : candidates)
+	{
+		SparseCholPlan p;
+		eliminate_min_degree(T, adj, W, s, el);
+		if (!build_plan(Pf, rowptr, colind, el, s, maxTiles, p)) continue;
+		if (!have || p.secondsEstimate() < out.secondsEstimate()) { out = std::move(p); have = true; }
+	}
+	return have;
+}
+
+// =====================================================================================================================================
+// numeric phase (device)
+// =====================================================================================================================================
+
+// value of lane `lane` (a compile-time constant after unrolling) in every lane, through scalar registers
+__device__ __forceinline__ Scalar lane_bcast(Scalar v, int lane)
+{
+	union { Scalar s; int w[sizeof(Scalar) / 4]; } u;
+	u.s = v;
+#pragma unroll
+	for (int i = 0; i < (int)(sizeof(Scalar) / 4); i++) u.w[i] = __builtin_amdgcn_readlane(u.w[i], lane);
+	return u.s;
+}
+
+// a wave-uniform pivot is usable: positive, normal, finite -- decided on the scalar unit from the bits of its high word
+__device__ __forceinline__ bool pivot_ok(Scalar dj)
+{
+	union { Scalar s; int w[sizeof(Scalar) / 4]; } u;
+	u.s = dj;
+	const int hi = __builtin_amdgcn_readfirstlane(u.w[sizeof(Scalar) / 4 - 1]);
+	return sizeof(Scalar) == 8 ? (unsigned)(hi - 0x00100000) < 0x7fe00000u : (unsigned)(hi - 0x00800000) < 0x7f000000u;
+}
+
+// upper-triangular BSR (damped, diagonal blocks full) -> the tiles of the permuted matrix's lower triangle
+__global__ __launch_bounds__(256) void schol_fill_blocks_kernel(DeviceStructure st, DeviceSystem sys, SparseChol d)
 {
 	const int b = blockIdx.x * 4 + (threadIdx.x >> 6), e = threadIdx.x & 63;
 	if (b >= st.nblk || e >= 36) return;
 	const int bi = st.hsc_blkrow[b], bj = st.hsc_colind[b];        // bi <= bj; element (r, c) of the 6 x 6 block, column-major
 	const int r = e % 6, c = e / 6;
-	const int row = 6 * bj + c, col = 6 * bi + r;                  // its mirror image below the diagonal
-	if (row >= col) d.A[(size_t)col * d.ld + row] = sys.hsc[36 * (size_t)b + e];
+	if (bi == bj && c < r) return;                                 // a diagonal block: one triangle
+	const int tt = d.blkTile[b], tile = tt & 0x3fffffff;
+	const int li = 6 * (bi % SC_TP) + r, lj = 6 * (bj % SC_TP) + c;
+	const int row = (tt >> 30) ? li : lj, col = (tt >> 30) ? lj : li;
+	d.tiles[(size_t)SC_TT * tile + col * SC_T + row] = sys.hsc[36 * (size_t)b + e];
 }
 
-__global__ __launch_bounds__(256) void dense_fill_rhs_kernel(const Scalar* __restrict__ b, DenseCholesky d)
+// right-hand side into elimination order; identity on the padded unknowns
+__global__ __launch_bounds__(256) void schol_fill_rhs_kernel(const Scalar* __restrict__ b, SparseChol d)
 {
-	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= d.N) return;
-	d.A[(size_t)j * d.ld + d.N] = j < d.n ? b[j] : Scalar(0);
-	if (j >= d.n) d.A[(size_t)j * d.ld + j] = Scalar(1);
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int seg = idx >> 5, i = idx & 31;
+	if (seg >= d.T) return;
+	const int k = d.posOfSeg[seg];
+	const int p = SC_TP * seg + i / 6;
+	const bool valid = i < 6 * SC_TP && p < d.Pf;
+	d.y[SC_T * (size_t)k + i] = valid ? b[6 * (size_t)p + i % 6] : Scalar(0);
+	if (!valid) d.tiles[(size_t)SC_TT * d.colPtr[k] + i * SC_T + i] = Scalar(1);
 }
 
-void launch_dense_fill(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const DenseCholesky& d, hipStream_t s)
+void launch_sparse_chol_fill(const DeviceStructure& st, const DeviceSystem& sys, const SparseChol& d, hipStream_t s)
 {
-	(void)g;
-	(void)hipMemsetAsync(d.A, 0, sizeof(Scalar) * (size_t)d.ld * d.N, s);
-	if (st.nblk) hipLaunchKernelGGL(dense_fill_kernel, dim3((st.nblk + 3) / 4), dim3(256), 0, s, st, sys, d);
-	hipLaunchKernelGGL(dense_fill_rhs_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, sys.bsc, d);
+	(void)hipMemsetAsync(d.tiles, 0, sizeof(Scalar) * (size_t)SC_TT * ((size_t)d.nTiles + 1), s);
+	if (st.nblk) hipLaunchKernelGGL(schol_fill_blocks_kernel, dim3((st.nblk + 3) / 4), dim3(256), 0, s, st, sys, d);
+	hipLaunchKernelGGL(schol_fill_rhs_kernel, dim3((SC_T * d.T + 255) / 256), dim3(256), 0, s, sys.bsc, d);
 	(void)hipMemsetAsync(d.fail, 0, sizeof(int), s);
 }
 
-// Tile column k: every workgroup factorises the diagonal tile for itself (the chain is latency, not work: doing it once and handing it
-// over would cost a launch boundary per tile column) and applies L_kk^-T to ITS tile (i, k), i = k + 1 + blockIdx.x (the last one is the
-// right-hand side's tile).  The diagonal tile itself stays as it was in the matrix -- nobody reads it again; workgroup 0 stores
-// X_k = L_kk^-1 (row-major) for the backward substitution and raises the failure flag on a non-positive pivot (the factorisation then
-// carries on with pivot 1 so that nothing downstream sees a NaN; the solve is reported as failed).
-__global__ __launch_bounds__(256) void chol_panel_kernel(DenseCholesky d, int k)
+// eight k-steps of a 16-row slab of a column-major tile, in the matrix-core operand layout: element (row0 + (lane & 15), 4 s + (lane >> 4))
+__device__ __forceinline__ void load_slab(const Scalar* __restrict__ tile, int rowOff, Scalar out[8])
 {
-	__shared__ Scalar Tm[CH_T][CH_T + 1];
-	__shared__ Scalar Xs[CH_T][CH_T + 1];
-	__shared__ Scalar F[CH_T][CH_T + 1];
-	__shared__ Scalar rdiag[CH_T];
-	const int tid = threadIdx.x, r = tid & 31, cb = tid >> 5;
-	const size_t ld = d.ld;
-	const int i = k + 1 + blockIdx.x;
-	const Scalar* Akk = d.A + (size_t)(k * CH_T) * ld + (size_t)k * CH_T;
-	Scalar* Aik = d.A + (size_t)(k * CH_T) * ld + (size_t)i * CH_T;
-	Scalar own[4], fv[4];
 #pragma unroll
-	for (int u = 0; u < 4; u++)
-	{
-		own[u] = Akk[(size_t)(cb + 8 * u) * ld + r];
-		fv[u] = Aik[(size_t)(cb + 8 * u) * ld + r];
-	}
-#pragma unroll
-	for (int u = 0; u < 4; u++) { Tm[r][cb + 8 * u] = own[u]; F[r][cb + 8 * u] = fv[u]; }
-	__syncthreads();
-	// Unscaled right-looking elimination, 32 dependent steps with one barrier each: after step j the columns <= j + 1 of Tm are final,
-	// T[r][c] = L[r][c] L[c][c].  The same row operations -- row r -= (T[r][j] / T[j][j]) row j -- applied to the identity beside it give
-	// M = (unit-lower factor)^-1, so X = L^-1 = diag(T)^-1/2 M comes out of the SAME sweep.  (Measured against a second sweep of 32 steps
-	// for the triangular inversion: the same 19 us per tile column -- a step is bound by its LDS operations, ten reads and five writes here,
-	// not by its barrier --, so the one-sweep form is kept for being shorter, not faster: profiles/r05n_exact_solve_times.txt.)
-	// Thread (r, cb) keeps its four elements (r, cb + 8u) of T and of M in registers and publishes column j + 1 of T and row j + 1 of M
-	// for the next step.
-	Scalar mm[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++) { mm[u] = r == cb + 8 * u ? Scalar(1) : Scalar(0); Xs[r][cb + 8 * u] = mm[u]; }
-	__syncthreads();
-	bool bad = false;
-#pragma unroll
-	for (int j = 0; j < CH_T; j++)
-	{
-		Scalar dj = Tm[j][j];
-		if (!(dj > Scalar(0))) { bad = true; dj = Scalar(1); }
-		const Scalar lr = r > j ? Tm[r][j] * fast_rcp(dj) : Scalar(0);
-#pragma unroll
-		for (int u = 0; u < 4; u++)
-		{
-			const int c = cb + 8 * u;
-			if (c > j && r >= c) own[u] -= lr * Tm[c][j];
-			if (c <= j) mm[u] -= lr * Xs[j][c];                 // (row j of M is final: rows below it change)
-			if (c == j + 1) Tm[r][c] = own[u];
-		}
-		if (r == j + 1)
-		{
-#pragma unroll
-			for (int u = 0; u < 4; u++) Xs[r][cb + 8 * u] = mm[u];
-		}
-		__syncthreads();
-	}
-	if (tid < CH_T)
-	{
-		const Scalar dd = Tm[tid][tid];
-		rdiag[tid] = dd > Scalar(0) ? Scalar(1) / sqrt(dd) : Scalar(1);
-	}
-	__syncthreads();
-	{
-		const Scalar rd = rdiag[r];
-#pragma unroll
-		for (int u = 0; u < 4; u++) Xs[r][cb + 8 * u] = cb + 8 * u <= r ? mm[u] * rd : Scalar(0);       // X = L^-1, zero above the diagonal
-	}
-	__syncthreads();
-	// own tile: Out[r][c] = sum_m F[r][m] X[c][m] on the matrix cores (wave w owns the 16 x 16 output tile (w >> 1, w & 1))
-	const int wv = tid >> 6, lane = tid & 63, wi = wv >> 1, wj = wv & 1;
-	MfmaAcc o = mfma_zero();
-#pragma unroll
-	for (int s4 = 0; s4 < CH_T; s4 += 4)
-		o = mfma_16x16x4(F[16 * wi + (lane & 15)][s4 + (lane >> 4)], Xs[16 * wj + (lane & 15)][s4 + (lane >> 4)], o);
-	__syncthreads();
-#pragma unroll
-	for (int q = 0; q < 4; q++) F[16 * wi + mfma_row(lane, q)][16 * wj + (lane & 15)] = mfma_get(o, q);
-	__syncthreads();
-#pragma unroll
-	for (int u = 0; u < 4; u++) Aik[(size_t)(cb + 8 * u) * ld + r] = F[r][cb + 8 * u];
-	if (blockIdx.x == 0)
-	{
-		Scalar* X = d.invL + (size_t)k * CH_T * CH_T;
-#pragma unroll
-		for (int u = 0; u < 4; u++) X[(cb + 8 * u) * CH_T + r] = Xs[cb + 8 * u][r];
-		if (bad && tid == 0) *d.fail = 1;
-	}
+	for (int s = 0; s < 8; s++) out[s] = tile[128 * s + rowOff];
 }
 
-// A_ij -= A_ik A_jk^T for the tile columns j = j0t + blockIdx.y of the panel that are still to be factorised, i = j + blockIdx.x
-__global__ __launch_bounds__(256) void chol_upd32_kernel(DenseCholesky d, int k, int j0t, int Tr)
+// One level of the elimination tree: workgroup = one tile (i, j) of a column j of the level.
+//   phase 1 (four waves, one 16 x 16 quadrant each, transposed products so that a lane ends up with consecutive ROWS of a column):
+//            D = A_jj - sum_k L_jk L_jk^T,  F = A_ij - sum_k L_ik L_jk^T;  the diagonal tile's workgroup instead: v = sum_k L_jk y_k
+//   phase 2  D, F (or w = b_j - v) -> LDS
+//   phase 3 (wave 0, lane = row): unscaled elimination of D in registers -- T_rc = L_rc L_cc --, then
+//            off-diagonal tile:  L_ij = F L_jj^-T (row-wise triangular solve against the registers), stored plain and transposed
+//            diagonal tile:      y_j = L_jj^-1 w, L_jj (mirrored into both triangles, in the diagonal tile's slot of tilesT) and 1 / L_cc stored; failure flag on a non-positive
+//                                pivot (the factorisation carries on with pivot 1 so that nothing downstream sees a NaN)
+__global__ __launch_bounds__(256) void schol_factor_level_kernel(SparseChol d, int first)
 {
-	__shared__ Scalar F[CH_T][CH_T + 1];
-	__shared__ Scalar G[CH_T][CH_T + 1];
-	const int j = j0t + blockIdx.y, i = j + blockIdx.x;
-	if (i > Tr) return;
-	const int tid = threadIdx.x, r = tid & 31, cb = tid >> 5;
-	const size_t ld = d.ld;
-	const Scalar* Aik = d.A + (size_t)(k * CH_T) * ld + (size_t)i * CH_T;
-	const Scalar* Ajk = d.A + (size_t)(k * CH_T) * ld + (size_t)j * CH_T;
-	Scalar* Aij = d.A + (size_t)(j * CH_T) * ld + (size_t)i * CH_T;
-	Scalar fv[4], gv[4], sv[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++)
-	{
-		const size_t off = (size_t)(cb + 8 * u) * ld + r;
-		fv[u] = Aik[off]; gv[u] = Ajk[off]; sv[u] = Aij[off];
-	}
-#pragma unroll
-	for (int u = 0; u < 4; u++) { F[r][cb + 8 * u] = fv[u]; G[r][cb + 8 * u] = gv[u]; }
-	__syncthreads();
-	const int wv = tid >> 6, lane = tid & 63, wi = wv >> 1, wj = wv & 1;
-	MfmaAcc o = mfma_zero();
-#pragma unroll
-	for (int s4 = 0; s4 < CH_T; s4 += 4)
-		o = mfma_16x16x4(F[16 * wi + (lane & 15)][s4 + (lane >> 4)], G[16 * wj + (lane & 15)][s4 + (lane >> 4)], o);
-	__syncthreads();
-#pragma unroll
-	for (int q = 0; q < 4; q++) F[16 * wi + mfma_row(lane, q)][16 * wj + (lane & 15)] = mfma_get(o, q);
-	__syncthreads();
-#pragma unroll
-	for (int u = 0; u < 4; u++) Aij[(size_t)(cb + 8 * u) * ld + r] = sv[u] - F[r][cb + 8 * u];
-}
-
-// Trailing update of one panel: C_IJ -= W_I W_J^T, W = the panel's 128 columns (in place), one 128 x 128 macro tile per workgroup,
-// I >= J (2-D grid, the workgroups above the diagonal return at once; I = N / 128 is the right-hand side's macro row).  Four waves in
-// a 2 x 2 arrangement, 64 x 64 outputs = 4 x 4 matrix-core tiles each; the panel operands go through LDS in chunks of 16 columns,
-// double-buffered (the next chunk's global loads are in flight while the matrix cores work on this one).  The products are formed
-// transposed -- the instruction's "A" operand is the COLUMN-side panel -- so that a lane ends up with 16 consecutive rows of a
-// column across its half-row of lanes: the read-modify-write of C is 128-byte segments, no LDS transposition.
-constexpr int TR_KC = 16;
-constexpr int TR_LD = CH_P + 16;
-typedef Scalar Scalar2 __attribute__((ext_vector_type(2)));
-
-__global__ __launch_bounds__(256, 2) void chol_trail_kernel(DenseCholesky d, int c0, int Jfirst)
-{
-	const int J = Jfirst + blockIdx.x, I = Jfirst + blockIdx.y;
-	if (I < J) return;
-	__shared__ __attribute__((aligned(16))) Scalar sA[2][TR_KC][TR_LD];      // row-side operand (macro row I)
-	__shared__ __attribute__((aligned(16))) Scalar sB[2][TR_KC][TR_LD];      // column-side operand (macro row J)
+	__shared__ Scalar Ds[SC_T][SC_T + 1];
+	__shared__ Scalar Fs[SC_T][SC_T + 1];
+	__shared__ Scalar ws[SC_T];
+	__shared__ Scalar pivS[2 * SC_T];
+	const int t = d.lvlTiles[first + blockIdx.x];
+	const int j = d.colOfTile[t], t0 = d.colPtr[j];
+	const bool diag = t == t0;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wi = wv >> 1, wj = wv & 1;
-	const size_t ld = d.ld;
-	const Scalar* pA = d.A + (size_t)c0 * ld + (size_t)I * CH_P + 2 * lane;
-	const Scalar* pB = d.A + (size_t)c0 * ld + (size_t)J * CH_P + 2 * lane;
-	Scalar2 ra[4], rb[4];
-#pragma unroll
-	for (int p = 0; p < 4; p++)
+	const int off = (lane >> 4) * SC_T + (lane & 15);
+	const int offI = 16 * wi + off, offJ = 16 * wj + off;
+	MfmaAcc aD = mfma_zero(), aF = mfma_zero();
+	const int g0 = d.gPtr[t], g1 = d.gPtr[t + 1];
+	const int4* __restrict__ G = reinterpret_cast<const int4*>(d.gather);
+	if (diag)
 	{
-		const size_t off = (size_t)(4 * p + wv) * ld;
-		ra[p] = *(const Scalar2*)(pA + off);
-		rb[p] = *(const Scalar2*)(pB + off);
-	}
-#pragma unroll
-	for (int p = 0; p < 4; p++)
-	{
-		*(Scalar2*)&sA[0][4 * p + wv][2 * lane] = ra[p];
-		*(Scalar2*)&sB[0][4 * p + wv][2 * lane] = rb[p];
-	}
-	__syncthreads();
-	MfmaAcc acc[4][4];
-#pragma unroll
-	for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-		for (int nj = 0; nj < 4; nj++) acc[mi][nj] = mfma_zero();
-	constexpr int NCH = CH_P / TR_KC;
-#pragma unroll 1
-	for (int ch = 0; ch < NCH; ch++)
-	{
-		const int buf = ch & 1;
-		if (ch + 1 < NCH)
+		const bool yl = wj == 0 && (lane & 15) == 0;
+		for (int e = g0; e < g1; e += 2)
 		{
+			const int4 ea = G[e], eb = G[e + 1];
+			const Scalar* La = d.tiles + (size_t)SC_TT * ea.y;
+			const Scalar* Lb = d.tiles + (size_t)SC_TT * eb.y;
+			Scalar ra[8], ca[8], ya[8], rb[8], cb[8], yb[8];
+			load_slab(La, offI, ra); load_slab(La, offJ, ca);
+			load_slab(Lb, offI, rb); load_slab(Lb, offJ, cb);
 #pragma unroll
-			for (int p = 0; p < 4; p++)
+			for (int s = 0; s < 8; s++)
 			{
-				const size_t off = (size_t)((ch + 1) * TR_KC + 4 * p + wv) * ld;
-				ra[p] = *(const Scalar2*)(pA + off);
-				rb[p] = *(const Scalar2*)(pB + off);
-			}
-		}
-#pragma unroll
-		for (int ks = 0; ks < TR_KC / 4; ks++)
-		{
-			const int kk = 4 * ks + (lane >> 4);
-			Scalar a[4], b[4];
-#pragma unroll
-			for (int t = 0; t < 4; t++)
-			{
-				a[t] = sB[buf][kk][64 * wj + 16 * t + (lane & 15)];
-				b[t] = sA[buf][kk][64 * wi + 16 * t + (lane & 15)];
+				ya[s] = yl ? d.y[SC_T * (size_t)ea.z + 4 * s + (lane >> 4)] : Scalar(0);
+				yb[s] = yl ? d.y[SC_T * (size_t)eb.z + 4 * s + (lane >> 4)] : Scalar(0);
 			}
 #pragma unroll
-			for (int mi = 0; mi < 4; mi++)
+			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(ca[s], ra[s], aD); aF = mfma_16x16x4(ya[s], ra[s], aF); }
 #pragma unroll
-				for (int nj = 0; nj < 4; nj++) acc[mi][nj] = mfma_16x16x4(a[nj], b[mi], acc[mi][nj]);
+			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(cb[s], rb[s], aD); aF = mfma_16x16x4(yb[s], rb[s], aF); }
 		}
-		if (ch + 1 < NCH)
-		{
-#pragma unroll
-			for (int p = 0; p < 4; p++)
-			{
-				*(Scalar2*)&sA[buf ^ 1][4 * p + wv][2 * lane] = ra[p];
-				*(Scalar2*)&sB[buf ^ 1][4 * p + wv][2 * lane] = rb[p];
-			}
-		}
-		__syncthreads();
 	}
-	// lane l holds C[row = 16 mi + (l & 15)][column = 16 nj + mfma_row(l, q)] of its wave's 64 x 64 piece
-	Scalar* C = d.A + (size_t)(J * CH_P + 64 * wj) * ld + (size_t)I * CH_P + 64 * wi + (lane & 15);
+	else
+	{
+		for (int e = g0; e < g1; e += 2)
+		{
+			const int4 ea = G[e], eb = G[e + 1];
+			const Scalar* La = d.tiles + (size_t)SC_TT * ea.y;
+			const Scalar* Lb = d.tiles + (size_t)SC_TT * eb.y;
+			const Scalar* Ia = d.tiles + (size_t)SC_TT * ea.x;
+			const Scalar* Ib = d.tiles + (size_t)SC_TT * eb.x;
+			Scalar ra[8], ca[8], fa[8], rb[8], cb[8], fb[8];
+			load_slab(La, offI, ra); load_slab(La, offJ, ca); load_slab(Ia, offI, fa);
+			load_slab(Lb, offI, rb); load_slab(Lb, offJ, cb); load_slab(Ib, offI, fb);
 #pragma unroll
-	for (int nj = 0; nj < 4; nj++)
+			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(ca[s], ra[s], aD); aF = mfma_16x16x4(ca[s], fa[s], aF); }
+#pragma unroll
+			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(cb[s], rb[s], aD); aF = mfma_16x16x4(cb[s], fb[s], aF); }
+		}
+	}
+	// lane l holds element (row 16 wi + (l & 15), column 16 wj + mfma_row(l, q)) of its wave's quadrant
+	{
+		const Scalar* A0 = d.tiles + (size_t)SC_TT * t0;
+		const Scalar* At = d.tiles + (size_t)SC_TT * t;
+		const int row = 16 * wi + (lane & 15);
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 		{
-			Scalar* col = C + (size_t)(16 * nj + mfma_row(lane, q)) * ld;
-			Scalar v[4];
-#pragma unroll
-			for (int mi = 0; mi < 4; mi++) v[mi] = col[16 * mi];
-#pragma unroll
-			for (int mi = 0; mi < 4; mi++) col[16 * mi] = v[mi] - mfma_get(acc[mi][nj], q);
+			const int col = 16 * wj + mfma_row(lane, q);
+			Ds[row][col] = A0[col * SC_T + row] - mfma_get(aD, q);
+			if (!diag) Fs[row][col] = At[col * SC_T + row] - mfma_get(aF, q);
 		}
-}
-
-__global__ __launch_bounds__(256) void chol_extract_y_kernel(DenseCholesky d)
-{
-	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j < d.N) d.y[j] = d.A[(size_t)j * d.ld + d.N];
-}
-
-// Backward substitution, tile column k (k = T-1 .. 0, one launch each): every workgroup forms x_k = X_k^T y_k for itself (y_k is final:
-// all launches k' > k have subtracted their share), workgroup j < k then subtracts L_kj^T x_k from y_j; workgroup 0 stores x_k.
-__global__ __launch_bounds__(256) void chol_back_kernel(DenseCholesky d, int k, Scalar* __restrict__ x)
-{
-	__shared__ Scalar red[8][CH_T + 1];
-	__shared__ Scalar xk[CH_T];
-	__shared__ Scalar P[CH_T][CH_T + 1];
-	const int tid = threadIdx.x, r = tid & 31, cb = tid >> 5;
-	const size_t ld = d.ld;
-	const int j = blockIdx.x;
-	const bool upd = j < k;
-	const Scalar* Lkj = d.A + (size_t)(j * CH_T) * ld + (size_t)k * CH_T;
-	Scalar lv[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++) lv[u] = upd ? Lkj[(size_t)(cb + 8 * u) * ld + r] : Scalar(0);
-	const Scalar* X = d.invL + (size_t)k * CH_T * CH_T;          // X[row][column], row-major
-	Scalar part = 0;
-#pragma unroll
-	for (int u = 0; u < 4; u++) part += X[(4 * cb + u) * CH_T + r] * d.y[k * CH_T + 4 * cb + u];
-	red[cb][r] = part;
-	__syncthreads();
-	if (tid < CH_T)
-	{
-		const Scalar s = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
-		xk[tid] = s;
-		if (blockIdx.x == 0 && k * CH_T + tid < d.n) x[k * CH_T + tid] = s;
+		if (diag && wj == 0 && lane < 16) ws[row] = d.y[SC_T * (size_t)j + row] - mfma_get(aF, 0);
 	}
 	__syncthreads();
-	if (!upd) return;
+	if (wv != 0) return;
+	const int r = lane & 31;
+	Scalar T[SC_T];
 #pragma unroll
-	for (int u = 0; u < 4; u++) P[cb + 8 * u][r] = lv[u] * xk[r];
-	__syncthreads();
-	if (tid < CH_T)
+	for (int c = 0; c < SC_T; c++) T[c] = Ds[r][c];
+	// (pivot k and its reciprocal are wave-uniform: they reach the lane that owns row k through LDS -- every lane stores the same number
+	// -- instead of through 32 compare masks; positivity is tested on the scalar unit)
+	int bad = 0;
+#pragma unroll
+	for (int jj = 0; jj < SC_T; jj++)
 	{
-		Scalar s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+		Scalar dj = lane_bcast(T[jj], jj);
+		if (!pivot_ok(dj)) { bad = 1; dj = Scalar(1); }
+		const Scalar rj = fast_rcp(dj);
+		pivS[jj] = dj; pivS[SC_T + jj] = rj;
+		const Scalar lr = T[jj] * rj;
 #pragma unroll
-		for (int m = 0; m < CH_T; m += 4) { s0 += P[tid][m]; s1 += P[tid][m + 1]; s2 += P[tid][m + 2]; s3 += P[tid][m + 3]; }
-		d.y[j * CH_T + tid] -= (s0 + s1) + (s2 + s3);
+		for (int c = jj + 1; c < SC_T; c++) T[c] -= lr * lane_bcast(T[jj], c);
 	}
-}
-
-void launch_dense_cholesky_solve(const DenseCholesky& d, Scalar* x, hipStream_t s)
-{
-	const int T = d.N / CH_T, NM = d.N / CH_P, Tr = T;       // Tr: the right-hand side's tile row
-	for (int p = 0; p < NM; p++)
+	const Scalar sv = Scalar(1) / sqrt(pivS[r]);       // 1 / L_rr
+	const Scalar rjv = pivS[SC_T + r];                 // 1 / T_rr
+	// (the solves below broadcast the same register / lane pairs as the elimination did: without this fence the compiler keeps all 496
+	// broadcast values alive in scalar registers across both loops and spills a thousand of them)
+#pragma unroll
+	for (int c = 0; c < SC_T; c++) asm volatile("" : "+v"(T[c]));
+	if (!diag)
 	{
-		for (int t = 0; t < CH_P / CH_T; t++)
+		Scalar a[SC_T];
+#pragma unroll
+		for (int c = 0; c < SC_T; c++) a[c] = Fs[r][c];
+#pragma unroll
+		for (int m = 0; m < SC_T; m++)
 		{
-			const int k = 4 * p + t;
-			hipLaunchKernelGGL(chol_panel_kernel, dim3(Tr - k), dim3(256), 0, s, d, k);
-			if (t < 3) hipLaunchKernelGGL(chol_upd32_kernel, dim3(Tr - k, 3 - t), dim3(256), 0, s, d, k, k + 1, Tr);
+			asm volatile("" : "+v"(T[m]), "+v"(a[m]));        // (keeps step m's broadcasts behind step m - 1: hoisted, they spill)
+			const Scalar z = a[m] * lane_bcast(rjv, m);
+#pragma unroll
+			for (int c = m + 1; c < SC_T; c++) a[c] -= z * lane_bcast(T[m], c);
 		}
-		const int m = NM - 1 - p;
-		if (m > 0) hipLaunchKernelGGL(chol_trail_kernel, dim3(m, m + 1), dim3(256), 0, s, d, CH_P * p, p + 1);
+#pragma unroll
+		for (int m = 0; m < SC_T; m++) a[m] *= lane_bcast(sv, m);
+		if (lane < SC_T)
+		{
+			Scalar* Lt = d.tiles + (size_t)SC_TT * t;
+			Scalar* Ltt = d.tilesT + (size_t)SC_TT * t;
+#pragma unroll
+			for (int c = 0; c < SC_T; c++) { Lt[c * SC_T + r] = a[c]; Ltt[r * SC_T + c] = a[c]; }
+		}
+		return;
 	}
-	hipLaunchKernelGGL(chol_extract_y_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d);
-	for (int k = T - 1; k >= 0; k--) hipLaunchKernelGGL(chol_back_kernel, dim3(k > 0 ? k : 1), dim3(256), 0, s, d, k, x);
+	// the diagonal tile's workgroup: forward substitution of the right-hand side, then L_jj itself
+	Scalar w = ws[r], yfin = Scalar(0);
+#pragma unroll
+	for (int m = 0; m < SC_T; m++)
+	{
+		const Scalar wm = lane_bcast(w, m);
+		const Scalar zm = wm * lane_bcast(rjv, m);
+		if (r == m) yfin = wm * sv;
+		if (r > m) w -= T[m] * zm;
+	}
+	if (lane < SC_T)
+	{
+		d.y[SC_T * (size_t)j + r] = yfin;
+		d.rinv[SC_T * (size_t)j + r] = sv;
+	}
+	// (into the transposed array's slot of the diagonal tile: the other workgroups of this column may still be reading A_jj)
+	Scalar* L0 = d.tilesT + (size_t)SC_TT * t0;
+#pragma unroll
+	for (int c = 0; c < SC_T; c++)
+	{
+		const Scalar v = T[c] * lane_bcast(sv, c);
+		if (lane < SC_T && c <= r) { L0[c * SC_T + r] = v; L0[r * SC_T + c] = v; }
+	}
+	if (bad != 0 && lane == 0) *d.fail = 1;
+}
+
+// One level of the backward substitution (levels in reverse): workgroup = one column j.
+//   v = sum over the column's off-diagonal tiles of L_ij^T x_i  (wave w takes tiles w, w + 4, ..; lane = (column c, row half): the
+//   transposed copy makes the loads of a row contiguous across the lanes), summed over halves and waves in a fixed order;
+//   x_j = L_jj^-T (y_j - v): 32 dependent steps in one wave, lane m holding column m of L_jj (= row m of the mirrored tile)
+__global__ __launch_bounds__(256) void schol_back_level_kernel(SparseChol d, int first)
+{
+	__shared__ Scalar part[4][2][SC_T];
+	const int j = d.lvlCols[first + blockIdx.x];
+	const int t0 = d.colPtr[j], s = d.colPtr[j + 1] - t0 - 1;
+	const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	Scalar acc = 0;
+	for (int a = wv; a < s; a += 4)
+	{
+		const int t = t0 + 1 + a;
+		const int i = d.rowIdx[t];
+		const Scalar* __restrict__ Lt = d.tilesT + (size_t)SC_TT * t + (16 * h) * SC_T + c;
+		const Scalar* __restrict__ xi = d.y + SC_T * (size_t)i + 16 * h;
+#pragma unroll
+		for (int rr = 0; rr < 16; rr++) acc += Lt[rr * SC_T] * xi[rr];
+	}
+	part[wv][h][c] = acc;
+	__syncthreads();
+	if (wv != 0) return;
+	const Scalar v = ((part[0][0][c] + part[0][1][c]) + (part[1][0][c] + part[1][1][c])) + ((part[2][0][c] + part[2][1][c]) + (part[3][0][c] + part[3][1][c]));
+	Scalar w = d.y[SC_T * (size_t)j + c] - v;
+	const Scalar sOwn = d.rinv[SC_T * (size_t)j + c];
+	const Scalar* __restrict__ L0 = d.tilesT + (size_t)SC_TT * t0 + c;
+	Scalar Lc[SC_T];
+#pragma unroll
+	for (int cc = 0; cc < SC_T; cc++) Lc[cc] = L0[cc * SC_T];          // element (row c, column cc) of the mirrored tile = L[cc][c] for cc >= c
+	Scalar xfin = 0;
+#pragma unroll
+	for (int cc = SC_T - 1; cc >= 0; cc--)
+	{
+		const Scalar xc = lane_bcast(w * sOwn, cc);
+		if (c == cc) xfin = xc;
+		if (c < cc) w -= Lc[cc] * xc;
+	}
+	if (lane < SC_T) d.y[SC_T * (size_t)j + c] = xfin;
+}
+
+__global__ __launch_bounds__(256) void schol_extract_kernel(SparseChol d, Scalar* __restrict__ x)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= 6 * d.Pf) return;
+	const int p = idx / 6, c = idx % 6;
+	x[idx] = d.y[SC_T * (size_t)d.posOfSeg[p / SC_TP] + 6 * (p % SC_TP) + c];
+}
+
+void launch_sparse_chol_solve(const SparseChol& d, const SparseCholPlan& plan, Scalar* x, hipStream_t s)
+{
+	for (int l = 0; l < plan.nLevels; l++)
+	{
+		const int n = plan.lvlPtr[l + 1] - plan.lvlPtr[l];
+		if (n > 0) hipLaunchKernelGGL(schol_factor_level_kernel, dim3(n), dim3(256), 0, s, d, plan.lvlPtr[l]);
+	}
+	for (int l = plan.nLevels - 1; l >= 0; l--)
+	{
+		const int n = plan.lvlColPtr[l + 1] - plan.lvlColPtr[l];
+		if (n > 0) hipLaunchKernelGGL(schol_back_level_kernel, dim3(n), dim3(256), 0, s, d, plan.lvlColPtr[l]);
+	}
+	if (d.Pf > 0) hipLaunchKernelGGL(schol_extract_kernel, dim3((6 * d.Pf + 255) / 256), dim3(256), 0, s, d, x);
 }
 
 }  // namespace cubahip

@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 #include "ba_math.hpp"
 
@@ -216,20 +217,50 @@ void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const De
 void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s,
 	const Scalar* copySrc = nullptr, Scalar* copyDst = nullptr, size_t copyCount = 0);
 
-// ---- exact reduced solve (ba_direct.hip): dense blocked Cholesky of the damped reduced matrix + triangular solves --------------
-struct DenseCholesky
+// ---- exact reduced solve (ba_direct.hip): sparse tile Cholesky of the damped reduced matrix + triangular solves -------------------
+// The free poses (internal order) are cut into segments of SC_TP consecutive poses = one 32 x 32 tile of the matrix (30 unknowns + 2
+// identity-padded ones).  A minimum-degree elimination of the segment graph (multiple elimination: independent segments of near-minimal
+// degree per round) gives the tile order, the fill and the elimination tree; columns of one tree LEVEL are independent, so the numeric
+// phase is one launch per level (left-looking: every tile gathers the updates of its descendants in a fixed order -- no atomics, results
+// reproducible bit for bit) and the two substitutions ride on the same levels.
+constexpr int SC_T = 32;          // tile edge
+constexpr int SC_TP = 5;          // poses per tile
+constexpr int SC_TT = SC_T * SC_T;
+
+struct SparseCholPlan             // host: the symbolic phase's result for one block pattern
 {
-	Scalar* A = nullptr;       // [(N + 160) x N] column-major: lower triangle of the matrix, the right-hand side in row N
-	Scalar* invL = nullptr;    // [N / 32][32 x 32] inverses of the diagonal tiles' Cholesky factors (row-major)
-	Scalar* y = nullptr;       // [N] work vector of the backward substitution
-	int* fail = nullptr;       // != 0 after the solve: a non-positive pivot was met (the matrix is not positive definite)
-	int n = 0, N = 0, ld = 0;  // unknowns, unknowns rounded up to 128, column stride
+	int Pf = 0, T = 0, nTiles = 0, nLevels = 0, slack = 0;
+	std::vector<int> posOfSeg, segOfPos;     // segment <-> elimination position (= tile column)
+	std::vector<int> colPtr;                 // [T + 1] tiles of column k: the diagonal tile first, then its rows in ascending position
+	std::vector<int> rowIdx, colOfTile;      // [nTiles]
+	std::vector<int> gPtr;                   // [nTiles + 1] gather list of every tile ...
+	std::vector<int> gather;                 // ... 4 ints per entry {tile (i, k) or the zero tile, tile (j, k), k, 0}, k ascending, padded to an even count
+	std::vector<int> lvlPtr, lvlTiles;       // [nLevels + 1], [nTiles]: tiles by the level of their column (work list of the factorisation)
+	std::vector<int> lvlColPtr, lvlCols;     // [nLevels + 1], [T]: columns by level (work list of the backward substitution)
+	std::vector<int> blkTile;                // [nblk] destination tile of every block of the upper-triangular BSR storage (bit 30: transposed)
+	long long entries = 0;                   // gather entries (two tile products each at most)
+	size_t tileBytes() const { return sizeof(Scalar) * (size_t)SC_TT * ((size_t)2 * nTiles + 1); }
+	double secondsEstimate() const;          // what one factorisation + solve costs (a model: launches per level + tile traffic)
 };
-size_t dense_cholesky_elems(int n, int* N, int* ld);       // numbers in DenseCholesky::A for n unknowns
-// hsc (damped by launch_pcg_setup: full diagonal blocks) and bsc -> d.A; clears d.fail
-void launch_dense_fill(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const DenseCholesky& d, hipStream_t s);
-// factorise d.A in place and solve: x[0 .. n) = A^-1 b
-void launch_dense_cholesky_solve(const DenseCholesky& d, Scalar* x, hipStream_t s);
+// slack < 0: automatic (the cheapest of a few multiple-elimination slacks by secondsEstimate).  false: more than maxTiles tiles of fill
+bool sparse_chol_plan(int Pf, const int* rowptr, const int* colind, int slack, size_t maxTiles, SparseCholPlan& out);
+
+struct SparseChol                 // device view
+{
+	Scalar* tiles = nullptr;      // [nTiles + 1][32 x 32] column-major: the matrix; the off-diagonal tiles become L; the last tile stays zero
+	Scalar* tilesT = nullptr;     // [nTiles][32 x 32] the off-diagonal tiles of L once more, transposed (what the backward substitution reads); a diagonal
+	                              // tile's slot: L_jj mirrored into both triangles
+	Scalar* y = nullptr;          // [32 T] right-hand side -> L^-1 b -> solution, in elimination order
+	Scalar* rinv = nullptr;       // [32 T] 1 / L_cc
+	const int *colPtr = nullptr, *rowIdx = nullptr, *colOfTile = nullptr, *gPtr = nullptr, *gather = nullptr;
+	const int *lvlTiles = nullptr, *lvlCols = nullptr, *blkTile = nullptr, *posOfSeg = nullptr;
+	int* fail = nullptr;          // != 0 after the solve: a non-positive pivot was met (the matrix is not positive definite)
+	int T = 0, Pf = 0, nTiles = 0;
+};
+// hsc (damped by launch_pcg_setup: full diagonal blocks) and bsc -> d.tiles / d.y; clears d.fail
+void launch_sparse_chol_fill(const DeviceStructure& st, const DeviceSystem& sys, const SparseChol& d, hipStream_t s);
+// factorise and solve: x[0 .. 6 Pf) = A^-1 b (internal pose order)
+void launch_sparse_chol_solve(const SparseChol& d, const SparseCholPlan& plan, Scalar* x, hipStream_t s);
 
 // out3 = {chi2 total, landmark scale part, pose scale part} gathered from the result slots of the kernels enqueued before
 void launch_collect_eval(const DeviceSystem& sys, Scalar* out3, hipStream_t s);

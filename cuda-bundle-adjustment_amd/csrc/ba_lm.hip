@@ -264,56 +264,65 @@ bool cuba_hip_solver::solveReduced()
 	return ok2;
 }
 
-bool cuba_hip_solver::directUsable()
-{
-	return directFallback && !directRefused && Pf > 0 && 6LL * Pf <= (long long)directMaxUnknowns;
-}
-
-// PCG iterations a solve may use before it is handed to the exact solver: a THIRD of what one exact solve costs (measured on this
-// handle, or estimated: ~30 us of dependent launches per 32-column tile + n^3 / 3 flops at ~40 TFLOP/s -- KITTI-07 shape 1.5 ms,
-// KITTI-00 shape 11.7 ms).  A third, not the whole: within a run the damping shrinks and the iteration count grows from solve to solve
-// (x 1.3-2), so a solve at a third of the exact solver's cost announces solves beyond it; and the iteration count is the one measure of
-// the system's conditioning the PCG has -- pcg_tol bounds the residual, the error of the increment is up to cond(M^-1 Hsc) times larger,
-// and on the KITTI-00-size Tukey start of tests/test_ref_lm.py the solves of 370 and 800 iterations at the default tolerance are what
-// takes the run off the reference's (2.6e-5 on chi2 with them, 3e-9 when they go to the exact solver).
+// PCG iterations a solve may use before it is handed to the exact solver.  An exact solve costs what 50-60 iterations cost at every
+// size measured (a launch per level of the elimination tree); the hand-over waits for about twice that -- within a
+// run the damping shrinks and the iteration count grows from solve to solve (x 1.3-2), so a solve that needs this many announces solves
+// that need more; and the iteration count is the one measure of the system's conditioning the PCG has -- pcg_tol bounds the residual, the
+// error of the increment is up to cond(M^-1 Hsc) times larger (on the KITTI-00-size Tukey start of tests/test_ref_lm.py the solves of 370
+// and 800 iterations at the default tolerance are what takes the run off the reference's: 2.6e-5 on chi2 with them, 3e-9 when they go
+// to the exact solver).  A constant: the decision is a function of the call sequence alone, never of timing or of the memory that
+// happens to be free (every rank of a partitioned run hands over at the same iteration).
 int cuba_hip_solver::pcgBudget(int maxIter) const
 {
-	if (directAfter > 0) return std::min(maxIter, std::max(4, directAfter / 4 * 4));
-	const double n = 6.0 * Pf;
-	const double tDirect = directSeconds > 0 ? directSeconds : (n / 32) * 30e-6 + n * n * n / 3 / 40e12;
-	const double tIter = 10e-6 + 288.0 * (2.0 * st.nblk - Pf) / 3.5e12;
-	const double it = std::min((double)maxIter, std::max(128.0, tDirect / tIter / 3));
-	return std::max(4, (int)it / 4 * 4);
+	const int it = directAfter > 0 ? directAfter : 128;
+	return std::min(maxIter, std::max(4, it / 4 * 4));
+}
+
+bool cuba_hip_solver::ensureDirectPlan()
+{
+	if (directPlanValid) return !directRefused;
+	const auto t0 = Clock::now();
+	ensureHostPattern();
+	directPlanValid = true;
+	if (!sparse_chol_plan(Pf, h_rowptr.data(), h_colind.data(), directSlack, (size_t)std::max(1, directMaxTiles), directPlan))
+	{
+		directRefused = true;
+		char buf[200];
+		std::snprintf(buf, sizeof buf, "exact reduced solve unavailable: the factor of the %d-pose reduced matrix needs more than direct_max_tiles = %d tiles", Pf, directMaxTiles);
+		lastError = buf;
+		return false;
+	}
+	const SparseCholPlan& p = directPlan;
+	// all index arrays in one allocation, one copy
+	std::vector<int> ints;
+	auto put = [&](const std::vector<int>& v) { const size_t o = ints.size(); ints.insert(ints.end(), v.begin(), v.end()); while (ints.size() % 4) ints.push_back(0); return o; };
+	const size_t oColPtr = put(p.colPtr), oRowIdx = put(p.rowIdx), oColOf = put(p.colOfTile), oGPtr = put(p.gPtr), oGather = put(p.gather),
+		oLvlTiles = put(p.lvlTiles), oLvlCols = put(p.lvlCols), oBlkTile = put(p.blkTile), oPos = put(p.posOfSeg);
+	d_scInts.upload(ints, stream);
+	d_scTiles.resize((size_t)SC_TT * ((size_t)p.nTiles + 1)); d_scTilesT.resize((size_t)SC_TT * std::max(1, p.nTiles));
+	d_scY.resize((size_t)SC_T * p.T); d_scRinv.resize((size_t)SC_T * p.T); d_scFail.resize(1);
+	sync();                             // (`ints` leaves scope)
+	SparseChol& d = directDev;
+	d.tiles = d_scTiles.data(); d.tilesT = d_scTilesT.data(); d.y = d_scY.data(); d.rinv = d_scRinv.data(); d.fail = d_scFail.data();
+	const int* base = d_scInts.data();
+	d.colPtr = base + oColPtr; d.rowIdx = base + oRowIdx; d.colOfTile = base + oColOf; d.gPtr = base + oGPtr; d.gather = base + oGather;
+	d.lvlTiles = base + oLvlTiles; d.lvlCols = base + oLvlCols; d.blkTile = base + oBlkTile; d.posOfSeg = base + oPos;
+	d.T = p.T; d.Pf = Pf; d.nTiles = p.nTiles;
+	directPlanSeconds = std::chrono::duration<double>(Clock::now() - t0).count();
+	if (std::getenv("CUBA_HIP_DEBUG"))
+		std::fprintf(stderr, "[cuba_hip] exact reduced solve, symbolic phase: %d poses -> %d tile columns, %d tiles (%.1f MB), %d levels, %lld tile products, slack %d, %.2f ms\n",
+			Pf, p.T, p.nTiles, p.tileBytes() / 1e6, p.nLevels, p.entries, p.slack, 1e3 * directPlanSeconds);
+	return true;
 }
 
 bool cuba_hip_solver::solveDirect()
 {
-	int N = 0, ld = 0;
-	const size_t elems = dense_cholesky_elems(6 * Pf, &N, &ld);
-	if (d_dense.size() < elems)
-	{
-		size_t freeB = 0, totalB = 0;
-		const bool fits = hipMemGetInfo(&freeB, &totalB) == hipSuccess && elems * sizeof(Scalar) + ((size_t)1 << 30) <= freeB;
-		bool got = false;
-		if (fits) { try { d_dense.resize(elems); got = true; } catch (const HipError&) { (void)hipGetLastError(); } }
-		if (!got)
-		{
-			directRefused = true;
-			char buf[200];
-			std::snprintf(buf, sizeof buf, "exact reduced solve unavailable: %.1f GB for the dense matrix of %d unknowns do not fit the free device memory", elems * sizeof(Scalar) / 1e9, 6 * Pf);
-			lastError = buf;
-			return false;
-		}
-	}
-	d_denseInvL.resize((size_t)(N / 32) * 1024); d_denseY.resize(N); d_denseFail.resize(1);
+	if (!ensureDirectPlan()) return false;
 	const auto t0 = Clock::now();
-	DenseCholesky d;
-	d.A = d_dense.data(); d.invL = d_denseInvL.data(); d.y = d_denseY.data(); d.fail = d_denseFail.data();
-	d.n = 6 * Pf; d.N = N; d.ld = ld;
-	launch_dense_fill(g, st, sys, d, stream);
-	launch_dense_cholesky_solve(d, sys.xp, stream);
+	launch_sparse_chol_fill(st, sys, directDev, stream);
+	launch_sparse_chol_solve(directDev, directPlan, sys.xp, stream);
 	int* hflag = (int*)hostStage();
-	HIP_TRY(hipMemcpyAsync(hflag, d.fail, sizeof(int), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(hflag, directDev.fail, sizeof(int), hipMemcpyDeviceToHost, stream));
 	sync();
 	directSeconds = std::chrono::duration<double>(Clock::now() - t0).count();
 	cntDirect++;
@@ -342,16 +351,20 @@ bool cuba_hip_solver::solveReducedOnce()
 	if (failDirty) { d_fail.zero(stream); failDirty = false; }      // (the device flag only changes when a solve fails, and every solve reports it)
 	const bool twoLevel = sys.agg > 0;
 	const bool direct = directUsable();
-	if (direct && directSticky)
+	if (direct && (directSticky || directAlways))
 	{
-		// an earlier solve of this run needed the exact solver: this one goes there at once (the set-up launch damps the diagonal blocks)
+		// an earlier solve of this run needed the exact solver (or the caller wants every solve exact): this one goes there at once
+		// (the set-up launch damps the diagonal blocks; it may raise the device failure flag for a diagonal block that is not positive
+		// definite, which the next PCG solve must not inherit)
 		launch_pcg_setup(g, st, sys, lambda, stream);
+		failDirty = true;
 		coarseValid = false;
 		if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);
 		pcgHistory.push_back(0);
 		return solveDirect();
 	}
-	const int budget = direct ? pcgBudget(maxIter) : maxIter;     // iterations before the solve is handed to the exact solver
+	// iterations before the solve is handed to the exact solver (a caller who asked for the best iterate at max_iter gets max_iter)
+	const int budget = direct && !acceptUnconverged ? pcgBudget(maxIter) : maxIter;
 	// an inversion that ran on the second stream under the previous trial's PCG: its result moves into the buffer the iteration
 	// graphs read within the next launch
 	const size_t invCount = (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;

@@ -598,7 +598,7 @@ cuba_hip_solver::CoarseCfg cuba_hip_solver::coarseConfig() const
 
 void cuba_hip_solver::allocSystem(int nblk, const CoarseCfg& c)
 {
-	directRefused = false; directSticky = false; directSeconds = 0;      // (a new structure: the exact solver is sized and timed afresh)
+	directRefused = false; directSticky = false; directPlanValid = false;      // (a new structure: the exact solver analyses it afresh at its first use)
 	d_red.resize((size_t)36 * nblk + (size_t)12 * Pf);
 	d_lmSys.resize((size_t)9 * Lf); d_lmInv.resize((size_t)8 * std::max(Lf, 1)); d_erec.resize((size_t)8 * E); d_xp.resize((size_t)6 * Pf); d_xl.resize((size_t)3 * Lf);
 	d_minv.resize((size_t)36 * Pf);

@@ -135,7 +135,13 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		else if (k == "pcg_accept_unconverged") s->acceptUnconverged = value != 0;
 		else if (k == "direct_fallback") { s->directFallback = value != 0; s->directSticky = false; }
 		else if (k == "direct_after") s->directAfter = (int)value;
-		else if (k == "direct_max_unknowns") { s->directMaxUnknowns = (int)value; s->directRefused = false; }
+		else if (k == "direct_max_tiles") { s->directMaxTiles = (int)value; s->directRefused = false; s->directPlanValid = false; }
+		else if (k == "direct_slack") { s->directSlack = (int)value; s->directRefused = false; s->directPlanValid = false; }
+		else if (k == "reduced_solver")
+		{
+			if (value != 0 && value != 1) throw ArgError{ "reduced_solver: 0 = block PCG with the exact solver as fallback, 1 = exact sparse Cholesky for every solve" };
+			s->directAlways = value != 0;
+		}
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
 		else if (k == "device_lm_decision") s->deviceDecision = value != 0;
@@ -537,30 +543,53 @@ int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ain
 
 int cuba_hip_debug_dense_solve(int device, int n, const double* A, const double* b, double* x, int* not_positive_definite)
 {
+	return cuba_hip_debug_sparse_solve(device, n, A, b, x, not_positive_definite, -1, nullptr);
+}
+
+int cuba_hip_debug_sparse_solve(int device, int n, const double* A, const double* b, double* x, int* not_positive_definite, int slack, int32_t stats[4])
+{
 	if (n <= 0 || n % 6 != 0 || !A || !b || !x) return CUBA_HIP_ERR_INVALID_ARGUMENT;
 	if (hipSetDevice(device) != hipSuccess) return CUBA_HIP_ERR_NO_DEVICE;
 	try
 	{
-		// the matrix as the reduced system would hold it: every 6 x 6 block on or above the diagonal, one block per (row, column)
+		// the matrix as the reduced system would hold it: the 6 x 6 blocks on or above the diagonal that are not identically zero (the
+		// diagonal ones always), one block per (row, column)
 		const int P = n / 6;
-		std::vector<Scalar> blocks; std::vector<int> blkrow, colind;
+		std::vector<Scalar> blocks; std::vector<int> blkrow, colind, rowptr(1, 0);
 		for (int bi = 0; bi < P; bi++)
+		{
 			for (int bj = bi; bj < P; bj++)
 			{
+				bool any = bi == bj;
+				for (int c = 0; c < 6 && !any; c++) for (int r = 0; r < 6; r++) any = any || A[(size_t)(6 * bj + c) * n + 6 * bi + r] != 0.0;
+				if (!any) continue;
 				blkrow.push_back(bi); colind.push_back(bj);
 				for (int c = 0; c < 6; c++) for (int r = 0; r < 6; r++) blocks.push_back((Scalar)A[(size_t)(6 * bj + c) * n + 6 * bi + r]);
 			}
+			rowptr.push_back((int)colind.size());
+		}
+		SparseCholPlan plan;
+		if (!sparse_chol_plan(P, rowptr.data(), colind.data(), slack, (size_t)1 << 22, plan)) return CUBA_HIP_ERR_RUNTIME;
+		if (stats) { stats[0] = plan.T; stats[1] = plan.nTiles; stats[2] = plan.nLevels; stats[3] = plan.slack; }
 		std::vector<Scalar> hb(b, b + n);
-		DevBuf<Scalar> dBlocks, dB, dA, dInvL, dY, dX; DevBuf<int> dRow, dCol, dFail;
+		DevBuf<Scalar> dBlocks, dB, dTiles, dTilesT, dY, dRinv, dX; DevBuf<int> dRow, dCol, dFail;
 		dBlocks.upload(blocks, nullptr); dB.upload(hb, nullptr); dRow.upload(blkrow, nullptr); dCol.upload(colind, nullptr);
-		DenseCholesky d;
-		dA.resize(dense_cholesky_elems(n, &d.N, &d.ld)); dInvL.resize((size_t)(d.N / 32) * 1024); dY.resize(d.N); dFail.resize(1); dX.resize(n);
-		d.A = dA.data(); d.invL = dInvL.data(); d.y = dY.data(); d.fail = dFail.data(); d.n = n;
-		DeviceGraph g; DeviceStructure st; DeviceSystem sys;
+		DevBuf<int> dColPtr, dRowIdx, dColOf, dGPtr, dGather, dLvlTiles, dLvlCols, dBlkTile, dPos;
+		dColPtr.upload(plan.colPtr, nullptr); dRowIdx.upload(plan.rowIdx, nullptr); dColOf.upload(plan.colOfTile, nullptr); dGPtr.upload(plan.gPtr, nullptr);
+		dGather.upload(plan.gather, nullptr); dLvlTiles.upload(plan.lvlTiles, nullptr); dLvlCols.upload(plan.lvlCols, nullptr);
+		dBlkTile.upload(plan.blkTile, nullptr); dPos.upload(plan.posOfSeg, nullptr);
+		dTiles.resize((size_t)SC_TT * ((size_t)plan.nTiles + 1)); dTilesT.resize((size_t)SC_TT * plan.nTiles);
+		dY.resize((size_t)SC_T * plan.T); dRinv.resize((size_t)SC_T * plan.T); dFail.resize(1); dX.resize(n);
+		SparseChol d;
+		d.tiles = dTiles.data(); d.tilesT = dTilesT.data(); d.y = dY.data(); d.rinv = dRinv.data(); d.fail = dFail.data();
+		d.colPtr = dColPtr.data(); d.rowIdx = dRowIdx.data(); d.colOfTile = dColOf.data(); d.gPtr = dGPtr.data(); d.gather = dGather.data();
+		d.lvlTiles = dLvlTiles.data(); d.lvlCols = dLvlCols.data(); d.blkTile = dBlkTile.data(); d.posOfSeg = dPos.data();
+		d.T = plan.T; d.Pf = P; d.nTiles = plan.nTiles;
+		DeviceStructure st; DeviceSystem sys;
 		st.nblk = (int)blkrow.size(); st.hsc_blkrow = dRow.data(); st.hsc_colind = dCol.data();
 		sys.hsc = dBlocks.data(); sys.bsc = dB.data();
-		launch_dense_fill(g, st, sys, d, nullptr);
-		launch_dense_cholesky_solve(d, dX.data(), nullptr);
+		launch_sparse_chol_fill(st, sys, d, nullptr);
+		launch_sparse_chol_solve(d, plan, dX.data(), nullptr);
 		std::vector<Scalar> hx(n); int flag = 0;
 		HIP_TRY(hipMemcpy(hx.data(), dX.data(), sizeof(Scalar) * n, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(&flag, dFail.data(), sizeof(int), hipMemcpyDeviceToHost));
@@ -569,6 +598,30 @@ int cuba_hip_debug_dense_solve(int device, int n, const double* A, const double*
 		return CUBA_HIP_OK;
 	}
 	catch (const HipError&) { return CUBA_HIP_ERR_RUNTIME; }
+}
+
+// The symbolic phase alone (host only: needs no device).  which: 0 header {T, nTiles, nLevels, slack, gather entries, nblk}, 1 posOfSeg,
+// 2 colPtr, 3 rowIdx, 4 gPtr, 5 gather (4 ints per entry), 6 lvlPtr, 7 lvlTiles, 8 lvlColPtr, 9 lvlCols, 10 blkTile
+int cuba_hip_debug_sparse_plan(int n_poses, const int32_t* row_ptr, const int32_t* col_ind, int slack, int which, int32_t* out, size_t capacity, size_t* count)
+{
+	if (n_poses <= 0 || !row_ptr || !col_ind || !count) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	static thread_local SparseCholPlan plan;
+	static thread_local std::vector<int> key;
+	std::vector<int> k(row_ptr, row_ptr + n_poses + 1);
+	k.insert(k.end(), col_ind, col_ind + row_ptr[n_poses]);
+	k.push_back(slack);
+	if (k != key)
+	{
+		if (!sparse_chol_plan(n_poses, row_ptr, col_ind, slack, (size_t)1 << 22, plan)) return CUBA_HIP_ERR_RUNTIME;
+		key.swap(k);
+	}
+	const std::vector<int> header{ plan.T, plan.nTiles, plan.nLevels, plan.slack, (int)(plan.gather.size() / 4), (int)plan.blkTile.size() };
+	const std::vector<int>* src[] = { &header, &plan.posOfSeg, &plan.colPtr, &plan.rowIdx, &plan.gPtr, &plan.gather, &plan.lvlPtr, &plan.lvlTiles,
+		&plan.lvlColPtr, &plan.lvlCols, &plan.blkTile };
+	if (which < 0 || which > 10) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	*count = src[which]->size();
+	if (out) std::memcpy(out, src[which]->data(), sizeof(int) * std::min(capacity, src[which]->size()));
+	return CUBA_HIP_OK;
 }
 
 int cuba_hip_begin_run(cuba_hip_solver* s)

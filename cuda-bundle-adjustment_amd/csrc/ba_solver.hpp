@@ -584,24 +584,32 @@ struct cuba_hip_solver
 	int lastFailCode = 0;        // device failure code of the last PCG (1: a diagonal block is not positive definite, 2: p.Ap <= 0, 3: NaN)
 	bool solveReduced();
 
-	// Exact reduced solve (ba_direct.hip: dense blocked Cholesky on the matrix cores), the counterpart of the reference's
+	// Exact reduced solve (ba_direct.hip: sparse tile Cholesky, tile products on the matrix cores), the counterpart of the reference's
 	// SparseLinearSolver::solve (src/cuda_linear_solver.cpp:386-415: exact, false only on a non-positive pivot).  A solve goes there when
 	// the PCG has used its iteration budget without meeting pcg_tol, when it broke down, and -- for the rest of the LM run -- once one
 	// solve of the run had to: such systems (nearly singular Hsc: most observations of many poses at zero robust weight) are the ones an
-	// iterative solve is the wrong tool for.  Dense, hence limited in size: "direct_max_unknowns" (default 65536 = 34 GB) and the free
-	// device memory at the time of the first use; beyond, the old failure report stands (the trial is rejected like a failed
-	// factorisation of the reference).
+	// iterative solve is the wrong tool for.  "reduced_solver" = 1 sends EVERY solve there (the reference's behaviour).  Ordering and
+	// symbolic analysis happen once per structure, at the first exact solve (the reference's SparseLinearSolver::initialize, :278-348);
+	// the only limit is the factor's fill: "direct_max_tiles" 32 x 32 tiles (a pure function of the block pattern -- every rank of a
+	// partitioned run decides alike); beyond, the old failure report stands (the trial is rejected like a failed factorisation of the
+	// reference).
 	bool directFallback = true;         // option "direct_fallback"
-	int directAfter = 0;                // option "direct_after": PCG iterations a solve may use before it is handed over; 0 = automatic
-	int directMaxUnknowns = 65536;      // option "direct_max_unknowns"
+	bool directAlways = false;          // option "reduced_solver" = 1
+	int directAfter = 0;                // option "direct_after": PCG iterations a solve may use before it is handed over; 0 = automatic (128)
+	int directMaxTiles = 1 << 20;       // option "direct_max_tiles" (2^20 tiles = 16 GiB of factor in fp64)
+	int directSlack = -1;               // option "direct_slack": multiple-elimination slack of the ordering, -1 = automatic
 	bool directSticky = false;          // a solve of the current run went to the exact solver: the run's remaining solves go there at once
-	bool directRefused = false;         // the dense matrix did not fit into the free device memory (asked once per structure)
-	double directSeconds = 0;           // host-side wall time of the last exact solve (sizes the automatic budget)
-	DevBuf<Scalar> d_dense, d_denseInvL, d_denseY;
-	DevBuf<int> d_denseFail;
+	bool directRefused = false;         // the factor's fill exceeds direct_max_tiles (decided once per structure)
+	bool directPlanValid = false;       // directPlan describes the current structure
+	double directSeconds = 0, directPlanSeconds = 0;    // host-side wall time of the last exact solve / of the symbolic phase (reporting only)
+	SparseCholPlan directPlan;
+	SparseChol directDev;
+	DevBuf<Scalar> d_scTiles, d_scTilesT, d_scY, d_scRinv;
+	DevBuf<int> d_scInts, d_scFail;
 	int64_t cntDirect = 0, cntDirectFailed = 0;
-	bool directUsable();
+	bool directUsable() const { return directFallback && !directRefused && Pf > 0; }
 	int pcgBudget(int maxIter) const;
+	bool ensureDirectPlan();
 	bool solveDirect();
 
 	bool solveReducedOnce();

@@ -98,12 +98,15 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 /* Options (22).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
    "direct_fallback" (default 1: a reduced solve whose PCG uses up its iteration budget, breaks down, or follows such a solve in the
-   same Levenberg-Marquardt run is solved EXACTLY on the device -- dense blocked Cholesky on the matrix cores, csrc/ba_direct.hip, the
-   role of SparseLinearSolver::solve, /root/reference/src/cuda_linear_solver.cpp:386-415 -- and fails only on a non-positive pivot
-   like the reference, :406-410; 0 = the solve is reported as failed instead), "direct_after" (PCG iterations before the hand-over;
-   default 0 = automatic: as many as one exact solve costs, at most pcg_max_iter), "direct_max_unknowns" (default 65536: the exact
-   solver is dense -- 8 (6 Pf)^2 bytes, allocated at its first use -- and is not used beyond this size or when the matrix does not fit
-   the free device memory; the failure report then stands),
+   same Levenberg-Marquardt run is solved EXACTLY on the device -- sparse tile Cholesky, csrc/ba_direct.hip: minimum-degree ordering
+   and symbolic analysis once per structure at the first exact solve, numeric factorisation + triangular solves per solve, the three
+   phases of SparseLinearSolver, /root/reference/src/cuda_linear_solver.cpp:278-348, 147-232, 386-415 -- and fails only on a
+   non-positive pivot like the reference, :406-410; 0 = the solve is reported as failed instead), "reduced_solver" (default 0 = block
+   PCG with that fallback; 1 = EVERY reduced solve is the exact one, the reference's behaviour), "direct_after" (PCG iterations before
+   the hand-over; default 0 = automatic: 128 -- about twice what an exact solve costs --, at most pcg_max_iter; a constant, so that the
+   decision never depends on timing), "direct_max_tiles" (default 2^20: the fill of the factor, in 32 x 32 tiles of 5 poses x 5 poses,
+   beyond which the exact solver is not used and the failure report stands; a 10 000-pose trajectory with loop closures needs 19 000),
+   "direct_slack" (default -1 = automatic: multiple-elimination slack of the ordering, 0 / 2 / 4 / 8 by a cost model of levels and fill),
    "pcg_aggregate" (poses per coarse aggregate of the two-level preconditioner; -1 = automatic: max(6, Pf/55) below 1320 free poses,
    max(16, Pf/min(180, max(115, Pf/32))) above; 0 = block-Jacobi only), "coarse_linear" (default 1: constant + linear-in-pose-index
    coarse functions per aggregate, 12 unknowns each; 0 = constant only, 6 unknowns), "precond_fp32" (fp64 library only, default 1: the
@@ -356,11 +359,20 @@ int cuba_hip_get_sizes(cuba_hip_solver* s, int sizes[5]);
    coarse inverse of the two-level preconditioner.  A, Ainv: n x n, column-major, SPD input.  No solver handle involved. */
 int cuba_hip_debug_dense_inverse(int device, int n, const double* A, double* Ainv);
 
-/* Test hook for the exact reduced solve (csrc/ba_direct.hip: dense blocked Cholesky on the matrix cores + triangular solves), the
-   counterpart of SparseLinearSolver::solve (/root/reference/src/cuda_linear_solver.cpp:386-415).  A: n x n column-major, symmetric
-   (n a multiple of 6: it is cut into the 6 x 6 blocks of a reduced system); x = A^-1 b.  *not_positive_definite != 0 reports a
-   non-positive pivot (ref :406-410).  No solver handle involved. */
+/* Test hooks for the exact reduced solve (csrc/ba_direct.hip: sparse tile Cholesky on the matrix cores + triangular solves), the
+   counterpart of SparseLinearSolver::initialize / solve (/root/reference/src/cuda_linear_solver.cpp:278-348, 386-415).  A: n x n
+   column-major, symmetric (n a multiple of 6: it is cut into the 6 x 6 blocks of a reduced system; off-diagonal blocks that are
+   identically zero are not part of the pattern); x = A^-1 b.  *not_positive_definite != 0 reports a non-positive pivot (ref :406-410).
+   slack: multiple-elimination slack of the ordering (-1 = automatic); stats (optional) = {tile columns, tiles, levels, slack used}.
+   No solver handle involved.  cuba_hip_debug_dense_solve = the same with slack -1 and no statistics. */
 int cuba_hip_debug_dense_solve(int device, int n, const double* A, const double* b, double* x, int* not_positive_definite);
+int cuba_hip_debug_sparse_solve(int device, int n, const double* A, const double* b, double* x, int* not_positive_definite, int slack, int32_t stats[4]);
+/* The symbolic phase alone, on the host (no device needed): ordering, fill, elimination-tree levels and gather lists for the
+   upper-triangular block pattern (row_ptr[n_poses + 1], col_ind; diagonal block first in every row).  which: 0 header {tile columns,
+   tiles, levels, slack, gather entries, blocks}, 1 posOfSeg, 2 colPtr, 3 rowIdx, 4 gPtr, 5 gather (4 ints per entry), 6 lvlPtr,
+   7 lvlTiles, 8 lvlColPtr, 9 lvlCols, 10 blkTile (see SparseCholPlan in csrc/ba_kernels.hpp).  *count = length of the array; out may be
+   NULL to ask for it. */
+int cuba_hip_debug_sparse_plan(int n_poses, const int32_t* row_ptr, const int32_t* col_ind, int slack, int which, int32_t* out, size_t capacity, size_t* count);
 
 /* A driver that runs the Levenberg-Marquardt loop itself through the stage calls announces the start of a run (a new lambda_0):
    the coarse inverse of the two-level preconditioner and the iteration-count predictions of the previous run are dropped, as
