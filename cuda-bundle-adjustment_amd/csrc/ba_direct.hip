@@ -143,7 +143,7 @@ bool build_plan(int Pf, const int* rowptr, const int* colind, const Elimination&
 	size_t total = 0;
 	for (int j = 0; j < T; j++)
 	{
-		const size_t len = ((size_t)(rowCnt[j + 1] - rowCnt[j]) + 1) & ~(size_t)1;       // (even: the kernel takes two entries per trip)
+		const size_t len = ((size_t)(rowCnt[j + 1] - rowCnt[j]) + 3) & ~(size_t)3;       // (a multiple of 4: the kernel takes four entries per trip)
 		for (int t = p.colPtr[j]; t < p.colPtr[j + 1]; t++) { p.gPtr[t] = (int)total; total += len; }
 		if (total > ((size_t)1 << 29)) return false;
 	}
@@ -177,6 +177,14 @@ bool build_plan(int Pf, const int* rowptr, const int* colind, const Elimination&
 			p.lvlCols[b[level[j]]++] = j;
 			for (int t = p.colPtr[j]; t < p.colPtr[j + 1]; t++) p.lvlTiles[a[level[j]]++] = t;
 		}
+	}
+	// one record per workgroup of the factorisation, in work-list order: everything its first instructions need in ONE scalar load
+	p.wgRec.assign(8 * nTiles, 0);
+	for (size_t w = 0; w < nTiles; w++)
+	{
+		const int t = p.lvlTiles[w], j = p.colOfTile[t];
+		int* r = p.wgRec.data() + 8 * w;
+		r[0] = t; r[1] = p.colPtr[j]; r[2] = j; r[3] = p.gPtr[t]; r[4] = p.gPtr[t + 1] - p.gPtr[t];
 	}
 	// destination of every block of the upper-triangular BSR storage
 	p.blkTile.resize(rowptr[Pf]);
@@ -316,54 +324,58 @@ __global__ __launch_bounds__(256) void schol_factor_level_kernel(SparseChol d, i
 	__shared__ Scalar Fs[SC_T][SC_T + 1];
 	__shared__ Scalar ws[SC_T];
 	__shared__ Scalar pivS[2 * SC_T];
-	const int t = d.lvlTiles[first + blockIdx.x];
-	const int j = d.colOfTile[t], t0 = d.colPtr[j];
+	const int4* __restrict__ R = reinterpret_cast<const int4*>(d.wgRec) + 2 * (size_t)(first + blockIdx.x);
+	const int4 rec0 = R[0];
+	const int t = rec0.x, t0 = rec0.y, j = rec0.z, g0 = rec0.w, len = R[1].x;
 	const bool diag = t == t0;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wi = wv >> 1, wj = wv & 1;
 	const int off = (lane >> 4) * SC_T + (lane & 15);
 	const int offI = 16 * wi + off, offJ = 16 * wj + off;
 	MfmaAcc aD = mfma_zero(), aF = mfma_zero();
-	const int g0 = d.gPtr[t], g1 = d.gPtr[t + 1];
-	const int4* __restrict__ G = reinterpret_cast<const int4*>(d.gather);
-	if (diag)
+	const int4* __restrict__ G = reinterpret_cast<const int4*>(d.gather) + g0;
+	// Four entries per trip: all their operand loads are in flight before the first product (a trip costs one memory round trip -- the
+	// tiles were written by other compute units, they come from the memory-side cache --, not one per entry), and the next trip's
+	// entries are fetched under this trip's loads.
+	if (len > 0)
 	{
+		int4 cur[4] = { G[0], G[1], G[2], G[3] };
 		const bool yl = wj == 0 && (lane & 15) == 0;
-		for (int e = g0; e < g1; e += 2)
+		for (int e = 0; e < len; e += 4)
 		{
-			const int4 ea = G[e], eb = G[e + 1];
-			const Scalar* La = d.tiles + (size_t)SC_TT * ea.y;
-			const Scalar* Lb = d.tiles + (size_t)SC_TT * eb.y;
-			Scalar ra[8], ca[8], ya[8], rb[8], cb[8], yb[8];
-			load_slab(La, offI, ra); load_slab(La, offJ, ca);
-			load_slab(Lb, offI, rb); load_slab(Lb, offJ, cb);
-#pragma unroll
-			for (int s = 0; s < 8; s++)
+			const int en = e + 4 < len ? e + 4 : e;
+			const int4 nxt[4] = { G[en], G[en + 1], G[en + 2], G[en + 3] };
+			Scalar rr[4][8], cc[4][8], ff[4][8];
+			if (diag)
 			{
-				ya[s] = yl ? d.y[SC_T * (size_t)ea.z + 4 * s + (lane >> 4)] : Scalar(0);
-				yb[s] = yl ? d.y[SC_T * (size_t)eb.z + 4 * s + (lane >> 4)] : Scalar(0);
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					const Scalar* L = d.tiles + (size_t)SC_TT * cur[u].y;
+					load_slab(L, offI, rr[u]); load_slab(L, offJ, cc[u]);
+#pragma unroll
+					for (int s8 = 0; s8 < 8; s8++) ff[u][s8] = yl ? d.y[SC_T * (size_t)cur[u].z + 4 * s8 + (lane >> 4)] : Scalar(0);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+#pragma unroll
+					for (int s8 = 0; s8 < 8; s8++) { aD = mfma_16x16x4(cc[u][s8], rr[u][s8], aD); aF = mfma_16x16x4(ff[u][s8], rr[u][s8], aF); }
+			}
+			else
+			{
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					const Scalar* L = d.tiles + (size_t)SC_TT * cur[u].y;
+					load_slab(L, offI, rr[u]); load_slab(L, offJ, cc[u]);
+					load_slab(d.tiles + (size_t)SC_TT * cur[u].x, offI, ff[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+#pragma unroll
+					for (int s8 = 0; s8 < 8; s8++) { aD = mfma_16x16x4(cc[u][s8], rr[u][s8], aD); aF = mfma_16x16x4(cc[u][s8], ff[u][s8], aF); }
 			}
 #pragma unroll
-			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(ca[s], ra[s], aD); aF = mfma_16x16x4(ya[s], ra[s], aF); }
-#pragma unroll
-			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(cb[s], rb[s], aD); aF = mfma_16x16x4(yb[s], rb[s], aF); }
-		}
-	}
-	else
-	{
-		for (int e = g0; e < g1; e += 2)
-		{
-			const int4 ea = G[e], eb = G[e + 1];
-			const Scalar* La = d.tiles + (size_t)SC_TT * ea.y;
-			const Scalar* Lb = d.tiles + (size_t)SC_TT * eb.y;
-			const Scalar* Ia = d.tiles + (size_t)SC_TT * ea.x;
-			const Scalar* Ib = d.tiles + (size_t)SC_TT * eb.x;
-			Scalar ra[8], ca[8], fa[8], rb[8], cb[8], fb[8];
-			load_slab(La, offI, ra); load_slab(La, offJ, ca); load_slab(Ia, offI, fa);
-			load_slab(Lb, offI, rb); load_slab(Lb, offJ, cb); load_slab(Ib, offI, fb);
-#pragma unroll
-			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(ca[s], ra[s], aD); aF = mfma_16x16x4(ca[s], fa[s], aF); }
-#pragma unroll
-			for (int s = 0; s < 8; s++) { aD = mfma_16x16x4(cb[s], rb[s], aD); aF = mfma_16x16x4(cb[s], fb[s], aF); }
+			for (int u = 0; u < 4; u++) cur[u] = nxt[u];
 		}
 	}
 	// lane l holds element (row 16 wi + (l & 15), column 16 wj + mfma_row(l, q)) of its wave's quadrant
@@ -381,7 +393,9 @@ __global__ __launch_bounds__(256) void schol_factor_level_kernel(SparseChol d, i
 		if (diag && wj == 0 && lane < 16) ws[row] = d.y[SC_T * (size_t)j + row] - mfma_get(aF, 0);
 	}
 	__syncthreads();
-	if (wv != 0) return;
+	// (the serial part takes one wave: a different one from workgroup to workgroup, so that the workgroups sharing a compute unit do not
+	// queue their chains on one SIMD)
+	if (wv != (int)(blockIdx.x & 3)) return;
 	const int r = lane & 31;
 	Scalar T[SC_T];
 #pragma unroll
@@ -396,9 +410,17 @@ __global__ __launch_bounds__(256) void schol_factor_level_kernel(SparseChol d, i
 		if (!pivot_ok(dj)) { bad = 1; dj = Scalar(1); }
 		const Scalar rj = fast_rcp(dj);
 		pivS[jj] = dj; pivS[SC_T + jj] = rj;
-		const Scalar lr = T[jj] * rj;
+		Scalar lr = T[jj] * rj;
+		// (all broadcasts of the step, then all multiply-adds: interleaved one by one, every multiply-add waits for its scalar pair;
+		// the empty asm statements pin that order)
+		Scalar sc[SC_T];
 #pragma unroll
-		for (int c = jj + 1; c < SC_T; c++) T[c] -= lr * lane_bcast(T[jj], c);
+		for (int c = jj + 1; c < SC_T; c++) sc[c] = lane_bcast(T[jj], c);
+#pragma unroll
+		for (int c = jj + 1; c < SC_T; c++) asm volatile("" : "+s"(sc[c]));
+		asm volatile("" : "+v"(lr));
+#pragma unroll
+		for (int c = jj + 1; c < SC_T; c++) T[c] -= lr * sc[c];
 	}
 	const Scalar sv = Scalar(1) / sqrt(pivS[r]);       // 1 / L_rr
 	const Scalar rjv = pivS[SC_T + r];                 // 1 / T_rr
@@ -415,9 +437,15 @@ __global__ __launch_bounds__(256) void schol_factor_level_kernel(SparseChol d, i
 		for (int m = 0; m < SC_T; m++)
 		{
 			asm volatile("" : "+v"(T[m]), "+v"(a[m]));        // (keeps step m's broadcasts behind step m - 1: hoisted, they spill)
-			const Scalar z = a[m] * lane_bcast(rjv, m);
+			Scalar z = a[m] * lane_bcast(rjv, m);
+			Scalar sc[SC_T];
 #pragma unroll
-			for (int c = m + 1; c < SC_T; c++) a[c] -= z * lane_bcast(T[m], c);
+			for (int c = m + 1; c < SC_T; c++) sc[c] = lane_bcast(T[m], c);
+#pragma unroll
+			for (int c = m + 1; c < SC_T; c++) asm volatile("" : "+s"(sc[c]));
+			asm volatile("" : "+v"(z));
+#pragma unroll
+			for (int c = m + 1; c < SC_T; c++) a[c] -= z * sc[c];
 		}
 #pragma unroll
 		for (int m = 0; m < SC_T; m++) a[m] *= lane_bcast(sv, m);

@@ -197,6 +197,7 @@ void launch_coarse_finish(const Scalar* swept, Scalar* dst, int n, hipStream_t s
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 // one iteration of the upper-triangle form (sys.upper): which = 1 SpMV | 2 row updates | 4 preconditioner (7 = all three, in this order)
 int spmv_upper_grid(int Pf);      // workgroups of the upper-triangle SpMV (= its p.Ap partials)
+int pcg_rows_max_aggregate();     // largest aggregate (poses) the row-update launch of the upper-triangle iteration handles
 void launch_build_lowpos(const DeviceGraph& g, const DeviceStructure& st, int* lowpos, hipStream_t s);
 void launch_pcg_upper_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s, int which = 7);
 // what the last node of an iteration graph does, as a launch: advance the iteration offset by n, run the stop test on the residual the
@@ -234,7 +235,8 @@ struct SparseCholPlan             // host: the symbolic phase's result for one b
 	std::vector<int> colPtr;                 // [T + 1] tiles of column k: the diagonal tile first, then its rows in ascending position
 	std::vector<int> rowIdx, colOfTile;      // [nTiles]
 	std::vector<int> gPtr;                   // [nTiles + 1] gather list of every tile ...
-	std::vector<int> gather;                 // ... 4 ints per entry {tile (i, k) or the zero tile, tile (j, k), k, 0}, k ascending, padded to an even count
+	std::vector<int> gather;                 // ... 4 ints per entry {tile (i, k) or the zero tile, tile (j, k), k, 0}, k ascending, padded to a multiple of 4
+	std::vector<int> wgRec;                  // [8 nTiles] per entry of lvlTiles: {tile, diagonal tile of its column, column, first gather entry, entries, 0, 0, 0}
 	std::vector<int> lvlPtr, lvlTiles;       // [nLevels + 1], [nTiles]: tiles by the level of their column (work list of the factorisation)
 	std::vector<int> lvlColPtr, lvlCols;     // [nLevels + 1], [T]: columns by level (work list of the backward substitution)
 	std::vector<int> blkTile;                // [nblk] destination tile of every block of the upper-triangular BSR storage (bit 30: transposed)
@@ -253,7 +255,7 @@ struct SparseChol                 // device view
 	Scalar* y = nullptr;          // [32 T] right-hand side -> L^-1 b -> solution, in elimination order
 	Scalar* rinv = nullptr;       // [32 T] 1 / L_cc
 	const int *colPtr = nullptr, *rowIdx = nullptr, *colOfTile = nullptr, *gPtr = nullptr, *gather = nullptr;
-	const int *lvlTiles = nullptr, *lvlCols = nullptr, *blkTile = nullptr, *posOfSeg = nullptr;
+	const int *wgRec = nullptr, *lvlCols = nullptr, *blkTile = nullptr, *posOfSeg = nullptr;
 	int* fail = nullptr;          // != 0 after the solve: a non-positive pivot was met (the matrix is not positive definite)
 	int T = 0, Pf = 0, nTiles = 0;
 };

@@ -297,7 +297,7 @@ bool cuba_hip_solver::ensureDirectPlan()
 	std::vector<int> ints;
 	auto put = [&](const std::vector<int>& v) { const size_t o = ints.size(); ints.insert(ints.end(), v.begin(), v.end()); while (ints.size() % 4) ints.push_back(0); return o; };
 	const size_t oColPtr = put(p.colPtr), oRowIdx = put(p.rowIdx), oColOf = put(p.colOfTile), oGPtr = put(p.gPtr), oGather = put(p.gather),
-		oLvlTiles = put(p.lvlTiles), oLvlCols = put(p.lvlCols), oBlkTile = put(p.blkTile), oPos = put(p.posOfSeg);
+		oWgRec = put(p.wgRec), oLvlCols = put(p.lvlCols), oBlkTile = put(p.blkTile), oPos = put(p.posOfSeg);
 	d_scInts.upload(ints, stream);
 	d_scTiles.resize((size_t)SC_TT * ((size_t)p.nTiles + 1)); d_scTilesT.resize((size_t)SC_TT * std::max(1, p.nTiles));
 	d_scY.resize((size_t)SC_T * p.T); d_scRinv.resize((size_t)SC_T * p.T); d_scFail.resize(1);
@@ -306,7 +306,7 @@ bool cuba_hip_solver::ensureDirectPlan()
 	d.tiles = d_scTiles.data(); d.tilesT = d_scTilesT.data(); d.y = d_scY.data(); d.rinv = d_scRinv.data(); d.fail = d_scFail.data();
 	const int* base = d_scInts.data();
 	d.colPtr = base + oColPtr; d.rowIdx = base + oRowIdx; d.colOfTile = base + oColOf; d.gPtr = base + oGPtr; d.gather = base + oGather;
-	d.lvlTiles = base + oLvlTiles; d.lvlCols = base + oLvlCols; d.blkTile = base + oBlkTile; d.posOfSeg = base + oPos;
+	d.wgRec = base + oWgRec; d.lvlCols = base + oLvlCols; d.blkTile = base + oBlkTile; d.posOfSeg = base + oPos;
 	d.T = p.T; d.Pf = Pf; d.nTiles = p.nTiles;
 	directPlanSeconds = std::chrono::duration<double>(Clock::now() - t0).count();
 	if (std::getenv("CUBA_HIP_DEBUG"))

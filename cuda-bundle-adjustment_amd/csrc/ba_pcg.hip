@@ -1016,7 +1016,11 @@ __global__ __launch_bounds__(64 * UPPER_WAVES, 4) void pcg_spmv_upper_kernel(Dev
 }
 
 // second launch of the upper-triangle iteration: one workgroup per aggregate
+// (EPT = row entries per thread: an aggregate of `agg` poses has 6 agg of them -- 2 per thread up to 170 poses, 4 up to 341, 8 up to 682;
+// publishStructure switches the upper-triangle iteration off beyond ROWS_MAX_AGG)
 constexpr int ROWS_T = 512;
+constexpr int ROWS_MAX_AGG = 8 * ROWS_T / 6;
+template <int EPT>
 __global__ __launch_bounds__(ROWS_T) void pcg_rows_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
 {
 	extern __shared__ __align__(16) unsigned char rows_lds[];
@@ -1048,9 +1052,11 @@ __global__ __launch_bounds__(ROWS_T) void pcg_rows_kernel(DeviceGraph g, DeviceS
 	const int own0 = 6 * I * sys.agg;
 	const int ownN = min(6 * g.Pf, own0 + 6 * sys.agg) - own0;
 	// completed rows of q = A p: the SpMV's share + the transposed products of the lower neighbours, in adjacency order
-	Scalar qrow[2] = { 0, 0 }, rrow[2] = { 0, 0 }, prow[2] = { 0, 0 }, xrow[2] = { 0, 0 };      // (aggregates of up to 170 poses: two entries per thread)
+	Scalar qrow[EPT], rrow[EPT], prow[EPT], xrow[EPT];
 #pragma unroll
-	for (int e = 0; e < 2; e++)
+	for (int e = 0; e < EPT; e++) { qrow[e] = 0; rrow[e] = 0; prow[e] = 0; xrow[e] = 0; }
+#pragma unroll
+	for (int e = 0; e < EPT; e++)
 	{
 		const int w = t + e * ROWS_T;
 		if (w >= ownN) break;
@@ -1094,7 +1100,7 @@ __global__ __launch_bounds__(ROWS_T) void pcg_rows_kernel(DeviceGraph g, DeviceS
 	}
 	const Scalar alpha = rzk / pqk;
 #pragma unroll
-	for (int e = 0; e < 2; e++)
+	for (int e = 0; e < EPT; e++)
 	{
 		const int w = t + e * ROWS_T;
 		if (w >= ownN) break;
@@ -1125,6 +1131,14 @@ __global__ __launch_bounds__(ROWS_T) void pcg_rows_kernel(DeviceGraph g, DeviceS
 	TRACE_FLUSH(2, blockIdx.x * (ROWS_T / 64) + wv);
 }
 
+typedef void (*PcgRowsKernel)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar);
+static PcgRowsKernel pcg_rows_kernel_for(const DeviceSystem& sys)
+{
+	const int entries = 6 * sys.agg;
+	return entries <= 2 * ROWS_T ? pcg_rows_kernel<2> : entries <= 4 * ROWS_T ? pcg_rows_kernel<4> : pcg_rows_kernel<8>;
+}
+int pcg_rows_max_aggregate() { return ROWS_MAX_AGG; }
+
 // lowpos[b] for every off-diagonal block b = (i, j): its position among the lower neighbours of row j, counted over all rows (the
 // SpMV parks B^T p_i there, pcg_rows_kernel reads the range of row j)
 __global__ __launch_bounds__(256) void build_lowpos_kernel(DeviceStructure st, int Pf, int* __restrict__ lowpos)
@@ -1150,7 +1164,7 @@ void launch_pcg_upper_iteration(const DeviceGraph& g, const DeviceStructure& st,
 {
 	typedef void (*K3)(DeviceGraph, DeviceStructure, DeviceSystem, int, int, Scalar);
 	if (which & 1) hipLaunchKernelGGL((K3)spmv_upper_kernel_for(sys), dim3(spmv_upper_grid(g.Pf)), dim3(64 * UPPER_WAVES), 0, s, g, st, sys, k, maxIter, tol2);
-	if (which & 2) hipLaunchKernelGGL(pcg_rows_kernel, dim3(sys.nc), dim3(ROWS_T), rows_lds_bytes(sys), s, g, st, sys, k, maxIter, tol2);
+	if (which & 2) hipLaunchKernelGGL(pcg_rows_kernel_for(sys), dim3(sys.nc), dim3(ROWS_T), rows_lds_bytes(sys), s, g, st, sys, k, maxIter, tol2);
 	if (which & 4)
 		hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(PCG2_T), pcg2_lds_bytes(sys), s,
 			g, sys, k, k + 1, maxIter, tol2, 1);
@@ -1262,7 +1276,7 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		if (sys.upper && sys.agg > 0)
 		{
 			e = add_kernel_node(graph, last, spmv_upper_kernel_for(sys), dim3(spmv_upper_grid(g.Pf)), dim3(64 * UPPER_WAVES), 0, g, st, sys, k, maxIter, tol2);
-			if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_rows_kernel, dim3(sys.nc), dim3(ROWS_T), (unsigned)rows_lds_bytes(sys), g, st, sys, k, maxIter, tol2);
+			if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_rows_kernel_for(sys), dim3(sys.nc), dim3(ROWS_T), (unsigned)rows_lds_bytes(sys), g, st, sys, k, maxIter, tol2);
 			if (e == hipSuccess) e = add_kernel_node(graph, last, pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(PCG2_T), (unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
 			continue;
 		}

@@ -734,7 +734,9 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 	d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
 	d_lamS.resize(1); d_lmState.resize(8); sys.lam_dev = d_lamS.data();
-	sys.upper = agg > 0 && (spmvUpper < 0 ? spmvRows == 4 : spmvUpper != 0) ? 1 : 0;
+	// (the row-update launch of the upper-triangle iteration keeps an aggregate's 6 agg row entries in the registers of one workgroup:
+	// beyond pcg_rows_max_aggregate() poses -- a user-set pcg_aggregate, or ~120 000 poses with the automatic one -- the two-launch form serves)
+	sys.upper = agg > 0 && agg <= pcg_rows_max_aggregate() && (spmvUpper < 0 ? spmvRows == 4 : spmvUpper != 0) ? 1 : 0;
 	if (sys.upper)
 	{
 		d_tq.resize((size_t)6 * nblk); sys.tq = d_tq.data(); d_hrow.release(); sys.hrow = nullptr;

@@ -576,14 +576,14 @@ int cuba_hip_debug_sparse_solve(int device, int n, const double* A, const double
 		dBlocks.upload(blocks, nullptr); dB.upload(hb, nullptr); dRow.upload(blkrow, nullptr); dCol.upload(colind, nullptr);
 		DevBuf<int> dColPtr, dRowIdx, dColOf, dGPtr, dGather, dLvlTiles, dLvlCols, dBlkTile, dPos;
 		dColPtr.upload(plan.colPtr, nullptr); dRowIdx.upload(plan.rowIdx, nullptr); dColOf.upload(plan.colOfTile, nullptr); dGPtr.upload(plan.gPtr, nullptr);
-		dGather.upload(plan.gather, nullptr); dLvlTiles.upload(plan.lvlTiles, nullptr); dLvlCols.upload(plan.lvlCols, nullptr);
+		dGather.upload(plan.gather, nullptr); dLvlTiles.upload(plan.wgRec, nullptr); dLvlCols.upload(plan.lvlCols, nullptr);
 		dBlkTile.upload(plan.blkTile, nullptr); dPos.upload(plan.posOfSeg, nullptr);
 		dTiles.resize((size_t)SC_TT * ((size_t)plan.nTiles + 1)); dTilesT.resize((size_t)SC_TT * plan.nTiles);
 		dY.resize((size_t)SC_T * plan.T); dRinv.resize((size_t)SC_T * plan.T); dFail.resize(1); dX.resize(n);
 		SparseChol d;
 		d.tiles = dTiles.data(); d.tilesT = dTilesT.data(); d.y = dY.data(); d.rinv = dRinv.data(); d.fail = dFail.data();
 		d.colPtr = dColPtr.data(); d.rowIdx = dRowIdx.data(); d.colOfTile = dColOf.data(); d.gPtr = dGPtr.data(); d.gather = dGather.data();
-		d.lvlTiles = dLvlTiles.data(); d.lvlCols = dLvlCols.data(); d.blkTile = dBlkTile.data(); d.posOfSeg = dPos.data();
+		d.wgRec = dLvlTiles.data(); d.lvlCols = dLvlCols.data(); d.blkTile = dBlkTile.data(); d.posOfSeg = dPos.data();
 		d.T = plan.T; d.Pf = P; d.nTiles = plan.nTiles;
 		DeviceStructure st; DeviceSystem sys;
 		st.nblk = (int)blkrow.size(); st.hsc_blkrow = dRow.data(); st.hsc_colind = dCol.data();

@@ -638,11 +638,13 @@ def test_dense_inverse_kernel_larger_sweeps(n):
 
 @pytest.mark.parametrize("n", [6, 30, 126, 132, 384, 1482])
 def test_exact_reduced_solve_kernels_against_lapack(n):
-    """csrc/ba_direct.hip -- the dense blocked Cholesky (32 x 32 tiles factorised in LDS, 128-column panels, trailing update on
-    v_mfma_f64_16x16x4_f64, the right-hand side carried as a border row) that stands in the seat of the reference's exact
-    SparseLinearSolver::solve (src/cuda_linear_solver.cpp:386-415) -- against LAPACK on SPD matrices of condition 1e8: sizes below one
-    tile, one panel, just over a panel (identity padding), three panels, KITTI-07's reduced system.  Backward-stable: the residual is
-    at working precision whatever the condition number; the solve is deterministic."""
+    """csrc/ba_direct.hip -- the sparse tile Cholesky (32 x 32 tiles of 5 poses; minimum-degree order and symbolic analysis on the host;
+    one launch per level of the elimination tree: gathered tile products on v_mfma_f64_16x16x4_f64, the diagonal tile eliminated in
+    registers, the right-hand side carried by the diagonal tile's workgroup) that stands in the seat of the reference's exact
+    SparseLinearSolver::solve (src/cuda_linear_solver.cpp:386-415) -- against LAPACK on DENSE SPD matrices of condition 1e8 (every tile
+    of the factor present: the worst case for fill, 50 levels at KITTI-07's size): sizes below one tile, five tiles with and without
+    identity padding, KITTI-07's reduced system.  Backward-stable: the residual is at working precision whatever the condition number;
+    the solve is deterministic."""
     from cuba_amd.capi import dense_solve
     rng = np.random.default_rng(n)
     Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
@@ -660,6 +662,31 @@ def test_exact_reduced_solve_kernels_against_lapack(n):
     A32 = 0.5 * (A32 + A32.T)
     x32, bad32 = dense_solve(A32, b, precision="f32")
     assert not bad32 and np.abs(A32 @ x32 - b).max() <= 2e-3 * max(1.0, np.abs(x32).max() * np.abs(A32).max())
+
+
+@pytest.mark.parametrize("name", ["band_120", "band_loop_closure", "two_closures", "block_diagonal", "short_last_segment", "trajectory_1000"])
+def test_exact_reduced_solve_on_sparse_patterns(name):
+    """The same kernels on SPARSE block patterns -- a band (trajectory), a band whose last stretch sees the first one again (loop
+    closure), two separate revisits, independent poses, a last segment of fewer than five poses, and a 1000-pose lap-and-a-third -- for
+    every multiple-elimination slack of the ordering: LAPACK's solution to 1e-12, bit-reproducible, few tiles and a shallow tree where
+    the band order would fill the whole revisit (tests/test_sparse_plan.py checks the symbolic phase alone, on the CPU)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from sparse_chol_emulator import random_spd_blocks
+    from test_sparse_plan import CASES, band_pattern
+    from cuba_amd.capi import dense_solve
+    rp, ci = band_pattern(1000, 18, closures=[(0, 770, 230)]) if name == "trajectory_1000" else CASES[name]()
+    rng = np.random.default_rng(len(ci))
+    A = random_spd_blocks(rp, ci, rng); b = rng.normal(size=A.shape[0])
+    ref = np.linalg.solve(A, b)
+    for slack in (-1, 0, 4, 8):
+        x, bad, st = dense_solve(A, b, slack=slack, with_stats=True)
+        assert not bad and np.abs(x - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (slack, st)
+        assert np.array_equal(dense_solve(A, b, slack=slack)[0], x)
+        if name == "trajectory_1000":
+            assert st["tiles"] < 8000 and st["levels"] <= 100, st          # (band order: 46 x 154 tiles for the revisit alone, 200 levels)
+    x32, bad32 = dense_solve(A, b, precision="f32")
+    assert not bad32 and np.abs(x32 - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_exact_reduced_solve_reports_a_non_positive_pivot():
@@ -710,6 +737,24 @@ def test_upper_triangle_iteration_float32_build(solvers):
     a = HipSolver(fp, RK_HUBER, precision="f32", spmv_upper=0).optimize(6)["chi2"]
     b = HipSolver(fp, RK_HUBER, precision="f32", spmv_upper=1).optimize(6)["chi2"]
     assert len(a) == len(b) and rel(b[:len(ref)], ref[:len(b)]) < 1e-3 and rel(a, b) < 1e-3
+
+
+@pytest.mark.parametrize("agg", [172, 344, 700])
+def test_upper_triangle_iteration_with_large_aggregates(solvers, agg):
+    """Round-5 advisor: the row-update launch of the upper-triangle iteration gave each of its 512 threads two row entries, so aggregates
+    above 170 poses (6 agg > 1024; the automatic rule gets there from ~30 000 free poses, a user-set pcg_aggregate at any size) were
+    silently truncated.  The launch now takes 2 / 4 / 8 entries per thread by aggregate size, and beyond 682 poses the handle uses the
+    two-launch form: same trajectory as spmv_upper = 0 in every case, oracle parity, no unconverged solve."""
+    HipSolver, OracleSolver = solvers
+    fp = flatten(synth_ba(1500, 30000, 120000, seed=21))
+    ref = OracleSolver(fp, RK_HUBER).optimize(4)["chi2"]
+    # (direct_fallback = 0: the PCG itself, to convergence -- with so few aggregates it needs more than the hand-over budget)
+    a = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, pcg_aggregate=agg, spmv_upper=0, direct_fallback=0); ra = a.optimize(4)["chi2"]
+    b = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, pcg_aggregate=agg, spmv_upper=1, direct_fallback=0); rb = b.optimize(4)["chi2"]
+    assert rel(ra, ref) < 1e-9 and rel(rb, ref) < 1e-9 and rel(ra, rb) < 1e-10
+    assert a.pcg_history()[1] == 0 and b.pcg_history()[1] == 0
+    ia, ib = a.pcg_history()[0], b.pcg_history()[0]
+    assert len(ia) == len(ib) and np.abs(ia - ib).max() <= 3, (ia.tolist(), ib.tolist())
 
 
 def test_device_resident_lm_decision_is_bit_identical(solvers):

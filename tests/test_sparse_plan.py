@@ -52,7 +52,7 @@ def test_plan_solves_the_system(name, slack):
     for k in range(T):
         r = plan["rowIdx"][plan["colPtr"][k]:plan["colPtr"][k + 1]]
         assert r[0] == k and np.all(np.diff(r) > 0)
-    assert np.all(np.diff(plan["gPtr"]) % 2 == 0)              # the kernel takes two gather entries per trip
+    assert np.all(np.diff(plan["gPtr"]) % 4 == 0)              # the kernel takes four gather entries per trip
     rng = np.random.default_rng(len(col_ind))
     A = random_spd_blocks(row_ptr, col_ind, rng)
     b = rng.normal(size=6 * P)
