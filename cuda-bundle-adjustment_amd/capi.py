@@ -99,6 +99,7 @@ def load_library(precision="f64"):
         "cuba_hip_restore_state_slot": [H, C.c_int],
         "cuba_hip_get_counter": [H, C.c_char_p, C.POINTER(C.c_int64)],
         "cuba_hip_optimize": [H, C.c_int, _dp, C.POINTER(C.c_int)],
+        "cuba_hip_optimize_batch": [C.POINTER(H), C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "cuba_hip_get_solution": [H, _dp, _dp, _dp],
         "cuba_hip_set_solution": [H, _dp, _dp, _dp],
         "cuba_hip_chi_squares": [H, _dp],
@@ -209,6 +210,21 @@ def sparse_plan(row_ptr, col_ind, slack=-1, precision="f64"):
     h = out.pop("header")
     out.update(T=int(h[0]), nTiles=int(h[1]), nLevels=int(h[2]), slack=int(h[3]), entries=int(h[4]), nblk=int(h[5]))
     return out
+
+
+def optimize_batch(solvers, niter):
+    """cuba_hip_optimize_batch: the LM runs of several HipSolver handles (one library, one device) in one launch chain.
+    Returns ([chi2 per iteration of every handle], reduced solves that ran batched)."""
+    n = len(solvers)
+    lib = solvers[0].lib
+    arr = (C.c_void_p * n)(*[s.h.value for s in solvers])
+    chi2 = np.zeros((n, max(niter, 1)))
+    done = (C.c_int * n)()
+    batched = C.c_int()
+    rc = lib.cuba_hip_optimize_batch(arr, n, int(niter), _d(chi2), done, C.byref(batched))
+    if rc != 0:
+        raise CubaHipError(f"cuba_hip_optimize_batch failed with status {rc}: {lib.cuba_hip_last_error(solvers[0].h).decode()}")
+    return [chi2[i, :done[i]].copy() for i in range(n)], int(batched.value)
 
 
 class HipSolver:

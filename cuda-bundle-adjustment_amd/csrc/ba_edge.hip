@@ -219,14 +219,6 @@ __global__ __launch_bounds__(256) void pose_scale_kernel(DeviceGraph g, DeviceSy
 	pose_scale_body(g, sys, lambda, parts, blockIdx.x, gridDim.x);
 }
 
-// Evaluation of an LM trial in one launch: the first nRes workgroups sum the robust chi2 at the updated estimate, the others the
-// pose part of the gain-ratio denominator (same partials, in the same places of their arrays, as the two separate kernels).
-__global__ __launch_bounds__(256) void eval_trial_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* resParts, int nRes, Scalar* scaleParts, int nScale)
-{
-	if ((int)blockIdx.x < nRes) residual_chi2_body(g, resParts, nullptr, blockIdx.x, nRes);
-	else pose_scale_body(g, sys, lambda, scaleParts, blockIdx.x - nRes, nScale);
-}
-
 // Second stage of the three sums of a trial (landmark part of the denominator from the back-substitution, chi2, pose part) and
 // the report to the host in one launch: each sum is added exactly as reduce_parts_kernel adds it; the results go into the
 // mapped host block, the ticket follows them.
@@ -260,6 +252,7 @@ __device__ __forceinline__ void lm_decide(double* st, Scalar* lamOut, double* ri
 			lamN = lam * nu; nuN = nu * 2; rej += 1;
 			if (!(rho < 0) && rho <= 0) haltN = true;         // (rho == 0: the reference leaves its trial loop and then its iteration loop)
 			if (rej >= st[7]) haltN = true;
+			if (!(rho < 0)) rej = 0;                          // (a NaN gain ratio ends the iteration without ending the run: the host loop starts counting afresh)
 		}
 		if (!(fabs(lamN) <= 1.7e308)) haltN = true;           // (not finite)
 	}
@@ -654,25 +647,6 @@ void launch_restore_if_rejected(Scalar* state, const Scalar* backup, size_t coun
 {
 	const unsigned grid = (unsigned)std::min<size_t>(512, (count + 255) / 256);
 	if (grid) hipLaunchKernelGGL(restore_if_rejected_kernel, dim3(grid), dim3(256), 0, s, state, backup, count, lm.state);
-}
-
-// Everything between a converged reduced solve and the LM decision in four launches: back-substitution, update, evaluation of
-// the trial (chi2 + pose part of the gain-ratio denominator), then the second stage of the three sums with the report to the
-// host.  The stage API runs the same kernels one call at a time (eight launches); per LM trial that is ~26 us more.
-// The partial sums share sys.parts: [0, nWaves + nBig) back-substitution, then 2048 for chi2, then 1024 for the pose part.
-void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s)
-{
-	const int nA = g.Lf > 0 ? st.nWaves + st.nBig : 0;
-	Scalar* resParts = sys.parts + (nA + 63) / 64 * 64;
-	Scalar* scaleParts = resParts + 2048;
-	if (g.Lf > 0) launch_back_substitute_kernels(g, st, sys, lambda, s);
-	launch_update_state(g, sys, s);
-	const int n = g.e_end - g.e_begin;
-	const int nRes = n > 0 ? min((n + 255) / 256, 2048) : 0;
-	const int nScale = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
-	if (nRes + nScale > 0) hipLaunchKernelGGL(eval_trial_kernel, dim3(nRes + nScale), dim3(256), 0, s, g, sys, lambda, resParts, nRes, scaleParts, nScale);
-	hipLaunchKernelGGL(reduce_report_kernel, dim3(1), dim3(1024), 0, s, sys, sys.parts, nA, sys.slots + NSLOT, resParts, nRes, sys.slots, scaleParts, 4 * nScale, sys.slots + 3 * NSLOT,
-		(double*)nullptr, (Scalar*)nullptr, (double*)nullptr);
 }
 
 }  // namespace cubahip

@@ -160,9 +160,8 @@ void launch_back_substitute(const DeviceGraph& g, const DeviceStructure& st, con
 
 // pose-side part of the gain-ratio denominator: sum xp (lambda xp + bp) -> slots[0..NSLOT)
 void launch_pose_scale(const DeviceGraph& g, const DeviceSystem& sys, Scalar lambda, Scalar* slots, hipStream_t s);
-// back-substitution + update + evaluation of the trial + second stage of their three sums + report to the host: four launches
-void launch_trial_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda, hipStream_t s);
-// the same in two launches: back-substitution, update and evaluation fused into one pass over the edges (`old` = copy of the state
+// back-substitution + update + evaluation of the trial + second stage of their three sums + report to the host in two launches:
+// back-substitution, update and evaluation fused into one pass over the edges (`old` = copy of the state
 // [q | t | Xw] made before the trial: the pass reads the pre-update estimate from it while it writes the updated one), then the sums
 // + report.  trial_tail_parts(): numbers of partial-sum scratch (sys.parts) it needs.
 struct LmDevice;
@@ -205,6 +204,22 @@ void launch_pcg_upper_iteration(const DeviceGraph& g, const DeviceStructure& st,
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s, Scalar tol2 = Scalar(-1));
 void launch_coarse_to_fp32(const Scalar* swept, float* dst, int n, hipStream_t s);   // swept buffer -> +A^-1 in the sys.acinv32 layout
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s);
+
+// ---- batched execution (cuba_hip_optimize_batch): the PCG iterations of several graphs as ONE launch chain ---------------------------
+// Device table entry of one graph: what its kernels otherwise receive as kernel arguments.  The batched kernels take blockIdx.y as the
+// graph number; a graph whose reduced solve has finished keeps its entry (its `done` flag makes its workgroups return at once).
+struct BatchEntry
+{
+	DeviceGraph g; DeviceStructure st; DeviceSystem sys;
+	int maxIter = 0;
+	int gridSpmv = 0;              // workgroups of this graph's SpMV launch (the batched grid is the maximum over the graphs)
+};
+int batch_kernel_class(const DeviceGraph& g, const DeviceSystem& sys);       // graphs of one batch must agree on it; -1 = not batchable
+size_t batch_pcg2_lds_bytes(const DeviceSystem& sys);
+// one PCG iteration (chunk-local k) of all n graphs of the table: SpMV + fused two-level kernel, 2 launches
+void launch_pcg_batch_iteration(const BatchEntry* tab, int n, const DeviceGraph& g0, const DeviceSystem& sys0, int gridSpmvMax, int ncMax, size_t ldsMax, int k, Scalar tol2, hipStream_t s);
+// advance every graph's iteration offset by `iters`, stop test on the residual the chunk left, report to every graph's host block
+void launch_pcg_batch_advance(const BatchEntry* tab, int n, int iters, hipStream_t s, Scalar tol2);
 
 // Adds `chunk` PCG iterations (chunk-local k = 0..chunk-1) and the kbase advance to `graph` as a chain of kernel nodes.
 // report != 0: the last node also copies the solver's flags and a ticket into the mapped host block (only the last graph of a

@@ -241,9 +241,10 @@ void cuba_hip_solver::schur(bool withBackup)
 	linearize(1, lambda, withBackup);
 }
 
-bool cuba_hip_solver::solveReduced()
+bool cuba_hip_solver::solveReduced() { return retryWithFp64Inverse(solveReducedOnce()); }
+
+bool cuba_hip_solver::retryWithFp64Inverse(bool ok)
 {
-	const bool ok = solveReducedOnce();
 	// (only a loss of positive definiteness ALONG THE ITERATION, code 2, can come from the fp32 rounding of the coarse inverse: a NaN or a
 	// diagonal block that is not positive definite would fail with fp64 storage just the same -- round-4 advisor)
 	if (ok || !lastSolveBrokeDown || lastFailCode != 2 || !fp32Inverse() || sys.agg <= 0) return ok;
@@ -264,17 +265,18 @@ bool cuba_hip_solver::solveReduced()
 	return ok2;
 }
 
-// PCG iterations a solve may use before it is handed to the exact solver.  An exact solve costs what 50-60 iterations cost at every
-// size measured (a launch per level of the elimination tree); the hand-over waits for about twice that -- within a
-// run the damping shrinks and the iteration count grows from solve to solve (x 1.3-2), so a solve that needs this many announces solves
-// that need more; and the iteration count is the one measure of the system's conditioning the PCG has -- pcg_tol bounds the residual, the
-// error of the increment is up to cond(M^-1 Hsc) times larger (on the KITTI-00-size Tukey start of tests/test_ref_lm.py the solves of 370
-// and 800 iterations at the default tolerance are what takes the run off the reference's: 2.6e-5 on chi2 with them, 3e-9 when they go
-// to the exact solver).  A constant: the decision is a function of the call sequence alone, never of timing or of the memory that
-// happens to be free (every rank of a partitioned run hands over at the same iteration).
+// PCG iterations a solve may use before it is handed to the exact solver.  An exact solve costs what 50 (KITTI-07 shape) ... 150-200
+// (KITTI-00, S2M, G4M shapes) iterations cost -- a launch per level of the elimination tree against two or three launches per iteration,
+// DESIGN.md section 4 --, and the hand-over waits for about twice that: Pf / 4 iterations, at least 128, at most 384.  Within a run the
+// damping shrinks and the iteration count grows from solve to solve (x 1.3-2), so a solve that needs this many announces solves that
+// need more; and the iteration count is the one measure of the system's conditioning the PCG has -- pcg_tol bounds the residual, the
+// error of the increment is up to cond(M^-1 Hsc) times larger (on the KITTI-00-size Tukey start of tests/test_ref_lm.py the solves of
+// 370 and 800 iterations at the default tolerance are what takes the run off the reference's: 2.6e-5 on chi2 with them, 3e-9 when they
+// go to the exact solver).  A function of the graph's size alone: the decision follows from the call sequence, never from timing or from
+// the memory that happens to be free (every rank of a partitioned run hands over at the same iteration).
 int cuba_hip_solver::pcgBudget(int maxIter) const
 {
-	const int it = directAfter > 0 ? directAfter : 128;
+	const int it = directAfter > 0 ? directAfter : std::min(384, std::max(128, Pf / 4));
 	return std::min(maxIter, std::max(4, it / 4 * 4));
 }
 
@@ -340,17 +342,20 @@ bool cuba_hip_solver::solveDirect()
 	return true;
 }
 
-bool cuba_hip_solver::solveReducedOnce()
+// The reduced solve of one handle in three parts, so that cuba_hip_optimize_batch can run the middle one -- the iterations -- for several
+// handles in one launch chain: solveBegin (set-up launch, coarse inverse schedule, first preconditioner application, batch-length
+// prediction; true = the solve is finished, sc.result is its outcome), the iteration loop, solveEnd (bookkeeping, hand-over to the
+// exact solver) / solveBrokeDown (the device reported a failure).
+bool cuba_hip_solver::solveBegin(SolveCtx& sc)
 {
 	lastSolveBrokeDown = false;
 	need();
-	StageTimer tm(this, 6);
-	if (Pf == 0) return true;
-	const int maxIter = maxIterAlloc;
-	const Scalar tol2 = pcgTol * pcgTol;
+	if (Pf == 0) { sc.result = true; return true; }
+	const int maxIter = sc.maxIter = maxIterAlloc;
+	const Scalar tol2 = sc.tol2 = pcgTol * pcgTol;
 	if (failDirty) { d_fail.zero(stream); failDirty = false; }      // (the device flag only changes when a solve fails, and every solve reports it)
-	const bool twoLevel = sys.agg > 0;
-	const bool direct = directUsable();
+	const bool twoLevel = sc.twoLevel = sys.agg > 0;
+	const bool direct = sc.direct = directUsable();
 	if (direct && (directSticky || directAlways))
 	{
 		// an earlier solve of this run needed the exact solver (or the caller wants every solve exact): this one goes there at once
@@ -361,10 +366,11 @@ bool cuba_hip_solver::solveReducedOnce()
 		coarseValid = false;
 		if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);
 		pcgHistory.push_back(0);
-		return solveDirect();
+		sc.result = solveDirect();
+		return true;
 	}
 	// iterations before the solve is handed to the exact solver (a caller who asked for the best iterate at max_iter gets max_iter)
-	const int budget = direct && !acceptUnconverged ? pcgBudget(maxIter) : maxIter;
+	sc.budget = direct && !acceptUnconverged ? pcgBudget(maxIter) : maxIter;
 	// an inversion that ran on the second stream under the previous trial's PCG: its result moves into the buffer the iteration
 	// graphs read within the next launch
 	const size_t invCount = (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
@@ -388,7 +394,7 @@ bool cuba_hip_solver::solveReducedOnce()
 			// the work buffers of the sweep, which leaves its result in d_coarse[0].
 			ensureOverlapObjects();
 			const size_t invBytes = sizeof(Scalar) * (size_t)36 * sys.cl * sys.cl * sys.nc * sys.nc;
-			if (!coarseValid && coarseFirstReuse && firstInvValid)
+			if (!coarseValid && heuristics && firstInvValid)
 			{
 				// first solve of a run on a structure that has seen a run before: start with the inverse that run's first solve had
 				// and let this trial's own inversion run on the other stream right away
@@ -406,7 +412,7 @@ bool cuba_hip_solver::solveReducedOnce()
 				if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[0].data(), 6 * sys.cl * sys.nc, stream);
 				else launch_coarse_finish(d_coarse[0].data(), d_coarse[2].data(), 6 * sys.cl * sys.nc, stream);
 				coarseValid = true; cntCoarseRefresh++; cntCoarseInline++; sideAge = 0;
-				if (coarseFirstReuse)
+				if (heuristics)
 				{
 					// every run keeps ONE schedule of overlapped inversions -- under trial 1, 1 + period, ... --, whether its first solve was
 					// given an in-line inverse (here: the first run on a structure; the sweep under trial 1 then repeats this inversion) or
@@ -449,21 +455,15 @@ bool cuba_hip_solver::solveReducedOnce()
 	// first solve on this structure: the usual chunk lengths are ordered at once (the helper thread builds them while this solve runs
 	// on plain launches), longest first -- the first batches of a run are the long ones
 	// (graphs only while this is the one handle of the process: see g_liveHandles)
-	const bool graphs = useGraph && g_liveHandles.load(std::memory_order_relaxed) <= 1;
+	const bool graphs = sc.graphs = useGraph && !sc.batched && g_liveHandles.load(std::memory_order_relaxed) <= 1;
 	if (useGraph && !graphs && (!pcgGraphs.empty() || graphsOrderedFor)) dropPcgGraph();
 	if (graphs && pcgGraphs.empty() && graphsOrderedFor != (const void*)sys.acinv)
 	{
 		for (int c = 64; c >= 4; c /= 2) (void)pcgGraphIfReady(c, maxIter, tol2);
 		graphsOrderedFor = (const void*)sys.acinv;
 	}
-	// Iterations are enqueued in chunks (graphs of 4/8/.../256 iterations; chunk lengths are multiples of 4
-	// because the kernels address their reduction slots by the chunk-local k & 3) and the host looks at the device
-	// stop flag after each batch.  A launch after convergence still costs ~2.5 us per kernel and a look costs a
-	// host round trip, so the first batch is sized from the previous solve of this run.
-	volatile int* hInts = (volatile int*)((char*)h_pinned + 1024);   // fail, iterations done, stop flag: written by the device
-	bool converged = false;
-	int k0 = 0, looks = 0, eagerIters = 0;
-	const auto tSolve0 = Clock::now();
+	sc.hInts = (volatile int*)((char*)h_pinned + 1024);   // fail, iterations done, stop flag: written by the device
+	sc.tSolve0 = Clock::now();
 	// prediction: within an LM run the damping shrinks geometrically and the iteration count grows by a fairly steady
 	// factor from solve to solve, so extrapolate the last two counts of this run
 	// (the larger of a linear and a geometric extrapolation, + 1 for the iteration in which the stop test fires: small graphs grow
@@ -482,14 +482,46 @@ bool cuba_hip_solver::solveReducedOnce()
 	// sliding window that barely moved) most likely does so again: exactly that many iterations, no margin
 	{
 		const size_t k = runIters.size();
-		if (repeatPrediction && k < prevRunIters.size() && std::equal(runIters.begin(), runIters.end(), prevRunIters.begin())) predicted = prevRunIters[k];
+		if (heuristics && k < prevRunIters.size() && std::equal(runIters.begin(), runIters.end(), prevRunIters.begin())) predicted = prevRunIters[k];
 	}
 	// (the last node of every iteration graph runs the stop test on the residual its chunk left: a batch of exactly the needed
 	// length is recognised as converged)
-	int target = (predicted + 3) / 4 * 4;
-	while (k0 < budget && !converged)
+	sc.predicted = predicted;
+	return false;
+}
+
+bool cuba_hip_solver::solveBrokeDown(SolveCtx& sc)
+{
+	lastSolveBrokeDown = true; lastFailCode = sc.hInts[0];
+	cntPcgIters += sc.hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; failDirty = true;
+	// (code 1, a diagonal block that is not positive definite, fails a Cholesky factorisation just the same; code 2 with the
+	// fp32-stored inverse is first repeated with fp64 storage by solveReduced)
+	if (sc.direct && lastFailCode != 1 && !(lastFailCode == 2 && fp32Inverse() && sc.twoLevel))
 	{
-		int todo = std::max(4, std::min(target, budget) - k0);
+		if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);
+		pcgHistory.push_back(-sc.hInts[1]);
+		d_fail.zero(stream); failDirty = false;
+		return solveDirect();
+	}
+	return false;
+}
+
+bool cuba_hip_solver::solveReducedOnce()
+{
+	StageTimer tm(this, 6);
+	SolveCtx sc;
+	if (solveBegin(sc)) return sc.result;
+	const int maxIter = sc.maxIter; const Scalar tol2 = sc.tol2; const bool graphs = sc.graphs; const int predicted = sc.predicted;
+	// Iterations are enqueued in chunks (graphs of 4/8/.../256 iterations; chunk lengths are multiples of 4
+	// because the kernels address their reduction slots by the chunk-local k & 3) and the host looks at the device
+	// stop flag after each batch.  A launch after convergence still costs ~2.5 us per kernel and a look costs a
+	// host round trip, so the first batch is sized from the previous solve of this run.
+	bool converged = false;
+	int k0 = 0, looks = 0, eagerIters = 0;
+	int target = (predicted + 3) / 4 * 4;
+	while (k0 < sc.budget && !converged)
+	{
+		int todo = std::max(4, std::min(target, sc.budget) - k0);
 		while (todo > 0)
 		{
 			int c = 256;
@@ -498,7 +530,7 @@ bool cuba_hip_solver::solveReducedOnce()
 			// batch instead of one per power of two.  Not on the first request -- the reference's timing protocol meets most lengths for
 			// the first time inside its timed part, and an instantiation costs ~2 us per node.
 			// (the exact graph is ordered on the second request and used from the moment it exists)
-			if (graphs && exactBatchGraphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
+			if (graphs && todo > c && todo % 4 == 0 && todo <= 128 && pcgGraphMaxIter == maxIter && pcgGraphTol2 == tol2)
 			{
 				if ((pcgGraphs.count(std::make_pair(todo, (const Scalar*)sys.acinv)) || ++batchRequests[todo] >= 2) && pcgGraphIfReady(todo, maxIter, tol2)) c = todo;
 			}
@@ -516,25 +548,19 @@ bool cuba_hip_solver::solveReducedOnce()
 		}
 		if (!graphs) { launch_pcg_report(sys, stream); noteReport(); }       // (graphs and chunks of plain launches end with this report)
 		waitReport();
-		if (hInts[0] != 0)
-		{
-			lastSolveBrokeDown = true; lastFailCode = hInts[0];
-			cntPcgIters += hInts[1]; coarseValid = false; firstInvValid = false; firstInvPending = false; failDirty = true;
-			// (code 1, a diagonal block that is not positive definite, fails a Cholesky factorisation just the same; code 2 with the
-			// fp32-stored inverse is first repeated with fp64 storage by solveReduced)
-			if (direct && lastFailCode != 1 && !(lastFailCode == 2 && fp32Inverse() && twoLevel))
-			{
-				if (pcgHistory.size() >= 65536) pcgHistory.erase(pcgHistory.begin(), pcgHistory.begin() + 32768);
-				pcgHistory.push_back(-hInts[1]);
-				d_fail.zero(stream); failDirty = false;
-				return solveDirect();
-			}
-			return false;
-		}
-		if (hInts[2] != 0 || hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
+		if (sc.hInts[0] != 0) return solveBrokeDown(sc);
+		if (sc.hInts[2] != 0 || sc.hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
 		target = k0 + ((looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));   // (a batch sized from the run's own history misses by a few iterations at most)
 		looks++; cntPcgLooks++; cntHostLooks++;
 	}
+	sc.converged = converged; sc.k0 = k0; sc.looks = looks; sc.eagerIters = eagerIters;
+	return solveEnd(sc);
+}
+
+bool cuba_hip_solver::solveEnd(SolveCtx& sc)
+{
+	const int maxIter = sc.maxIter; const bool direct = sc.direct; const bool converged = sc.converged;
+	const int k0 = sc.k0, looks = sc.looks, eagerIters = sc.eagerIters, predicted = sc.predicted;
 	const auto tSolve1 = Clock::now();
 	if (std::getenv("CUBA_HIP_DEBUG"))
 	{
@@ -544,9 +570,9 @@ bool cuba_hip_solver::solveReducedOnce()
 		sync();
 		double rz0 = 0; for (Scalar v : part) rz0 += (double)v;
 		std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued (%d as plain launches), %d host looks (prediction %d), lambda %.3e, r0.z0 %.6e, solve %.3f ms, graphs built so far %lld\n",
-			hInts[1], k0, eagerIters, looks, predicted, lambda, rz0, 1e3 * std::chrono::duration<double>(tSolve1 - tSolve0).count(), (long long)gb.builds.load());
+			sc.hInts[1], k0, eagerIters, looks, predicted, lambda, rz0, 1e3 * std::chrono::duration<double>(tSolve1 - sc.tSolve0).count(), (long long)gb.builds.load());
 	}
-	const int itersDone = hInts[1];
+	const int itersDone = sc.hInts[1];
 	cntPcgIters += itersDone; cntPcgEnqueued += k0;
 	if (runIters.empty()) firstSolveIters = itersDone;
 	runIters.push_back(itersDone);
@@ -599,9 +625,9 @@ double cuba_hip_solver::computeScale(double lam)
 	return a + b;
 }
 
-int cuba_hip_solver::optimizeDeviceDecision(int niter, double* chi2Out)
+// ---- the device-decided LM run in steps (shared by cuba_hip_optimize and cuba_hip_optimize_batch) ---------------------------------------
+void cuba_hip_solver::lmRunBegin(LmRun& r, int niter, double* chi2Out)
 {
-	const int maxq = 10;
 	const double tau = 1e-5;
 	if (!h_lmRing)
 	{
@@ -610,64 +636,209 @@ int cuba_hip_solver::optimizeDeviceDecision(int niter, double* chi2Out)
 	}
 	coarseValid = false;
 	startRunHistory();
-	double F = computeErrors();
-	double lam = tau * maxDiagonal();
+	r = LmRun();
+	r.niter = niter; r.chi2Out = chi2Out; r.stop = niter <= 0;
+	r.F = computeErrors();
+	r.lam = tau * maxDiagonal();
 	{
 		double* st8 = reinterpret_cast<double*>(hostStage());          // (pinned staging block)
-		st8[0] = F; st8[1] = lam; st8[2] = 2.0; st8[3] = 0.0; st8[4] = 0.0; st8[5] = 1.0; st8[6] = 0.0; st8[7] = (double)maxq;
+		st8[0] = r.F; st8[1] = r.lam; st8[2] = 2.0; st8[3] = 0.0; st8[4] = 0.0; st8[5] = 1.0; st8[6] = 0.0; st8[7] = (double)LmRun::maxq;
 		Scalar* l1 = reinterpret_cast<Scalar*>(st8 + 8);
-		l1[0] = (Scalar)lam;
+		l1[0] = (Scalar)r.lam;
 		HIP_TRY(hipMemcpyAsync(d_lmState.data(), st8, sizeof(double) * 8, hipMemcpyHostToDevice, stream));
 		HIP_TRY(hipMemcpyAsync(d_lamS.data(), l1, sizeof(Scalar), hipMemcpyHostToDevice, stream));
 	}
-	LmDevice lm; lm.state = d_lmState.data(); lm.lam = d_lamS.data(); lm.ring = lmRingDev;
-	int enq = 0, seen = 0, done = 0, rejRun = 0;
-	bool stop = niter <= 0;
-	// outcomes of the trials [seen, upto): every one of them is complete (the caller has waited for a report that follows them in the stream)
-	auto absorb = [&](int upto) {
-		std::atomic_thread_fence(std::memory_order_acquire);
-		for (; seen < upto && !stop; seen++)
-		{
-			const volatile double* r = h_lmRing + (size_t)(seen % LM_RING) * LM_REC;
-			const bool acc = r[5] != 0.0;
-			const double rho = r[2];
-			lam = r[3]; F = r[4];
-			if (acc) rejRun = 0; else rejRun++;
-			// the reference's loops: an iteration ends with an accepted trial, with the maxq-th rejection, or with a rejected trial whose
-			// rho is not < 0; the run ends after niter iterations, or on `qn == maxq || rho <= 0 || !isfinite(lambda)` (:851)
-			const bool iterationEnds = acc || rejRun == maxq || !(rho < 0);
-			if (!iterationEnds) continue;
-			if (chi2Out) chi2Out[done] = F;
-			done++;
-			if (done == niter || rejRun == maxq || rho <= 0 || !std::isfinite(lam)) stop = true;
-			rejRun = 0;
-		}
-	};
-	while (!stop)
+	r.lm.state = d_lmState.data(); r.lm.lam = d_lamS.data(); r.lm.ring = lmRingDev;
+}
+
+// outcomes of the trials [seen, upto): every one of them is complete (the caller has waited for a report that follows them in the stream)
+void cuba_hip_solver::lmAbsorb(LmRun& r, int upto)
+{
+	std::atomic_thread_fence(std::memory_order_acquire);
+	for (; r.seen < upto && !r.stop; r.seen++)
 	{
-		if (enq > seen)
-		{
-			// trial enq - 1 is still undecided as far as the host knows.  Trial enq is needed whatever its outcome -- unless that
-			// outcome can end the run: the last iteration, or the maxq-th rejection in a row
-			const bool safe = done + 1 < niter && rejRun + 1 < maxq;
-			if (!safe) { waitReport(); cntHostLooks++; absorb(enq); if (stop) break; }
-		}
-		cntTrials++;
-		lambda = -1.0;                 // (every kernel of the trial reads the damping from device memory: launch_lambda)
-		schur(true);
-		const bool ok = solveReduced();        // (its looks follow every earlier trial's decision in the stream)
-		absorb(enq);
-		if (stop) { cntTrials--; break; }      // (an outcome nobody could foresee ended the run: the device has halted, this trial is void)
-		if (ok) launch_trial_tail_fused(g, st, sys, (Scalar)-1, d_backup.data(), stream, &lm);
-		else launch_lm_decide_failed(sys, lm, stream);
-		noteReport();
-		launch_restore_if_rejected(d_state.data(), d_backup.data(), d_state.size(), lm, stream);
-		enq++;
-		(void)hipStreamQuery(stream);
+		const volatile double* rec = h_lmRing + (size_t)(r.seen % LM_RING) * LM_REC;
+		const bool acc = rec[5] != 0.0;
+		const double rho = rec[2];
+		r.lam = rec[3]; r.F = rec[4];
+		if (acc) r.rejRun = 0; else r.rejRun++;
+		// the reference's loops: an iteration ends with an accepted trial, with the maxq-th rejection, or with a rejected trial whose
+		// rho is not < 0; the run ends after niter iterations, or on `qn == maxq || rho <= 0 || !isfinite(lambda)` (:851)
+		const bool iterationEnds = acc || r.rejRun == LmRun::maxq || !(rho < 0);
+		if (!iterationEnds) continue;
+		if (r.chi2Out) r.chi2Out[r.done] = r.F;
+		r.done++;
+		if (r.done == r.niter || r.rejRun == LmRun::maxq || rho <= 0 || !std::isfinite(r.lam)) r.stop = true;
+		r.rejRun = 0;
 	}
-	if (seen < enq) { waitReport(); cntHostLooks++; absorb(enq); }
-	lambda = lam;
-	return done;
+}
+
+// before trial r.enq is enqueued: false = the run has ended
+bool cuba_hip_solver::lmBeforeTrial(LmRun& r)
+{
+	if (r.stop) return false;
+	if (r.enq > r.seen)
+	{
+		// trial enq - 1 is still undecided as far as the host knows.  Trial enq is needed whatever its outcome -- unless that
+		// outcome can end the run: the last iteration, or the maxq-th rejection in a row
+		const bool safe = r.done + 1 < r.niter && r.rejRun + 1 < LmRun::maxq;
+		if (!safe) { waitReport(); cntHostLooks++; lmAbsorb(r, r.enq); if (r.stop) return false; }
+	}
+	cntTrials++;
+	lambda = -1.0;                 // (every kernel of the trial reads the damping from device memory: launch_lambda)
+	return true;
+}
+
+// after the reduced solve of trial r.enq (whose host looks follow every earlier trial's decision in the stream): false = the run has ended
+bool cuba_hip_solver::lmAfterSolve(LmRun& r, bool ok)
+{
+	lmAbsorb(r, r.enq);
+	if (r.stop) { cntTrials--; return false; }      // (an outcome nobody could foresee ended the run: the device has halted, this trial is void)
+	if (ok) launch_trial_tail_fused(g, st, sys, (Scalar)-1, d_backup.data(), stream, &r.lm);
+	else launch_lm_decide_failed(sys, r.lm, stream);
+	noteReport();
+	launch_restore_if_rejected(d_state.data(), d_backup.data(), d_state.size(), r.lm, stream);
+	r.enq++;
+	(void)hipStreamQuery(stream);
+	return true;
+}
+
+int cuba_hip_solver::lmRunEnd(LmRun& r)
+{
+	if (r.seen < r.enq) { waitReport(); cntHostLooks++; lmAbsorb(r, r.enq); }
+	lambda = r.lam;
+	return r.done;
+}
+
+int cuba_hip_solver::optimizeDeviceDecision(int niter, double* chi2Out)
+{
+	LmRun r;
+	lmRunBegin(r, niter, chi2Out);
+	while (lmBeforeTrial(r))
+	{
+		schur(true);
+		const bool ok = solveReduced();
+		if (!lmAfterSolve(r, ok)) break;
+	}
+	return lmRunEnd(r);
+}
+
+bool cuba_hip_solver::batchable() const
+{
+	return !profile && partHi < 0 && Pf > 0 && Lf > 0 && E > 0 && trial_tail_parts(g, st) <= d_parts.size() && batch_kernel_class(g, sys) >= 0;
+}
+
+// Several graphs, one launch chain (include/cuba_hip.h: cuba_hip_optimize_batch).  Every handle runs ITS OWN Levenberg-Marquardt loop --
+// decisions on the device, per graph -- and everything of a trial but the PCG iterations on its own stream (linearise + Schur, set-up
+// launch, coarse inverse, trial tail: they overlap across the streams); the iterations of all graphs go out as ONE chain of batched
+// launches (blockIdx.y = graph, kernel arguments from a device table) on the first handle's stream, joined and forked by events.  Per
+// graph the kernels, their arguments and their order are those of cuba_hip_optimize: results are bit-identical to the solo runs.  A graph
+// whose solve has converged returns at once from the iterations the others still need (its device-side stop flag), a graph whose run has
+// ended leaves the batch.  The host issues 2 launches per iteration for the whole batch instead of 2 per graph -- it is the host's launch
+// rate, not the GPU, that bounds several handles driven side by side.
+int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double* chi2, int* nDone)
+{
+	bool together = n > 1;
+	for (int i = 0; i < n; i++) hs[i]->need();
+	for (int i = 0; i < n && together; i++)
+		together = hs[i]->batchable() && hs[i]->device == hs[0]->device && batch_kernel_class(hs[i]->g, hs[i]->sys) == batch_kernel_class(hs[0]->g, hs[0]->sys) &&
+			hs[i]->pcgTol == hs[0]->pcgTol && (i == 0 || hs[i]->stream != hs[0]->stream);
+	if (!together)
+	{
+		for (int i = 0; i < n; i++) nDone[i] = hs[i]->optimize(niter, chi2 ? chi2 + (size_t)i * niter : nullptr);
+		return 0;
+	}
+	cuba_hip_solver* lead = hs[0];
+	hipStream_t bs = lead->stream;
+	std::vector<cuba_hip_solver::LmRun> runs((size_t)n);
+	std::vector<cuba_hip_solver::SolveCtx> ctx((size_t)n);
+	std::vector<hipEvent_t>& evJoin = lead->batchEvents;
+	while ((int)evJoin.size() < n + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evJoin.push_back(e); }
+	hipEvent_t evFork = evJoin[n];
+	if (!lead->h_batchTab) HIP_TRY(hipHostMalloc((void**)&lead->h_batchTab, sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX, hipHostMallocDefault));
+	lead->d_batchTab.resize(sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX);
+	BatchEntry* hTab = lead->h_batchTab;
+	const BatchEntry* dTab = reinterpret_cast<const BatchEntry*>(lead->d_batchTab.data());
+	for (int i = 0; i < n; i++) hs[i]->lmRunBegin(runs[i], niter, chi2 ? chi2 + (size_t)i * niter : nullptr);
+	std::vector<int> act, inPcg;
+	std::vector<char> okv((size_t)n);
+	int batchSolves = 0;
+	for (;;)
+	{
+		act.clear();
+		for (int i = 0; i < n; i++) if (hs[i]->lmBeforeTrial(runs[i])) act.push_back(i);
+		if (act.empty()) break;
+		// linearise + Schur and the front half of the reduced solve, each graph on its own stream
+		inPcg.clear();
+		for (int i : act)
+		{
+			hs[i]->schur(true);
+			ctx[i] = cuba_hip_solver::SolveCtx(); ctx[i].batched = true;
+			if (hs[i]->solveBegin(ctx[i])) okv[i] = ctx[i].result; else inPcg.push_back(i);
+		}
+		if (!inPcg.empty())
+		{
+			const int m = (int)inPcg.size();
+			int gridSpmvMax = 0, ncMax = 0; size_t ldsMax = 0; int target = 4, budgetMax = 0;
+			for (int a = 0; a < m; a++)
+			{
+				cuba_hip_solver* h = hs[inPcg[a]];
+				BatchEntry& e = hTab[a];
+				e.g = h->g; e.st = h->st; e.sys = h->sys; e.maxIter = ctx[inPcg[a]].maxIter;
+				e.gridSpmv = (h->g.Pf + h->sys.spmv_rows - 1) / h->sys.spmv_rows;
+				gridSpmvMax = std::max(gridSpmvMax, e.gridSpmv); ncMax = std::max(ncMax, h->sys.nc); ldsMax = std::max(ldsMax, batch_pcg2_lds_bytes(h->sys));
+				target = std::max(target, (ctx[inPcg[a]].predicted + 3) / 4 * 4); budgetMax = std::max(budgetMax, ctx[inPcg[a]].budget);
+				if (h != lead) { HIP_TRY(hipEventRecord(evJoin[a], h->stream)); HIP_TRY(hipStreamWaitEvent(bs, evJoin[a], 0)); }
+			}
+			HIP_TRY(hipMemcpyAsync(lead->d_batchTab.data(), hTab, sizeof(BatchEntry) * m, hipMemcpyHostToDevice, bs));
+			const Scalar tol2 = ctx[inPcg[0]].tol2;
+			int k0 = 0, looks = 0;
+			std::vector<char> conv((size_t)m, 0), broke((size_t)m, 0);
+			bool all = false;
+			while (k0 < budgetMax && !all)
+			{
+				int todo = std::max(4, std::min(target, budgetMax) - k0);
+				while (todo > 0)
+				{
+					int c = 256;
+					for (; c > 4 && c > todo; c >>= 1) {}
+					// chunk-local iteration numbers + the advance / stop test / report launch, as a lone handle enqueues a chunk it has no hipGraph for
+					for (int k = 0; k < c; k++) launch_pcg_batch_iteration(dTab, m, lead->g, lead->sys, gridSpmvMax, ncMax, ldsMax, k, tol2, bs);
+					launch_pcg_batch_advance(dTab, m, c, bs, tol2);
+					for (int a = 0; a < m; a++) hs[inPcg[a]]->noteReport();
+					k0 += c; todo -= c;
+				}
+				all = true;
+				for (int a = 0; a < m; a++)
+				{
+					cuba_hip_solver* h = hs[inPcg[a]];
+					h->waitReport();
+					const volatile int* f = ctx[inPcg[a]].hInts;
+					if (f[0] != 0) broke[a] = 1;
+					else if (f[2] != 0 || f[1] < std::min(k0, ctx[inPcg[a]].maxIter)) conv[a] = 1;
+					if (!broke[a] && !conv[a] && k0 < ctx[inPcg[a]].budget) all = false;
+					h->cntPcgLooks++; h->cntHostLooks++;
+				}
+				target = k0 + ((looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));
+				looks++;
+			}
+			// back to the graphs' own streams
+			HIP_TRY(hipEventRecord(evFork, bs));
+			for (int a = 0; a < m; a++)
+			{
+				const int i = inPcg[a];
+				cuba_hip_solver* h = hs[i];
+				if (h != lead) HIP_TRY(hipStreamWaitEvent(h->stream, evFork, 0));
+				cuba_hip_solver::SolveCtx& sc = ctx[i];
+				sc.k0 = std::min(k0, std::max(sc.budget, 4)); sc.looks = looks; sc.eagerIters = 0; sc.converged = conv[a] != 0;
+				okv[i] = h->retryWithFp64Inverse(broke[a] ? h->solveBrokeDown(sc) : h->solveEnd(sc));
+			}
+			batchSolves++;
+		}
+		for (int i : act) (void)hs[i]->lmAfterSolve(runs[i], okv[i] != 0);
+	}
+	for (int i = 0; i < n; i++) nDone[i] = hs[i]->lmRunEnd(runs[i]);
+	return batchSolves;
 }
 
 int cuba_hip_solver::optimize(int niter, double* chi2Out)
@@ -675,7 +846,9 @@ int cuba_hip_solver::optimize(int niter, double* chi2Out)
 	lap(nullptr);
 	need();
 	lap("optimize: structure ready");
-	if (deviceDecision && !profile && partHi < 0 && fusedTail && Pf > 0 && Lf > 0 && E > 0 && trial_tail_parts(g, st) <= d_parts.size())
+	// the default: the decision of every trial on the device, the trial's tail fused into one pass over the edges.  The host loop below
+	// serves the profiled run (every stage synchronises), landmark partitions (the sums need the other ranks) and the degenerate graphs.
+	if (!profile && partHi < 0 && Pf > 0 && Lf > 0 && E > 0 && trial_tail_parts(g, st) <= d_parts.size())
 		return optimizeDeviceDecision(niter, chi2Out);
 	coarseValid = false;          // a new LM run starts from a new lambda_0: never reuse the coarse inverse across runs
 	startRunHistory();
@@ -697,24 +870,8 @@ int cuba_hip_solver::optimize(int niter, double* chi2Out)
 			schur(true);          // (with the push() of the reference's loop: the backup of the state rides in the landmark pass's launch)
 			const bool ok = solveReduced();
 			double Fhat = 0, scale = 0;
-			if (ok && !profile && partHi < 0 && fusedTail && trial_tail_parts(g, st) <= d_parts.size())
-			{
-				// back-substitution + update + evaluation in one pass over the edges (reads the pre-trial estimate from the backup
-				// schur(true) has just made), then sums + report: two launches, one host look
-				launch_trial_tail_fused(g, st, sys, (Scalar)lam, d_backup.data(), stream); noteReport();
-				readEvaluate(true, &Fhat, &scale);
-			}
-			else if (ok && !profile && partHi < 0 && (size_t)st.nWaves + st.nBig + 64 + 3072 <= d_parts.size())
-			{
-				// back-substitution, update, evaluation, sums and report in four launches, one host look
-				launch_trial_tail(g, st, sys, (Scalar)lam, stream); noteReport();
-				readEvaluate(true, &Fhat, &scale);
-			}
-			else
-			{
-				if (ok) { backSubstitute(); update(); }
-				evaluateTrial(lam, ok, &Fhat, &scale);                  // chi2 at the trial estimate + gain-ratio denominator, one host look
-			}
+			if (ok) { backSubstitute(); update(); }
+			evaluateTrial(lam, ok, &Fhat, &scale);                  // chi2 at the trial estimate + gain-ratio denominator, one host look
 			scale += 1e-3;
 			rho = ok ? (F - Fhat) / scale : -1;
 			if (rho > 0)

@@ -229,8 +229,8 @@ __device__ __forceinline__ void spmv_batch(const DeviceSystem& sys, const Scalar
 // waves at occupancy 3 -- at S2M / G4M size the kernel is bound by waves in flight x latency -- not at KITTI-00 size.
 // ROWS = block rows per workgroup (2 or 4): more rows per workgroup mean fewer row-sum partials for the two-level kernel
 // to add up (large graphs), fewer rows mean more workgroups to spread over the CUs (small graphs).
-template <int ROWS, int MIN_WAVES>
-__global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+template <int ROWS>
+__device__ __forceinline__ void pcg_spmv_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int half = wv & 1, lr = wv >> 1;          // the two waves of a row take 10 of its 20 entry slots each
@@ -339,6 +339,22 @@ __global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceG
 	}
 	TRACE_MARK();
 	TRACE_FLUSH(0, blockIdx.x * 2 * ROWS + wv);
+}
+
+template <int ROWS, int MIN_WAVES>
+__global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, int k, int maxIter, Scalar tol2)
+{
+	pcg_spmv_body<ROWS>(g, st, sys, k, maxIter, tol2);
+}
+
+// Batched form (cuba_hip_optimize_batch): blockIdx.y selects the graph, whose kernel arguments come from a device table instead of the
+// kernel-argument segment; workgroups beyond the graph's own grid return at once.  Same body, same arithmetic, same bits.
+template <int ROWS, int MIN_WAVES>
+__global__ __launch_bounds__(128 * ROWS, MIN_WAVES) void pcg_spmv_batch_kernel(const BatchEntry* __restrict__ tab, int k, Scalar tol2)
+{
+	const BatchEntry& e = tab[blockIdx.y];
+	if ((int)blockIdx.x >= e.gridSpmv) return;
+	pcg_spmv_body<ROWS>(e.g, e.st, e.sys, k, e.maxIter, tol2);
 }
 
 // One wave per block row (large graphs).  With two waves per row S2M / G4M need 10 000 / 20 000 waves of ~5 KB each, i.e.
@@ -551,8 +567,8 @@ template <typename T> struct InvVec<T, 4> { typedef T type __attribute__((ext_ve
 // PRE = true: the preconditioner alone -- third launch of the upper-triangle iteration (large graphs, below): the residual and P^T r
 // of iteration k + 1 are already in place (pcg_rows_kernel), so this instantiation only applies M^-1 to them and forms r.z
 // (doUpdate = 1 at run time; alpha = 0, no partial sums of P^T q, nothing of x / r / P^T r is stored).
-template <int CL, int AC, int AC2, int W, bool PRE = false>
-__global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
+template <int CL, int AC, int AC2, int W, bool PRE>
+__device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
 	constexpr int QV = 16;             // SpMV-workgroup partials prefetched per coarse unknown
@@ -829,6 +845,20 @@ __global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, Devic
 	}
 	TRACE_MARK();
 	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
+}
+
+template <int CL, int AC, int AC2, int W, bool PRE = false>
+__global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
+{
+	pcg2_fused_body<CL, AC, AC2, W, PRE>(g, sys, k, kOut, maxIter, tol2, doUpdate);
+}
+
+template <int CL, int AC, int AC2, int W>
+__global__ __launch_bounds__(PCG2_T) void pcg2_fused_batch_kernel(const BatchEntry* __restrict__ tab, int k, int kOut, Scalar tol2, int doUpdate)
+{
+	const BatchEntry& e = tab[blockIdx.y];
+	if ((int)blockIdx.x >= e.sys.nc) return;
+	pcg2_fused_body<CL, AC, AC2, W, false>(e.g, e.sys, k, kOut, e.maxIter, tol2, doUpdate);
 }
 
 template <bool PRE>
@@ -1201,7 +1231,7 @@ void launch_pcg_update(const DeviceGraph& g, const DeviceStructure& st, const De
 // (one wave.  tol2 >= 0: the node also runs the stop test on the residual the chunk's last iteration left -- r.z of iteration
 // kbase + n lives in the ring slot of chunk-local index 0, chunk lengths being multiples of 4 -- so that a batch of exactly as many
 // iterations as the solve needs is recognised as converged without a further iteration launch)
-__global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n, int report, Scalar tol2)
+__device__ __forceinline__ void pcg_advance_body(const DeviceSystem& sys, int n, int report, Scalar tol2)
 {
 	if (tol2 >= 0 && n > 0)
 	{
@@ -1221,6 +1251,13 @@ __global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n
 		__threadfence_system();
 		sys.host_flags[3] = ++(*sys.ticket);      // the host spins on this word instead of paying a stream-synchronise round trip
 	}
+}
+
+__global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n, int report, Scalar tol2) { pcg_advance_body(sys, n, report, tol2); }
+
+__global__ __launch_bounds__(64) void pcg_advance_batch_kernel(const BatchEntry* __restrict__ tab, int n, int report, Scalar tol2)
+{
+	pcg_advance_body(tab[blockIdx.x].sys, n, report, tol2);
 }
 
 // {chi2, landmark part of the gain-ratio denominator, pose part} of the evaluation just enqueued -> three device scalars
@@ -1243,6 +1280,46 @@ void launch_pcg_report(const DeviceSystem& sys, hipStream_t s)
 void launch_pcg_advance(const DeviceSystem& sys, int n, hipStream_t s, Scalar tol2)
 {
 	hipLaunchKernelGGL(pcg_advance_kernel, dim3(1), dim3(64), 0, s, sys, n, 1, tol2);
+}
+
+// ---- batched execution: one launch chain for the PCG iterations of several graphs (cuba_hip_optimize_batch) ---------------------------
+// Every graph of a batch must use the same instantiations of the two iteration kernels (they are chosen by the graph's size class:
+// coarse dimension, storage of the coarse inverse, SpMV occupancy) and the two-launch iteration; batch_kernel_class() names the class.
+template <int CL, int AC, int AC2, int W>
+static void* pcg2_batch_fn() { return (void*)pcg2_fused_batch_kernel<CL, AC, AC2, W>; }
+static void* pcg2_batch_kernel_for(const DeviceSystem& sys)
+{
+	const int Nc = 6 * sys.cl * sys.nc;
+	if (sys.acinv32 && sizeof(Scalar) == 8)
+	{
+		if (sys.cl == 2) return Nc <= 768 ? pcg2_batch_fn<2, 3, 0, 4>() : Nc <= 1536 ? pcg2_batch_fn<2, 6, 0, 4>() : pcg2_batch_fn<2, 6, 3, 4>();
+		return Nc <= 768 ? pcg2_batch_fn<1, 3, 0, 4>() : Nc <= 1536 ? pcg2_batch_fn<1, 6, 0, 4>() : pcg2_batch_fn<1, 6, 3, 4>();
+	}
+	const bool small = Nc <= 768;
+	if (sys.cl == 2) return small ? pcg2_batch_fn<2, 6, 0, 2>() : pcg2_batch_fn<2, 12, 6, 2>();
+	return small ? pcg2_batch_fn<1, 6, 0, 2>() : pcg2_batch_fn<1, 12, 6, 2>();
+}
+
+int batch_kernel_class(const DeviceGraph& g, const DeviceSystem& sys)
+{
+	if (sys.agg <= 0 || sys.upper || sys.spmv_rows != 2) return -1;          // (block-Jacobi-only, upper-triangle and row-per-wave iterations run one graph at a time)
+	const int Nc = 6 * sys.cl * sys.nc;
+	const int cls = (sys.acinv32 && sizeof(Scalar) == 8) ? (Nc <= 768 ? 0 : Nc <= 1536 ? 1 : 2) : (Nc <= 768 ? 3 : 4);
+	return (cls * 2 + (sys.cl == 2 ? 1 : 0)) * 2 + (spmv_wants_occupancy(g) ? 1 : 0);
+}
+
+size_t batch_pcg2_lds_bytes(const DeviceSystem& sys) { return pcg2_lds_bytes(sys); }
+
+void launch_pcg_batch_iteration(const BatchEntry* tab, int n, const DeviceGraph& g0, const DeviceSystem& sys0, int gridSpmvMax, int ncMax, size_t ldsMax, int k, Scalar tol2, hipStream_t s)
+{
+	void* spmv = spmv_wants_occupancy(g0) ? (void*)pcg_spmv_batch_kernel<2, 4> : (void*)pcg_spmv_batch_kernel<2, 1>;
+	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, Scalar))spmv, dim3(gridSpmvMax, n), dim3(256), 0, s, tab, k, tol2);
+	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(PCG2_T), ldsMax, s, tab, k, k + 1, tol2, 1);
+}
+
+void launch_pcg_batch_advance(const BatchEntry* tab, int n, int iters, hipStream_t s, Scalar tol2)
+{
+	hipLaunchKernelGGL(pcg_advance_batch_kernel, dim3(n), dim3(64), 0, s, tab, iters, 1, tol2);
 }
 
 void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, int k, int maxIter, Scalar tol2, hipStream_t s)

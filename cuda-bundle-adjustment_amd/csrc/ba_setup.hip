@@ -591,9 +591,20 @@ cuba_hip_solver::CoarseCfg cuba_hip_solver::coarseConfig() const
 	int nc = agg > 0 ? (Pf + agg - 1) / agg : 0;
 	// the two-level kernel keeps two coarse vectors in LDS and the dense inverse costs O(Nc^3): a user-chosen aggregate
 	// that small for this many poses is widened
-	while (agg > 0 && (cl * nc > 600 || sizeof(Scalar) * (12 * (size_t)cl * nc + 12 * (size_t)agg + 200) > 60 * 1024)) { agg *= 2; nc = (Pf + agg - 1) / agg; }
+	// (round 6: this used to be one loop that doubled the aggregate until BOTH conditions held -- which never happens once the aggregate's
+	// own 12 agg numbers exceed the LDS budget (a user-chosen aggregate above ~600 poses, or the automatic one beyond ~47 000 poses): the
+	// doubling ran until the integer overflowed and the division below trapped.  Now: widen for the coarse dimension only, cap the
+	// aggregate at 600 poses, and when the two vectors + the aggregate's rows still do not fit, fall back to constant coarse functions
+	// (half the coarse dimension) and finally to block-Jacobi alone.)
+	int clOut = cl;
+	auto ldsFits = [&](int c, int n, int a) { return sizeof(Scalar) * (12 * (size_t)c * n + 12 * (size_t)a + 200) <= 60 * 1024; };
+	if (agg > 600) agg = 600 / spmvRows * spmvRows;
+	if (agg > 0) nc = (Pf + agg - 1) / agg;
+	while (agg > 0 && agg < 600 && (clOut * nc > 600 || !ldsFits(clOut, nc, agg))) { agg = std::min(600 / spmvRows * spmvRows, agg * 2); nc = (Pf + agg - 1) / agg; }
+	if (agg > 0 && (clOut * nc > 600 || !ldsFits(clOut, nc, agg)) && clOut == 2) clOut = 1;
+	if (agg > 0 && (clOut * nc > 600 || !ldsFits(clOut, nc, agg))) { agg = 0; nc = 0; }
 	if (nc < 2) { agg = 0; nc = 0; }
-	return CoarseCfg{ agg, cl, nc, spmvRows };
+	return CoarseCfg{ agg, agg > 0 ? clOut : cl, nc, spmvRows };
 }
 
 void cuba_hip_solver::allocSystem(int nblk, const CoarseCfg& c)

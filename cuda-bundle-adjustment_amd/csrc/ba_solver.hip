@@ -124,10 +124,7 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		const std::string k(key);
 		if (k == "pcg_tol") s->pcgTol = value;
 		else if (k == "pcg_max_iter") { s->pcgMaxIter = (int)value; s->haveStructure = false; }
-		else if (k == "fused_tail") s->fusedTail = value != 0;
-		else if (k == "pcg_exact_batch_graphs") s->exactBatchGraphs = value != 0;
-		else if (k == "pcg_repeat_prediction") s->repeatPrediction = value != 0;
-		else if (k == "coarse_first_reuse") { s->coarseFirstReuse = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
+		else if (k == "heuristics") { s->heuristics = value != 0; s->firstInvValid = false; s->firstInvPending = false; }
 		else if (k == "precond_fp32") { s->precondFp32 = value != 0; s->haveStructure = false; s->coarseValid = false; s->dropPcgGraph(); }
 		else if (k == "pose_reorder") { s->poseReorder = value != 0; s->haveStructure = false; }
 		else if (k == "device_setup") { s->deviceSetup = value != 0; s->haveStructure = false; }
@@ -144,7 +141,6 @@ int cuba_hip_set_option(cuba_hip_solver* s, const char* key, double value)
 		}
 		else if (k == "pcg_aggregate") { s->pcgAggregate = (int)value; s->haveStructure = false; }
 		else if (k == "coarse_linear") { s->coarseLinear = value != 0; s->haveStructure = false; }
-		else if (k == "device_lm_decision") s->deviceDecision = value != 0;
 		else if (k == "landmark_reorder") s->lmReorder = value != 0;         // (takes effect with the next cuba_hip_set_graph)
 		else if (k == "reduction_chunks")
 		{
@@ -290,6 +286,22 @@ int cuba_hip_optimize(cuba_hip_solver* s, int niterations, double* chi2_per_iter
 		if (niterations < 0) throw ArgError{ "negative iteration count" };
 		const int n = s->optimize(niterations, chi2_per_iter);
 		if (n_done) *n_done = n;
+	});
+}
+
+int cuba_hip_optimize_batch(cuba_hip_solver** handles, int n, int niterations, double* chi2_per_iter, int* n_done, int* batched_solves)
+{
+	if (!handles || n <= 0 || n > CUBA_HIP_BATCH_MAX || !n_done) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	for (int i = 0; i < n; i++)
+	{
+		if (!handles[i]) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+		for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return CUBA_HIP_ERR_INVALID_ARGUMENT;
+	}
+	// (an error is recorded on the first handle: cuba_hip_last_error(handles[0]))
+	return guarded(handles[0], [&] {
+		if (niterations < 0) throw ArgError{ "negative iteration count" };
+		const int b = cuba_hip_optimize_batch_impl(handles, n, niterations, chi2_per_iter, n_done);
+		if (batched_solves) *batched_solves = b;
 	});
 }
 

@@ -105,8 +105,13 @@ using Clock = std::chrono::steady_clock;
 // keeps a second handle from adding graphs of its own.
 extern std::atomic<int> g_liveHandles;
 
+constexpr int CUBA_HIP_BATCH_MAX = 64;       // graphs per cuba_hip_optimize_batch call
+
 }  // namespace cubahip_host
 using namespace cubahip_host;
+
+struct cuba_hip_solver;
+int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double* chi2, int* nDone);
 
 struct cuba_hip_solver
 {
@@ -215,7 +220,8 @@ struct cuba_hip_solver
 	// under that solve like every other.  A preconditioner only changes iteration counts; results stay a deterministic function of the
 	// call sequence (and identical when a run is repeated from the same estimate: the cached inverse IS the fresh one then).
 	DevBuf<Scalar> d_firstInv; DevBuf<float> d_firstInv32;
-	bool firstInvValid = false, firstInvPending = false, coarseFirstReuse = true;
+	bool firstInvValid = false, firstInvPending = false;
+	bool heuristics = true;     // option "heuristics": the two run-to-run memories (first solve's coarse inverse of the previous run, repeat prediction of the batch lengths)
 	bool precondFp32 = sizeof(Scalar) == 8;
 	bool fp32Inverse() const { return precondFp32 && sizeof(Scalar) == 8; }
 	size_t inv32Count() const { const size_t n = (size_t)6 * sys.cl * sys.nc; return n * ((n + 3) & ~(size_t)3); }
@@ -244,7 +250,7 @@ struct cuba_hip_solver
 	// (graphs are kept per chunk length -- 4, 8, ..., 256 and the exact batch lengths that come back)
 	std::map<std::pair<int, const Scalar*>, hipGraphExec_t> pcgGraphs;   // key: chunk length, coarse inverse the kernels read
 	bool useGraph = graphsByDefault();
-	static bool graphsByDefault() { const char* e = std::getenv("CUBA_HIP_GRAPHS"); return !(e && e[0] == '0'); }
+	static bool graphsByDefault() { const char* e = std::getenv("CUBA_HIP_GRAPHS"); return e && e[0] == '1'; }      // opt-in (round 6)
 	hipStream_t captureStream = nullptr;   // private stream used only by time_kernels to record timing graphs (the work stream may be the
 	                                       // legacy default stream, which cannot be captured)
 	hipStream_t capStream()
@@ -276,8 +282,6 @@ struct cuba_hip_solver
 	hipGraphExec_t pcgGraphIfReady(int chunk, int maxIter, Scalar tol2);
 	void dropPcgGraph();
 	std::map<int, int> batchRequests;      // how often a batch of this length was asked for since the graphs were dropped
-	bool exactBatchGraphs = true;          // option "pcg_exact_batch_graphs"
-	bool repeatPrediction = true;          // option "pcg_repeat_prediction"
 
 	void enqueuePcgIteration(int k, int maxIter, Scalar tol2, hipStream_t s)
 	{
@@ -357,6 +361,8 @@ struct cuba_hip_solver
 		if (evTileInputs) (void)hipEventDestroy(evTileInputs);
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (h_lmRing) (void)hipHostFree(h_lmRing);
+		if (h_batchTab) (void)hipHostFree(h_batchTab);
+		for (hipEvent_t e : batchEvents) (void)hipEventDestroy(e);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
 	}
 
@@ -367,7 +373,6 @@ struct cuba_hip_solver
 	bool failDirty = true;       // the device-side failure flag of the PCG may be non-zero
 	int expectedTicket = 0;
 	bool hintSameEdges = false, hintSameValues = false;   // cuba_hip_hint_unchanged: promises about the next set_graph call
-	bool fusedTail = true;       // optimize(): back-substitution, update and evaluation of a trial in one pass over the edges (option "fused_tail")
 	void noteReport() { expectedTicket++; }
 	void waitReport();
 
@@ -595,7 +600,7 @@ struct cuba_hip_solver
 	// reference).
 	bool directFallback = true;         // option "direct_fallback"
 	bool directAlways = false;          // option "reduced_solver" = 1
-	int directAfter = 0;                // option "direct_after": PCG iterations a solve may use before it is handed over; 0 = automatic (128)
+	int directAfter = 0;                // option "direct_after": PCG iterations a solve may use before it is handed over; 0 = automatic (Pf / 4 in 128 ... 384)
 	int directMaxTiles = 1 << 20;       // option "direct_max_tiles" (2^20 tiles = 16 GiB of factor in fp64)
 	int directSlack = -1;               // option "direct_slack": multiple-elimination slack of the ordering, -1 = automatic
 	bool directSticky = false;          // a solve of the current run went to the exact solver: the run's remaining solves go there at once
@@ -612,7 +617,20 @@ struct cuba_hip_solver
 	bool ensureDirectPlan();
 	bool solveDirect();
 
+	struct SolveCtx
+	{
+		int maxIter = 0, budget = 0, predicted = 32, k0 = 0, looks = 0, eagerIters = 0;
+		Scalar tol2 = 0;
+		bool twoLevel = false, direct = false, graphs = false, converged = false, result = false;
+		bool batched = false;               // the iterations run in another handle's launch chain (cuba_hip_optimize_batch): no hipGraphs
+		volatile int* hInts = nullptr;
+		Clock::time_point tSolve0;
+	};
+	bool solveBegin(SolveCtx& sc);
+	bool solveBrokeDown(SolveCtx& sc);
+	bool solveEnd(SolveCtx& sc);
 	bool solveReducedOnce();
+	bool retryWithFp64Inverse(bool ok);
 
 	void backSubstitute();
 
@@ -634,7 +652,25 @@ struct cuba_hip_solver
 	// records, at the look its next reduced solve needs anyway.  One host look per trial instead of two; only a trial whose outcome may
 	// END the run (last iteration, tenth rejection in a row) is waited for.  Same arithmetic as the host loop, bit for bit.
 	int optimizeDeviceDecision(int niter, double* chi2Out);
-	bool deviceDecision = true;         // option "device_lm_decision"
+	// (the same run in steps: cuba_hip_optimize_batch interleaves the steps of several handles and batches their PCG iterations)
+	struct LmRun
+	{
+		static constexpr int maxq = 10;
+		int niter = 0, enq = 0, seen = 0, done = 0, rejRun = 0;
+		bool stop = false;
+		double lam = 0, F = 0;
+		double* chi2Out = nullptr;
+		LmDevice lm;
+	};
+	void lmRunBegin(LmRun& r, int niter, double* chi2Out);
+	void lmAbsorb(LmRun& r, int upto);
+	bool lmBeforeTrial(LmRun& r);
+	bool lmAfterSolve(LmRun& r, bool ok);
+	int lmRunEnd(LmRun& r);
+	bool batchable() const;
+	std::vector<hipEvent_t> batchEvents;        // (the lead handle of a batch owns the join / fork events and the device table)
+	BatchEntry* h_batchTab = nullptr;
+	DevBuf<unsigned char> d_batchTab;
 	DevBuf<double> d_lmState; DevBuf<Scalar> d_lamS;
 	double* h_lmRing = nullptr; double* lmRingDev = nullptr;
 	int64_t cntHostLooks = 0;           // waits of the host for a device report (PCG looks + LM decisions it had to see)

@@ -70,13 +70,12 @@ enum
 /* Replaces: CudaBundleAdjustment::create() -> CudaBlockSolver construction (src/cuda_bundle_adjustment.cpp:905-908).
    Threads: a handle is not re-entrant; distinct handles may be driven from distinct host threads at once (the reference's
    CudaBundleAdjustment objects are independent too, include/cuda_bundle_adjustment.h:34-125).  Each handle owns one work stream, one
-   low-priority side stream (coarse inversions), one upload stream, and -- while it is the only live handle of the process and graphs
-   are on -- a helper thread that calls hipGraphInstantiate / hipGraphExecDestroy in the background (relevant for callers that fork, or
-   that capture with hipStreamCaptureModeGlobal).  A process that will drive SEVERAL handles side by side should export
-   CUBA_HIP_GRAPHS=0 before its first solve (= option "pcg_graph" 0 on every handle; no helper thread then): on this runtime a process
-   that has ever instantiated a hipGraph no longer overlaps the kernel chains of two streams (two KITTI-00 graphs from two threads:
-   1.5 x one graph's throughput without graphs, 1.0 x with; a lone handle is ~2 % faster with graphs).  The
-   library itself stops using graphs while more than one handle is alive. */
+   low-priority side stream (coarse inversions) and one upload stream.  hipGraphs are OPT-IN (option "pcg_graph" = 1 or CUBA_HIP_GRAPHS=1
+   in the environment; the handle then also owns a helper thread that calls hipGraphInstantiate / hipGraphExecDestroy in the background --
+   relevant for callers that fork, or that capture with hipStreamCaptureModeGlobal): on this runtime a process that has ever instantiated a
+   hipGraph no longer overlaps the kernel chains of two streams (two KITTI-00 graphs from two threads: 1.5 x one graph's throughput
+   without graphs, 1.0 x with), while a lone handle is only ~2 % faster with them.  With graphs on, the library
+   still stops using them while more than one handle is alive. */
 int cuba_hip_create(int device, cuba_hip_solver** out);
 int cuba_hip_destroy(cuba_hip_solver* s);
 const char* cuba_hip_last_error(const cuba_hip_solver* s);
@@ -95,7 +94,7 @@ void cuba_hip_host_free(void* p);
 /* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's private one. */
 int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
 
-/* Options (22).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
+/* Options (20).  Solver: "pcg_tol" (relative preconditioned-residual tolerance of the reduced solve, default 1e-7; fp32 build 1e-4),
    "pcg_max_iter" (default 4*6*Pf capped at 32768), "pcg_accept_unconverged" (default 0, see cuba_hip_get_pcg_history),
    "direct_fallback" (default 1: a reduced solve whose PCG uses up its iteration budget, breaks down, or follows such a solve in the
    same Levenberg-Marquardt run is solved EXACTLY on the device -- sparse tile Cholesky, csrc/ba_direct.hip: minimum-degree ordering
@@ -103,8 +102,8 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    phases of SparseLinearSolver, /root/reference/src/cuda_linear_solver.cpp:278-348, 147-232, 386-415 -- and fails only on a
    non-positive pivot like the reference, :406-410; 0 = the solve is reported as failed instead), "reduced_solver" (default 0 = block
    PCG with that fallback; 1 = EVERY reduced solve is the exact one, the reference's behaviour), "direct_after" (PCG iterations before
-   the hand-over; default 0 = automatic: 128 -- about twice what an exact solve costs --, at most pcg_max_iter; a constant, so that the
-   decision never depends on timing), "direct_max_tiles" (default 2^20: the fill of the factor, in 32 x 32 tiles of 5 poses x 5 poses,
+   the hand-over; default 0 = automatic: Pf / 4 clamped to 128 ... 384 -- about twice what an exact solve costs --, at most
+   pcg_max_iter; a function of the graph's size, so that the decision never depends on timing), "direct_max_tiles" (default 2^20: the fill of the factor, in 32 x 32 tiles of 5 poses x 5 poses,
    beyond which the exact solver is not used and the failure report stands; a 10 000-pose trajectory with loop closures needs 19 000),
    "direct_slack" (default -1 = automatic: multiple-elimination slack of the ordering, 0 / 2 / 4 / 8 by a cost model of levels and fill),
    "pcg_aggregate" (poses per coarse aggregate of the two-level preconditioner; -1 = automatic: max(6, Pf/55) below 1320 free poses,
@@ -118,12 +117,10 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    The coarse matrix of a trial is assembled and inverted on a second, low-priority stream under that trial's PCG and serves from a
    later trial on (every trial up to a coarse dimension of 512, every second up to 1024, every third beyond); only the first solve
    on a structure inverts in line.
-   Run-to-run heuristics (exact when a run repeats the previous one, harmless otherwise; bench.py prices them): "coarse_first_reuse"
-   (default 1: the first solve of an LM run starts with the inverse the first solve of the PREVIOUS run on this structure had -- same
-   damping regime -- while its own inversion runs on the second stream), "pcg_repeat_prediction" (default 1: a run that has repeated
-   the previous run solve for solve so far sizes its next batch of iterations from that run instead of extrapolating),
-   "pcg_exact_batch_graphs" (default 1: a batch length that is asked for a second time on one structure gets a hipGraph of exactly
-   that length -- one hand-over per batch instead of one per power of two).
+   "heuristics" (default 1: two run-to-run memories, exact when a run repeats the previous one and harmless otherwise -- the first
+   solve of an LM run starts with the coarse inverse the first solve of the PREVIOUS run on this structure had, same damping regime,
+   while its own inversion runs on the second stream; and a run that has repeated the previous run solve for solve so far sizes its
+   next batch of iterations from that run instead of extrapolating; 0 = neither, what bench.py's "heuristics_off" prices).
    "spmv_upper" (default -1 = automatic: on beyond 1536 free poses, where the PCG kernels are bound by bytes; 1 / 0 = on / off: the
    PCG iteration as three launches straight from the upper-triangular BSR storage -- SpMV with the transposed products parked per
    block, row updates + P^T r per aggregate, preconditioner -- instead of two launches on a row-ordered copy of both triangles).
@@ -133,14 +130,14 @@ int cuba_hip_set_stream(cuba_hip_solver* s, void* hip_stream);
    observing pose of the internal pose order, so that landmark-major data inherit the trajectory's locality whatever the caller's ids are;
    every host-pointer entry point keeps the caller's landmark numbering; a landmark partition other than the whole range, and the host
    pipeline, use the caller's order),
-   "device_lm_decision" (default 1: cuba_hip_optimize takes the decision of every trial -- gain ratio, acceptance, next damping -- on
-   the device and enqueues the next trial without having seen it, a rejected trial being undone by a conditional restore launch: one
-   host look per trial instead of two, results bit-identical to the host-side decision = 0; control flow of
-   /root/reference/src/cuda_bundle_adjustment.cpp:816-851).
-   Execution: "pcg_graph" (default 1, or 0 when the environment has CUBA_HIP_GRAPHS=0: PCG iterations are replayed as hipGraphs of
-   4 ... 256 iterations; 0 = eager launches; see cuba_hip_create about processes with several handles),
-   "fused_tail" (default 1: cuba_hip_optimize runs back-substitution, update and evaluation of a trial as ONE pass over the edges;
-   0 = the four-launch tail, which a landmark partition and "profile" use in any case), "device_setup" (default 1: the edge sort of
+   cuba_hip_optimize takes the decision of every trial -- gain ratio, acceptance, next damping -- on the device and enqueues the next
+   trial without having seen it, a rejected trial being undone by a conditional restore launch, and runs back-substitution, update and
+   evaluation of a trial as ONE pass over the edges (control flow of /root/reference/src/cuda_bundle_adjustment.cpp:816-851; a
+   landmark partition and "profile" use the host loop over the stage kernels instead).
+   Execution: "pcg_graph" (default 0, or 1 when the environment has CUBA_HIP_GRAPHS=1: PCG iterations are replayed as hipGraphs of
+   4 ... 256 iterations and of the exact batch lengths that come back; opt-in since round 6 -- a lone handle gains ~2 %, a process
+   that has instantiated a hipGraph no longer overlaps the kernel chains of several handles; see cuba_hip_create),
+   "device_setup" (default 1: the edge sort of
    cuba_hip_set_graph and the whole symbolic analysis of cuba_hip_build_structure run on the GPU; 0 = the host pipeline, the
    independent cross-check of the tests), "pose_reorder" (default 1: when most blocks of the reduced matrix lie far off its diagonal
    in the caller's pose numbering -- arbitrary vertex ids --, the free poses are renumbered internally along the trajectory found by
@@ -257,6 +254,20 @@ int cuba_hip_restore_state_slot(cuba_hip_solver* s, int slot);
    executed inside the library to avoid per-stage host round trips.
    chi2_per_iter[niterations] receives BatchInfo::chi2 for each executed iteration, *n_done their count. */
 int cuba_hip_optimize(cuba_hip_solver* s, int niterations, double* chi2_per_iter, int* n_done);
+
+/* The same for SEVERAL handles at once, in one launch chain.  Replaces: independent CudaBundleAdjustment objects optimised side by
+   side (include/cuda_bundle_adjustment.h:34-125 -- ORB-SLAM's local BA windows, BASELINE configs[3]'s independent graphs when they share
+   a GPU).  Every handle runs its own Levenberg-Marquardt loop exactly as cuba_hip_optimize would -- its own damping, acceptance
+   decisions (taken on the device, per graph), iteration counts and stopping -- and everything of a trial but the PCG iterations on its
+   own stream; the PCG iterations of all graphs are issued as ONE chain of batched launches (the graph number is the launch grid's second
+   dimension, the kernels' arguments come from a device table), so the host pays 2 launches per iteration for the batch instead of 2
+   per graph.  Results are bit-identical to cuba_hip_optimize on each handle alone.  Graphs of one size class batch together (two-launch
+   iteration with a two-level preconditioner, the same coarse-dimension and occupancy class, same "pcg_tol", same device, distinct
+   streams, no "profile", no landmark partition); anything else is run one handle after the other, with the same results.
+   handles[n] (distinct, n <= 64), chi2_per_iter[n * niterations] (row i = handle i; may be NULL), n_done[n];
+   *batched_solves (optional) = reduced solves that ran as a batch (0: the fallback ran).  The calling thread drives all handles: do not
+   use them from other threads meanwhile.  Errors are recorded on handles[0]. */
+int cuba_hip_optimize_batch(cuba_hip_solver** handles, int n, int niterations, double* chi2_per_iter, int* n_done, int* batched_solves);
 
 /* ---- results ------------------------------------------------------------------------------------ */
 

@@ -407,12 +407,12 @@ def test_failed_driver_creation_leaves_the_solver_handle_unrestricted():
 def test_native_driver_over_a_real_rccl_communicator_single_rank():
     """A 1-rank RCCL communicator (all this box can host: RCCL wants one device per rank): ncclCommInitRank + the whole
     native loop on the solver's stream; must reproduce cuba_hip_optimize -- bit for bit against the same stage kernels
-    (fused_tail = 0), to summation-order noise against the default fused tail (which adds the chi2 partials per landmark
+    (the host loop: "profile" = 1), to summation-order noise against the default fused tail (which adds the chi2 partials per landmark
     workgroup instead of per edge stride)."""
     from cuba_amd.capi import HipSolver
     from cuba_amd.dist import NativeDist, rccl_unique_id
     fp = flatten(synth_ba(120, 6000, 24000, seed=9))
-    want = HipSolver(fp, RK_HUBER, fused_tail=0).optimize(6)["chi2"]
+    want = HipSolver(fp, RK_HUBER, profile=1).optimize(6)["chi2"]
     want_fused = HipSolver(fp, RK_HUBER).optimize(6)["chi2"]
     h = HipSolver(fp, RK_HUBER)
     d = NativeDist(h, fp, 0, 1, unique_id=rccl_unique_id())

@@ -12,6 +12,19 @@ RMSE is taken exactly as samples/sample_comparison_with_g2o.cpp:107-131 does (co
 the mean squared norm per vertex).  The reference reports 7.6e-16 / 4.5e-13 / 4.5e-13 against g2o because both
 sides factorise the same reduced matrix; an iterative reduced solve is bounded by its tolerance instead, which
 is why the tolerance is stated per pcg_tol.  Repeat runs must be bit-identical (np.array_equal).
+
+Stated fp32 tolerances (the USE_FLOAT32 build, libcuba_hip_f32.so; FP32_TOL below, asserted by test_float32_variant_at_size, and the
+bench line's float32.<shape>.chi2_max_rel_diff_vs_fp64_golden must sit under the same numbers -- bench.py reads this table):
+
+  shape     per-iteration robust chi2 vs the fp64 oracle (relative)   measured (round 5, driver's box)
+  kitti00   <= 1e-5                                                     3.1e-6
+  s2m       <= 5e-5                                                     --
+  g4m       <= 5e-5                                                     1.1e-5
+  estimates (all shapes): RMSE <= 1e-5 x the scene extent (fp32 resolves a 730 m coordinate of the S2M circuit to 6e-5 m and ten
+  iterations accumulate that; measured 2.1e-3 m there), quaternion coefficients 1e-5 -- checked when the run completes all 10 iterations.
+  "May stop early": an fp32 run may end after 8 or 9 of the 10 iterations, when the gain of a step falls below the resolution of its fp32
+  chi2 sums and the gain ratio comes out <= 0 -- the reference's loop ends the same way (src/cuda_bundle_adjustment.cpp:851); at least 8
+  iterations must run and every executed one must meet the chi2 bar.
 """
 import copy
 import os
@@ -27,6 +40,8 @@ pytestmark = pytest.mark.gpu
 
 CHI2_TOL = 1e-6
 EST_TOL = {"default": dict(chi2=1e-6, q=1e-8, t=1e-6, X=1e-6), "tight": dict(chi2=1e-9, q=1e-10, t=1e-9, X=1e-9)}
+FP32_TOL = {"kitti00": 1e-5, "s2m": 5e-5, "g4m": 5e-5}          # per-iteration chi2 of the fp32 library vs the fp64 oracle; see the header
+FP32_MIN_ITERATIONS = 8
 
 
 def rmse(a, b):
@@ -133,16 +148,16 @@ def test_tight_tolerance_estimates(solvers, name):
 @pytest.mark.parametrize("name", ["kitti00", "s2m", "g4m"])
 def test_float32_variant_at_size(solvers, name):
     """USE_FLOAT32 build (src/scalar.h:25-29) at the BASELINE sizes, G4M (configs[4]'s "plus USE_FLOAT32 variant" on one
-    handle) included.  Stated fp32 tolerance: chi2 1e-4 relative,
-    estimates 1e-5 x the scene extent RMSE (fp32 resolves a 730 m coordinate of the S2M circuit to 6e-5 m and ten
-    iterations accumulate that; measured 2.1e-3 m there), quaternion coefficients 1e-5."""
+    handle) included, against the fp32 bars of this file's header (FP32_TOL per shape, FP32_MIN_ITERATIONS)."""
     HipSolver, _ = solvers
     fp, ref_chi2, ref_state = named_case(name)
     h = HipSolver(fp, RK_HUBER, precision="f32")
     got = h.optimize(10)["chi2"]
     m = min(len(got), len(ref_chi2))
-    assert m >= 8                                                   # fp32 may stop early once the gain is below its resolution
-    assert np.all(np.abs(got[:m] - ref_chi2[:m]) <= 1e-4 * ref_chi2[:m])
+    assert m >= FP32_MIN_ITERATIONS                                  # fp32 may stop early once the gain is below its resolution
+    dev = float(np.abs(got[:m] / ref_chi2[:m] - 1).max())
+    print(f"\n[{name}, fp32 library] {m} iterations, chi2 vs the fp64 oracle {dev:.2e} (bar {FP32_TOL[name]:.0e})")
+    assert dev <= FP32_TOL[name]
     if m == len(ref_chi2):
         for a, b in zip(h.state(), ref_state):
             assert rmse(a, b) < 1e-5 * max(1.0, np.abs(b).max())

@@ -127,11 +127,11 @@ def test_push_pop_and_set_state(solvers, small_fp):
     assert all(np.array_equal(a, b) for a, b in zip(h.state(), s1))
     r2 = h.optimize(4)["chi2"]
     # the same run again: to solver tolerance after a run from ANOTHER estimate (the first solve of a run is preconditioned with the
-    # inverse the previous run's first solve had, option coarse_first_reuse), bit for bit after a run from the same one
+    # inverse the previous run's first solve had, option heuristics), bit for bit after a run from the same one
     assert rel(r2, r1) < 1e-8
     h.restore_state()
     assert np.array_equal(h.optimize(4)["chi2"], r2)
-    h0 = HipSolver(small_fp, RK_HUBER, coarse_first_reuse=0)
+    h0 = HipSolver(small_fp, RK_HUBER, heuristics=0)
     h0.optimize(1); h0.snapshot_state(); a = h0.optimize(4)["chi2"]; h0.restore_state()
     assert np.array_equal(h0.optimize(4)["chi2"], a)         # without the reuse every run is a function of its start alone
 
@@ -182,7 +182,7 @@ def test_snapshot_slots_and_named_counters(solvers, small_fp):
     assert h.counter("pcg_iterations") == c["pcg_iterations"] and h.counter("lm_trials") == c["lm_trials"] == 4
     assert h.counter("coarse_refreshes") == c["coarse_refreshes"] and h.counter("pcg_iterations_enqueued") == c["pcg_iterations_enqueued"]
     # the first run on a structure inverts its first coarse matrix on the work stream, later runs start with the carried-over inverse
-    assert h.counter("coarse_inline_inversions") == 1 and h.counter("pcg_graph_instantiations") >= 0     # (graphs are built on a helper thread)
+    assert h.counter("coarse_inline_inversions") == 1 and h.counter("pcg_graph_instantiations") == 0     # (hipGraphs are opt-in: option pcg_graph)
     assert h.counter("precond_fp32_fallbacks") == 0 and h.counter("pcg_unconverged_solves") == 0
     with pytest.raises(CubaHipError):
         h.counter("no_such_counter")
@@ -313,11 +313,11 @@ def test_landmarks_with_more_than_64_observations(solvers):
 
 
 @pytest.mark.parametrize("case", ["small", "fixed_vertices", "big_landmarks", "fixed_big_landmark", "pose_only", "landmark_only"])
-def test_fused_trial_tail_equals_the_four_launch_tail(solvers, small_graph, case):
-    """optimize() runs back-substitution + update + evaluation of a trial as one pass over the edges (option fused_tail, default);
-    the four-launch tail (fused_tail = 0: the stage kernels one after the other) must give the same trajectory to summation-order
-    noise, and both must follow the oracle.  Covers the > 64-observation kernels, a FIXED landmark with > 64 observations (its
-    edges are evaluated but it has no increment -- the four-launch tail used to leave its partial sum unwritten) and the
+def test_fused_trial_tail_equals_the_stage_kernels(solvers, small_graph, case):
+    """optimize() runs back-substitution + update + evaluation of a trial as one pass over the edges, with the decision taken on the
+    device; the profiled run ("profile" = 1: the host loop over the stage kernels, one after the other, every stage synchronised -- also
+    what a landmark partition runs) must give the same trajectory to summation-order noise, and both must follow the oracle.  Covers the
+    > 64-observation kernels, a FIXED landmark with > 64 observations (its edges are evaluated but it has no increment) and the
     degenerate modes."""
     from conftest import with_fixed
     HipSolver, OracleSolver = solvers
@@ -339,7 +339,7 @@ def test_fused_trial_tail_equals_the_four_launch_tail(solvers, small_graph, case
             assert np.bincount(fp.eL)[fp.Lf:].max() > 64
     ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
     a = HipSolver(fp, RK_HUBER, pcg_tol=1e-11); ra = a.optimize(6)["chi2"]
-    b = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, fused_tail=0); rb = b.optimize(6)["chi2"]
+    b = HipSolver(fp, RK_HUBER, pcg_tol=1e-11, profile=1); rb = b.optimize(6)["chi2"]
     assert len(ra) == len(rb) == len(ref)
     assert np.all(np.abs(ra - rb) <= 1e-11 * rb), np.abs(ra / rb - 1).max()
     assert np.all(np.abs(ra - ref) <= 1e-8 * ref), np.abs(ra / ref - 1).max()
@@ -462,7 +462,7 @@ def test_hint_unchanged_covers_one_call_and_only_what_it_promises(solvers, small
 def test_coarse_refresh_schedule(solvers):
     """The coarse inverse of trial k is built on a second stream for a later trial (under every trial for a coarse dimension up to
     512, under every second up to 1024, every third beyond); only the first solve on a structure inverts in line.  Deterministic,
-    and the eager-launch path (pcg_graph = 0) solves the same problems."""
+    and the hipGraph path (pcg_graph = 1, opt-in) solves the same problems."""
     HipSolver, OracleSolver = solvers
     fp = flatten(synth_ba(200, 8000, 32000, seed=13))
     ref = OracleSolver(fp, RK_HUBER).optimize(6)["chi2"]
@@ -472,11 +472,20 @@ def test_coarse_refresh_schedule(solvers):
     assert h.counters()["coarse_refreshes"] >= 6 and h.counter("coarse_inline_inversions") == 1     # one in line + one under every trial
     h2 = HipSolver(fp, RK_HUBER)
     assert np.array_equal(h2.optimize(6)["chi2"], a)          # deterministic
-    e = HipSolver(fp, RK_HUBER, pcg_graph=0)
-    assert rel(e.optimize(6)["chi2"], ref) < CHI2_TOL
     b = h.optimize(3)["chi2"]                                  # a second run on the structure continues from the first one's result:
     assert np.isfinite(b).all() and b[0] <= a[-1] * (1 + 1e-12) and np.all(np.diff(b) <= 0)
     assert h.counter("coarse_inline_inversions") == 1        # ... its first solve started with the carried-over inverse
+    # the hipGraph path (opt-in; used only while the handle is the one live handle of the process, and built on a helper thread while the
+    # first batches go out as plain launches): same kernels, same arguments -- bit-identical
+    import time
+    h.close(); h2.close()
+    e = HipSolver(fp, RK_HUBER, pcg_graph=1)
+    assert np.array_equal(e.optimize(6)["chi2"], a)
+    time.sleep(0.3)
+    e.set_state(fp.q, fp.t, fp.Xw); again = e.optimize(6)["chi2"]
+    assert rel(again, a) < 1e-8                                # (the second run starts with the first one's coarse inverse)
+    print(f"\n[hipGraph path] graphs instantiated: {e.counter('pcg_graph_instantiations')}, iterations as plain launches {e.counter('pcg_iterations_plain_launches')}")
+    e.close()
 
 
 def test_golden_trajectories_on_gpu(solvers):
@@ -536,11 +545,11 @@ def test_same_topology_reuses_structure_new_values_only(solvers, small_fp):
     fresh = HipSolver(fp2, RK_HUBER).optimize(4)["chi2"]
     ref = OracleSolver(fp2, RK_HUBER).optimize(4)["chi2"]
     # (the re-used handle preconditions its first solve with the inverse of its previous run: same results to solver tolerance;
-    # with coarse_first_reuse = 0 the kept structure gives the fresh handle's bits)
+    # with heuristics = 0 the kept structure gives the fresh handle's bits)
     assert rel(got, fresh) < 1e-8 and rel(got, ref) < CHI2_TOL
-    h0 = HipSolver(small_fp, RK_HUBER, coarse_first_reuse=0)
+    h0 = HipSolver(small_fp, RK_HUBER, heuristics=0)
     h0.optimize(2); h0.set_graph(fp2)
-    assert np.array_equal(h0.optimize(4)["chi2"], HipSolver(fp2, RK_HUBER, coarse_first_reuse=0).optimize(4)["chi2"])
+    assert np.array_equal(h0.optimize(4)["chi2"], HipSolver(fp2, RK_HUBER, heuristics=0).optimize(4)["chi2"])
     fp3 = copy.deepcopy(fp2)                                       # drop the last edge: topology changed
     for name in ("eP", "eL", "eDim", "omega", "meas", "edge_src"):
         setattr(fp3, name, getattr(fp3, name)[:-1].copy())
@@ -702,8 +711,8 @@ def test_exact_reduced_solve_reports_a_non_positive_pivot():
     assert bad
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(pcg_aggregate=6), dict(coarse_linear=0), dict(precond_fp32=0), dict(pcg_graph=0)],
-                         ids=["default", "aggregate6", "constant_coarse", "fp64_inverse", "eager"])
+@pytest.mark.parametrize("opts", [dict(), dict(pcg_aggregate=6), dict(coarse_linear=0), dict(precond_fp32=0), dict(pcg_graph=1)],
+                         ids=["default", "aggregate6", "constant_coarse", "fp64_inverse", "graphs"])
 def test_upper_triangle_iteration_matches_the_two_launch_form(solvers, opts):
     """Option spmv_upper (automatic beyond 1536 free poses): the PCG iteration as three launches straight from the upper-triangular BSR
     storage -- SpMV with the transposed products parked per block, row updates + P^T r per aggregate, preconditioner -- instead of the
@@ -739,12 +748,13 @@ def test_upper_triangle_iteration_float32_build(solvers):
     assert len(a) == len(b) and rel(b[:len(ref)], ref[:len(b)]) < 1e-3 and rel(a, b) < 1e-3
 
 
-@pytest.mark.parametrize("agg", [172, 344, 700])
+@pytest.mark.parametrize("agg", [172, 344, 600, 5000])
 def test_upper_triangle_iteration_with_large_aggregates(solvers, agg):
     """Round-5 advisor: the row-update launch of the upper-triangle iteration gave each of its 512 threads two row entries, so aggregates
     above 170 poses (6 agg > 1024; the automatic rule gets there from ~30 000 free poses, a user-set pcg_aggregate at any size) were
-    silently truncated.  The launch now takes 2 / 4 / 8 entries per thread by aggregate size, and beyond 682 poses the handle uses the
-    two-launch form: same trajectory as spmv_upper = 0 in every case, oracle parity, no unconverged solve."""
+    silently truncated.  The launch now takes 2 / 4 / 8 entries per thread by aggregate size; an aggregate is capped at 600 poses (the
+    two-level kernel keeps its rows in LDS -- asking for 5000 used to send the size rule into an endless doubling that ended in an integer
+    division by zero): same trajectory as spmv_upper = 0 in every case, oracle parity, no unconverged solve."""
     HipSolver, OracleSolver = solvers
     fp = flatten(synth_ba(1500, 30000, 120000, seed=21))
     ref = OracleSolver(fp, RK_HUBER).optimize(4)["chi2"]
@@ -757,12 +767,13 @@ def test_upper_triangle_iteration_with_large_aggregates(solvers, agg):
     assert len(ia) == len(ib) and np.abs(ia - ib).max() <= 3, (ia.tolist(), ib.tolist())
 
 
-def test_device_resident_lm_decision_is_bit_identical(solvers):
+def test_device_resident_lm_decision_follows_the_host_loop(solvers):
     """cuba_hip_optimize takes the decision of every trial on the device (gain ratio, acceptance, next damping; a rejected trial is undone
     by a conditional restore launch) and enqueues the next trial without having seen it: one host look per trial instead of two.  Same
-    control flow as CudaBundleAdjustmentImpl::optimize (src/cuda_bundle_adjustment.cpp:816-851), same arithmetic as the host loop
-    (option device_lm_decision = 0): chi2 per iteration, estimates, trial counts and PCG histories are bit-identical -- with accepted
-    trials only, with rejected ones, with fixed vertices, when the run stops early, for a single iteration."""
+    control flow as CudaBundleAdjustmentImpl::optimize (src/cuda_bundle_adjustment.cpp:816-851) and as the library's host loop over the
+    stage kernels ("profile" = 1; round 5 proved the two decisions bit-identical on one tail, after which the host-side copy of the fused
+    tail was removed): chi2 per iteration and estimates to summation-order noise, trial counts and the PCG history exactly -- with
+    accepted trials only, with rejected ones, with fixed vertices, when the run stops early, for a single iteration."""
     from test_ref_lm import rough_start
     HipSolver, OracleSolver = solvers
     g = synth_ba(60, 1500, 6000, seed=3)
@@ -773,15 +784,15 @@ def test_device_resident_lm_decision_is_bit_identical(solvers):
              ("one_iteration", flatten(g), RK_HUBER, 1)]
     saw_rejection = False
     for name, fp, rk, n in cases:
-        a = HipSolver(fp, rk, device_lm_decision=0); ra = a.optimize(n)["chi2"]
-        b = HipSolver(fp, rk); rb = b.optimize(n)["chi2"]
-        assert np.array_equal(ra, rb), (name, ra, rb)
-        assert all(np.array_equal(x, y) for x, y in zip(a.state(), b.state())), name
+        a = HipSolver(fp, rk, profile=1, pcg_tol=1e-11); ra = a.optimize(n)["chi2"]
+        b = HipSolver(fp, rk, pcg_tol=1e-11); rb = b.optimize(n)["chi2"]
+        tol = 1e-6 if name == "tukey_rejections" else 1e-9
+        assert len(ra) == len(rb) and rel(ra, rb) < tol, (name, ra, rb)
         ta, tb = a.counters()["lm_trials"], b.counters()["lm_trials"]
-        assert ta == tb and np.array_equal(a.pcg_history()[0], b.pcg_history()[0]), (name, ta, tb)
+        assert ta == tb and len(a.pcg_history()[0]) == len(b.pcg_history()[0]), (name, ta, tb)
         saw_rejection |= ta > len(ra)
         la, lb = a.counter("host_looks"), b.counter("host_looks")
-        print(f"\n[{name}] {len(ra)} iterations, {ta} trials: host looks {la} (host decision) -> {lb} (device decision)")
+        print(f"\n[{name}] {len(ra)} iterations, {ta} trials: host looks {la} (host loop) -> {lb} (device decision)")
         assert lb < la or n == 1, (name, la, lb)
         # a second run on the same handle (the device state is re-initialised) and the oracle
         b.set_state(fp.q, fp.t, fp.Xw)
@@ -789,6 +800,50 @@ def test_device_resident_lm_decision_is_bit_identical(solvers):
         ro = OracleSolver(fp, rk).optimize(n)["chi2"]
         assert len(ro) == len(rb) and rel(rb, ro) < (1e-5 if name == "tukey_rejections" else 1e-6), name
     assert saw_rejection
+
+
+def test_batched_execution_is_bit_identical_to_solo_runs(solvers):
+    """cuba_hip_optimize_batch: several graphs, one launch chain (the PCG iterations of all graphs as batched launches, everything else of
+    a trial on each graph's own stream, every graph's LM decisions its own, on the device).  Independent graphs of one size class --
+    different seeds, so different iteration counts per solve, and one start that makes its run REJECT trials while the others accept --
+    must each reproduce their solo cuba_hip_optimize run bit for bit: chi2 per iteration, estimates, trial counts, PCG history; a second
+    batch call on the same handles likewise; mismatched handles (another size class, the fp32 library is another library) fall back to
+    one-after-the-other with the same results.  Ref: independent CudaBundleAdjustment objects, include/cuda_bundle_adjustment.h:34-125."""
+    from cuba_amd.capi import optimize_batch
+    from test_ref_lm import rough_start
+    HipSolver, OracleSolver = solvers
+    # (three 200-pose graphs with Huber + a 60-pose graph with Tukey from a rough start, whose run rejects trials: graphs of one size class
+    # need not have one size, and the robust kernels are per graph)
+    graphs = [synth_ba(200, 8000, 32000, seed=s) for s in (13, 14, 15)] + [rough_start(synth_ba(60, 1500, 6000, seed=3))]
+    rks = [RK_HUBER, RK_HUBER, RK_HUBER, RK_TUKEY]
+    fps = [flatten(g) for g in graphs]
+    n_it = 12
+    solo, solo_state, solo_trials, solo_hist = [], [], [], []
+    for fp, rk in zip(fps, rks):
+        h = HipSolver(fp, rk)
+        solo.append(h.optimize(n_it)["chi2"]); solo_state.append(h.state()); solo_trials.append(h.counters()["lm_trials"]); solo_hist.append(h.pcg_history()[0])
+        h.close()
+    assert solo_trials[3] > len(solo[3])                              # the Tukey run rejects trials
+    hs = [HipSolver(fp, rk) for fp, rk in zip(fps, rks)]
+    got, batched = optimize_batch(hs, n_it)
+    assert batched > 0
+    for i, h in enumerate(hs):
+        assert np.array_equal(got[i], solo[i]), (i, got[i], solo[i])
+        assert all(np.array_equal(a, b) for a, b in zip(h.state(), solo_state[i])), i
+        assert h.counters()["lm_trials"] == solo_trials[i] and np.array_equal(h.pcg_history()[0], solo_hist[i]), i
+    # again on the same handles, from the same starts: the runs repeat (first solve with the carried-over coarse inverse, like solo handles)
+    for h, fp in zip(hs, fps):
+        h.set_state(fp.q, fp.t, fp.Xw)
+    again, batched2 = optimize_batch(hs, n_it)
+    assert batched2 > 0 and all(rel(a, b) < 1e-8 for a, b in zip(again, solo))
+    # a handle of another size class in the batch: the call falls back to one handle after the other
+    small = flatten(synth_ba(40, 600, 2400, seed=1))
+    want_small = HipSolver(small, RK_HUBER).optimize(5)["chi2"]
+    mixed = [HipSolver(fps[0], RK_HUBER), HipSolver(small, RK_HUBER, pcg_aggregate=0)]
+    r, b3 = optimize_batch(mixed, 5)
+    assert b3 == 0 and np.array_equal(r[0], solo[0][:5]) and rel(r[1], want_small) < 1e-6       # (block-Jacobi only: not batchable)
+    for h in hs + mixed:
+        h.close()
 
 
 def test_internal_landmark_order_is_invisible_at_the_boundary(solvers):
