@@ -120,7 +120,7 @@ __device__ __forceinline__ Scalar (*gj_pivot_inverse(Scalar (*Dcur)[GJ_B + 1], S
 
 // Inverse of the first pivot block (rows / columns [0, bk)) of the sweep -> pivOut[c * 32 + r]; every later pivot block is
 // inverted by the step before it (below).
-__global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar* __restrict__ src, int n, int bk, Scalar* __restrict__ pivOut)
+__device__ __forceinline__ void dense_gj_first_pivot_body(const Scalar* __restrict__ src, int n, int bk, Scalar* __restrict__ pivOut)
 {
 	__shared__ Scalar D[GJ_B][GJ_B + 1];
 	__shared__ Scalar D2[GJ_B][GJ_B + 1];
@@ -142,6 +142,18 @@ __global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar*
 	for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
 }
 
+__global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar* __restrict__ src, int n, int bk, Scalar* __restrict__ pivOut)
+{
+	dense_gj_first_pivot_body(src, n, bk, pivOut);
+}
+
+// batched sweep (cuba_hip_optimize_batch): the coarse matrices of several graphs, one launch per step for all of them
+__global__ __launch_bounds__(256) void dense_gj_first_pivot_batch_kernel(const GjJob* __restrict__ jobs)
+{
+	const GjJob& j = jobs[blockIdx.x];
+	dense_gj_first_pivot_body(j.buf[0], j.n, min(GJ_B, j.n), j.piv[0]);
+}
+
 // One blocked step of the symmetric sweep with pivot rows/cols [p0, p0+bk), p0 a multiple of GJ_B:  with D = A_pp^-1,
 //     A_ij <- A_ij - A_ip D A_pj,   A_ip <- A_ip D,   A_pj <- D A_pj,   A_pp <- -D          (i, j != p)
 // applied to EVERY block row / column, swept before or not.  A symmetric matrix stays symmetric under it, so only the tiles
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) void dense_gj_first_pivot_kernel(const Scalar*
 //     chain: 15.9 us per step when every workgroup inverted the pivot block itself, ~11 now;
 //   * four LDS arrays (the chain's second array reuses an operand array): four workgroups per CU;
 //   * the two 32x32x32 products run on the matrix cores.
-__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk,
+__device__ __forceinline__ void dense_gj_step_body(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk,
 	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
 {
 	__shared__ Scalar D[GJ_B][GJ_B + 1];
@@ -288,6 +300,38 @@ __global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __rest
 	for (int u = 0; u < 4; u++) pivOut[(cb + 8 * u) * GJ_B + r] = res[r][cb + 8 * u];
 	TRACE_MARK();
 	TRACE_FLUSH(2, 8000 + (threadIdx.x >> 6));              // (kept apart: the last launch of a sweep has no look-ahead workgroup)
+}
+
+__global__ __launch_bounds__(256) void dense_gj_step_kernel(const Scalar* __restrict__ src, Scalar* __restrict__ dst, int n, int p0, int bk,
+	const Scalar* __restrict__ pivIn, Scalar* __restrict__ pivOut)
+{
+	dense_gj_step_body(src, dst, n, p0, bk, pivIn, pivOut);
+}
+
+__global__ __launch_bounds__(256) void dense_gj_step_batch_kernel(const GjJob* __restrict__ jobs, int step)
+{
+	const GjJob& j = jobs[blockIdx.y];
+	const int p0 = step * GJ_B;
+	if (p0 >= j.n || (int)blockIdx.x > j.tiles * (j.tiles + 1) / 2) return;
+	dense_gj_step_body(j.buf[step & 1], j.buf[(step & 1) ^ 1], j.n, p0, min(GJ_B, j.n - p0), j.piv[step & 1], j.piv[(step & 1) ^ 1]);
+}
+
+// jobs[m] on the device; every job's matrix starts in its buf[0] and ends in buf[steps & 1] (as launch_dense_inverse leaves it)
+void launch_dense_inverse_batch(const GjJob* jobs, int m, int nMax, hipStream_t s)
+{
+	if (m <= 0 || nMax <= 0) return;
+	const int tiles = (nMax + GJ_B - 1) / GJ_B;
+	hipLaunchKernelGGL(dense_gj_first_pivot_batch_kernel, dim3(m), dim3(256), 0, s, jobs);
+	for (int step = 0; step < tiles; step++)
+		hipLaunchKernelGGL(dense_gj_step_batch_kernel, dim3(1 + tiles * (tiles + 1) / 2, m), dim3(256), 0, s, jobs, step);
+}
+
+// the first two launches of launch_coarse_setup alone (zero + assemble; `assembled` recorded behind them)
+void launch_coarse_assemble(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, hipStream_t s)
+{
+	const int Nc = 6 * sys.cl * sys.nc;
+	(void)hipMemsetAsync(work0, 0, sizeof(Scalar) * (size_t)Nc * Nc, s);
+	if (st.nCb) hipLaunchKernelGGL(coarse_assemble_kernel, dim3(st.nCb), dim3(256), 0, s, st, sys, work0, g.Pf);
 }
 
 // symmetric sweep: work0 holds the matrix on entry (its upper triangle is what is read); returns the buffer (work0 or work1)

@@ -193,6 +193,10 @@ Scalar* launch_coarse_setup(const DeviceGraph& g, const DeviceStructure& st, con
 // returns whichever of the two buffers holds the inverse
 Scalar* launch_dense_inverse(Scalar* work0, Scalar* work1, int n, Scalar* pivots, hipStream_t s);   // symmetric sweep: the result's upper triangle holds -A^-1; pivots: 2 x 32 x 32 numbers of scratch
 void launch_coarse_finish(const Scalar* swept, Scalar* dst, int n, hipStream_t s);    // swept buffer -> full symmetric +A^-1 (dst may be the swept buffer)
+// batched sweep of several coarse matrices (cuba_hip_optimize_batch): one launch per step for all of them
+struct GjJob { Scalar* buf[2]; Scalar* piv[2]; int n, tiles; };       // buf[0]: the matrix on entry; piv: 2 x (32 x 32) scratch
+void launch_coarse_assemble(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar* work0, hipStream_t s);
+void launch_dense_inverse_batch(const GjJob* jobs, int m, int nMax, hipStream_t s);
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s);
 // one iteration of the upper-triangle form (sys.upper): which = 1 SpMV | 2 row updates | 4 preconditioner (7 = all three, in this order)
 int spmv_upper_grid(int Pf);      // workgroups of the upper-triangle SpMV (= its p.Ap partials)

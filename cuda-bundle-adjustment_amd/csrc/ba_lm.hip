@@ -434,18 +434,28 @@ bool cuba_hip_solver::solveBegin(SolveCtx& sc)
 			if (regular)
 			{
 				HIP_TRY(hipEventRecord(evSetup, stream));
-				HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
-				(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
-				if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[1].data(), 6 * sys.cl * sys.nc, gjStream);   // (staging: the iteration graphs read [0])
-				else launch_coarse_finish(d_coarse[0].data(), d_coarse[0].data(), 6 * sys.cl * sys.nc, gjStream);                     // (the sweep leaves -inverse in the upper triangle)
-				if (firstInvPending)
+				if (sc.deferCoarse)
 				{
-					if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, gjStream));
-					else HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, gjStream));
-					HIP_TRY(hipEventRecord(evFirstInv, gjStream));
-					firstInvPending = false; firstInvValid = true;
+					// cuba_hip_optimize_batch sweeps the coarse matrices of all its graphs together (one launch per step for all of them, on
+					// the first handle's side stream): only the decision is taken here, launchCoarseJobs enqueues the work
+					sc.deferCoarse->push_back(CoarseJob{ this, first, firstInvPending });
+					if (firstInvPending) { firstInvPending = false; firstInvValid = true; }
 				}
-				HIP_TRY(hipEventRecord(evInverse, gjStream));
+				else
+				{
+					HIP_TRY(hipStreamWaitEvent(gjStream, evSetup, 0));
+					(void)launch_coarse_setup(g, st, sys, d_coarse[first].data(), d_coarse[1 - first].data(), gjStream, evAssembled);
+					if (fp32Inverse()) launch_coarse_to_fp32(d_coarse[0].data(), d_coarse32[1].data(), 6 * sys.cl * sys.nc, gjStream);   // (staging: the iteration graphs read [0])
+					else launch_coarse_finish(d_coarse[0].data(), d_coarse[0].data(), 6 * sys.cl * sys.nc, gjStream);                     // (the sweep leaves -inverse in the upper triangle)
+					if (firstInvPending)
+					{
+						if (fp32Inverse()) HIP_TRY(hipMemcpyAsync(d_firstInv32.data(), d_coarse32[1].data(), inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, gjStream));
+						else HIP_TRY(hipMemcpyAsync(d_firstInv.data(), d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, gjStream));
+						HIP_TRY(hipEventRecord(evFirstInv, gjStream));
+						firstInvPending = false; firstInvValid = true;
+					}
+					HIP_TRY(hipEventRecord(evInverse, gjStream));
+				}
 				pendingInv = 0;
 				assemblePending = true; cntCoarseRefresh++;
 			}
@@ -728,6 +738,54 @@ bool cuba_hip_solver::batchable() const
 	return !profile && partHi < 0 && Pf > 0 && Lf > 0 && E > 0 && trial_tail_parts(g, st) <= d_parts.size() && batch_kernel_class(g, sys) >= 0;
 }
 
+// The overlapped coarse inversions a batch's handles decided on in this trial (solveBegin, `regular` schedule), enqueued together on
+// THIS handle's side stream: per graph what the solo path enqueues -- wait for its set-up launch, zero + assemble, [sweep], conversion,
+// copy for the next run's first solve, events -- with the sweeps of all graphs as one launch per step (launch_dense_inverse_batch).
+void cuba_hip_solver::launchCoarseJobs(std::vector<CoarseJob>& jobs)
+{
+	if (jobs.empty()) return;
+	ensureOverlapObjects();
+	hipStream_t side = gjStream;
+	const int m = (int)jobs.size();
+	if (!h_gjTab) { HIP_TRY(hipHostMalloc((void**)&h_gjTab, sizeof(GjJob) * CUBA_HIP_BATCH_MAX, hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&evGjTab, hipEventDisableTiming)); HIP_TRY(hipEventRecord(evGjTab, side)); }
+	d_gjTab.resize(sizeof(GjJob) * CUBA_HIP_BATCH_MAX);
+	HIP_TRY(hipEventSynchronize(evGjTab));          // (the previous table's copy has long left the pinned block)
+	int nMax = 0;
+	for (int a = 0; a < m; a++)
+	{
+		cuba_hip_solver* h = jobs[a].h;
+		const int Nc = 6 * h->sys.cl * h->sys.nc;
+		HIP_TRY(hipStreamWaitEvent(side, h->evSetup, 0));
+		launch_coarse_assemble(h->g, h->st, h->sys, h->d_coarse[jobs[a].first].data(), side);
+		GjJob& j = h_gjTab[a];
+		j.buf[0] = h->d_coarse[jobs[a].first].data(); j.buf[1] = h->d_coarse[1 - jobs[a].first].data();
+		j.piv[0] = h->sys.gj_pivots; j.piv[1] = h->sys.gj_pivots + 32 * 32;
+		j.n = Nc; j.tiles = (Nc + 31) / 32;
+		nMax = std::max(nMax, Nc);
+	}
+	for (int a = 0; a < m; a++) HIP_TRY(hipEventRecord(jobs[a].h->evAssembled, side));      // from here on no sweep reads a reduced matrix
+	HIP_TRY(hipMemcpyAsync(d_gjTab.data(), h_gjTab, sizeof(GjJob) * m, hipMemcpyHostToDevice, side));
+	HIP_TRY(hipEventRecord(evGjTab, side));
+	launch_dense_inverse_batch(reinterpret_cast<const GjJob*>(d_gjTab.data()), m, nMax, side);
+	for (int a = 0; a < m; a++)
+	{
+		cuba_hip_solver* h = jobs[a].h;
+		const int Nc = 6 * h->sys.cl * h->sys.nc;
+		const size_t invBytes = sizeof(Scalar) * (size_t)Nc * Nc;
+		// (the sweep of Nc / 32 steps started in d_coarse[first] with first = steps & 1: its result is in d_coarse[0])
+		if (h->fp32Inverse()) launch_coarse_to_fp32(h->d_coarse[0].data(), h->d_coarse32[1].data(), Nc, side);
+		else launch_coarse_finish(h->d_coarse[0].data(), h->d_coarse[0].data(), Nc, side);
+		if (jobs[a].firstInvCopy)
+		{
+			if (h->fp32Inverse()) HIP_TRY(hipMemcpyAsync(h->d_firstInv32.data(), h->d_coarse32[1].data(), h->inv32Count() * sizeof(float), hipMemcpyDeviceToDevice, side));
+			else HIP_TRY(hipMemcpyAsync(h->d_firstInv.data(), h->d_coarse[0].data(), invBytes, hipMemcpyDeviceToDevice, side));
+			HIP_TRY(hipEventRecord(h->evFirstInv, side));
+		}
+		HIP_TRY(hipEventRecord(h->evInverse, side));
+	}
+	jobs.clear();
+}
+
 // Several graphs, one launch chain (include/cuba_hip.h: cuba_hip_optimize_batch).  Every handle runs ITS OWN Levenberg-Marquardt loop --
 // decisions on the device, per graph -- and everything of a trial but the PCG iterations on its own stream (linearise + Schur, set-up
 // launch, coarse inverse, trial tail: they overlap across the streams); the iterations of all graphs go out as ONE chain of batched
@@ -759,6 +817,8 @@ int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double*
 	lead->d_batchTab.resize(sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX);
 	BatchEntry* hTab = lead->h_batchTab;
 	const BatchEntry* dTab = reinterpret_cast<const BatchEntry*>(lead->d_batchTab.data());
+	lead->ensureOverlapObjects();
+	std::vector<cuba_hip_solver::CoarseJob> coarseJobs;
 	for (int i = 0; i < n; i++) hs[i]->lmRunBegin(runs[i], niter, chi2 ? chi2 + (size_t)i * niter : nullptr);
 	std::vector<int> act, inPcg;
 	std::vector<char> okv((size_t)n);
@@ -773,9 +833,10 @@ int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double*
 		for (int i : act)
 		{
 			hs[i]->schur(true);
-			ctx[i] = cuba_hip_solver::SolveCtx(); ctx[i].batched = true;
+			ctx[i] = cuba_hip_solver::SolveCtx(); ctx[i].batched = true; ctx[i].deferCoarse = &coarseJobs;
 			if (hs[i]->solveBegin(ctx[i])) okv[i] = ctx[i].result; else inPcg.push_back(i);
 		}
+		lead->launchCoarseJobs(coarseJobs);
 		if (!inPcg.empty())
 		{
 			const int m = (int)inPcg.size();

@@ -1312,7 +1312,9 @@ size_t batch_pcg2_lds_bytes(const DeviceSystem& sys) { return pcg2_lds_bytes(sys
 
 void launch_pcg_batch_iteration(const BatchEntry* tab, int n, const DeviceGraph& g0, const DeviceSystem& sys0, int gridSpmvMax, int ncMax, size_t ldsMax, int k, Scalar tol2, hipStream_t s)
 {
-	void* spmv = spmv_wants_occupancy(g0) ? (void*)pcg_spmv_batch_kernel<2, 4> : (void*)pcg_spmv_batch_kernel<2, 1>;
+	// (the 128-register instantiation holds four workgroups per compute unit instead of one or two: it is the one to use as soon as the
+	// batch's rows need more than one round of workgroups -- same source, same arithmetic, same bits)
+	void* spmv = 2LL * gridSpmvMax * n * 2 > 3 * 1024 || spmv_wants_occupancy(g0) ? (void*)pcg_spmv_batch_kernel<2, 4> : (void*)pcg_spmv_batch_kernel<2, 1>;
 	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, Scalar))spmv, dim3(gridSpmvMax, n), dim3(256), 0, s, tab, k, tol2);
 	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(PCG2_T), ldsMax, s, tab, k, k + 1, tol2, 1);
 }

@@ -362,6 +362,7 @@ struct cuba_hip_solver
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		if (h_lmRing) (void)hipHostFree(h_lmRing);
 		if (h_batchTab) (void)hipHostFree(h_batchTab);
+		if (h_gjTab) { (void)hipHostFree(h_gjTab); (void)hipEventDestroy(evGjTab); }
 		for (hipEvent_t e : batchEvents) (void)hipEventDestroy(e);
 		if (ownStream && stream) (void)hipStreamDestroy(stream);
 	}
@@ -617,12 +618,16 @@ struct cuba_hip_solver
 	bool ensureDirectPlan();
 	bool solveDirect();
 
+	struct CoarseJob { cuba_hip_solver* h; int first; bool firstInvCopy; };
+	void launchCoarseJobs(std::vector<CoarseJob>& jobs);
+	GjJob* h_gjTab = nullptr; DevBuf<unsigned char> d_gjTab; hipEvent_t evGjTab = nullptr;
 	struct SolveCtx
 	{
 		int maxIter = 0, budget = 0, predicted = 32, k0 = 0, looks = 0, eagerIters = 0;
 		Scalar tol2 = 0;
 		bool twoLevel = false, direct = false, graphs = false, converged = false, result = false;
 		bool batched = false;               // the iterations run in another handle's launch chain (cuba_hip_optimize_batch): no hipGraphs
+		std::vector<CoarseJob>* deferCoarse = nullptr;      // ... and the overlapped coarse inversion is only decided here, enqueued by launchCoarseJobs
 		volatile int* hInts = nullptr;
 		Clock::time_point tSolve0;
 	};
