@@ -262,7 +262,7 @@ __device__ __forceinline__ void lm_decide(double* st, Scalar* lamOut, double* ri
 	lamOut[0] = (Scalar)lamN;
 }
 
-__global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, const Scalar* pA, int nA, Scalar* oA, const Scalar* pB, int nB, Scalar* oB,
+__device__ __forceinline__ void reduce_report_body(const DeviceSystem& sys, const Scalar* pA, int nA, Scalar* oA, const Scalar* pB, int nB, Scalar* oB,
 	const Scalar* pC, int nC, Scalar* oC, double* lmState, Scalar* lmLam, double* lmRing)
 {
 	__shared__ Scalar sh[3][16];
@@ -286,6 +286,21 @@ __global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, c
 		__threadfence_system();
 		sys.host_flags[3] = ++(*sys.ticket);
 	}
+}
+
+
+__global__ __launch_bounds__(1024) void reduce_report_kernel(DeviceSystem sys, const Scalar* pA, int nA, Scalar* oA, const Scalar* pB, int nB, Scalar* oB,
+	const Scalar* pC, int nC, Scalar* oC, double* lmState, Scalar* lmLam, double* lmRing)
+{
+	reduce_report_body(sys, pA, nA, oA, pB, nB, oB, pC, nC, oC, lmState, lmLam, lmRing);
+}
+
+__global__ __launch_bounds__(1024) void reduce_report_batch_kernel(const BatchEntry* __restrict__ tab)
+{
+	const BatchEntry& e = tab[blockIdx.x];
+	const BatchTrial& t = e.t;
+	if (!t.reportOn) return;
+	reduce_report_body(e.sys, t.scParts, t.nA, e.sys.slots + NSLOT, t.chiParts, t.nA, e.sys.slots, t.scaleParts, 4 * t.nScale, e.sys.slots + 3 * NSLOT, t.lmState, t.lmLam, t.lmRing);
 }
 
 __global__ __launch_bounds__(256) void landmark_scale_kernel(DeviceGraph g, DeviceSystem sys, Scalar lambda, Scalar* parts)
@@ -404,7 +419,7 @@ __device__ __forceinline__ void update_pose_rows(const DeviceGraph& g, const Dev
 	for (int k = 0; k < 3; k++) g.t[3 * (size_t)i + k] = t[k];
 }
 
-__global__ __launch_bounds__(LIN_BLOCK) void trial_tail_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
+__device__ __forceinline__ void trial_tail_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda,
 	const Scalar* __restrict__ old, Scalar* __restrict__ scParts, Scalar* __restrict__ chiParts, int nLmGroups, int poseBlocks, Scalar* __restrict__ scaleParts, int nScale)
 {
 	lambda = launch_lambda(sys, lambda);
@@ -518,6 +533,21 @@ __global__ __launch_bounds__(LIN_BLOCK) void trial_tail_kernel(DeviceGraph g, De
 	}
 }
 
+
+__global__ __launch_bounds__(LIN_BLOCK) void trial_tail_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
+	const Scalar* __restrict__ old, Scalar* __restrict__ scParts, Scalar* __restrict__ chiParts, int nLmGroups, int poseBlocks, Scalar* __restrict__ scaleParts, int nScale)
+{
+	trial_tail_body(g, st, sys, lambda, old, scParts, chiParts, nLmGroups, poseBlocks, scaleParts, nScale);
+}
+
+__global__ __launch_bounds__(LIN_BLOCK) void trial_tail_batch_kernel(const BatchEntry* __restrict__ tab)
+{
+	const BatchEntry& e = tab[blockIdx.y];
+	const BatchTrial& t = e.t;
+	if (blockIdx.x >= t.tailGrid) return;
+	trial_tail_body(e.g, e.st, e.sys, Scalar(-1), t.old, t.scParts, t.chiParts, t.nLm, t.poseBlocks, t.scaleParts, t.nScale);
+}
+
 // landmarks with more than 64 observations: one workgroup each (free or fixed: their edges are evaluated either way)
 __global__ __launch_bounds__(256) void big_trial_tail_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
 	const Scalar* __restrict__ old, Scalar* __restrict__ scParts, Scalar* __restrict__ chiParts)
@@ -616,6 +646,23 @@ void launch_trial_tail_fused(const DeviceGraph& g, const DeviceStructure& st, co
 		decide ? decide->state : (double*)nullptr, decide ? decide->lam : (Scalar*)nullptr, decide ? decide->ring : (double*)nullptr);
 }
 
+// launch_trial_tail_fused + launch_restore_if_rejected of one graph as entries of the batched launches (no landmark with more than 64 observations)
+void batch_fill_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const Scalar* old, const LmDevice& lm, Scalar* state, size_t stateCount, BatchTrial& t)
+{
+	const int nLm = (st.nWaves + LIN_BLOCK / WAVE - 1) / (LIN_BLOCK / WAVE);
+	const int nA = nLm + st.nBig;
+	t.scParts = sys.parts;
+	t.chiParts = sys.parts + (size_t)(nA + 63) / 64 * 64;
+	t.scaleParts = t.chiParts + (size_t)(nA + 63) / 64 * 64;
+	t.poseBlocks = (g.Pf + LIN_BLOCK - 1) / LIN_BLOCK;
+	t.nScale = g.Pf > 0 ? min((g.Pf * 6 + 255) / 256, 256) : 0;
+	t.nLm = nLm; t.nA = nA; t.old = old;
+	t.tailGrid = (unsigned)(nLm + t.poseBlocks + t.nScale);
+	t.lmState = lm.state; t.lmLam = lm.lam; t.lmRing = lm.ring; t.reportOn = 1;
+	t.state = state; t.stateCount = stateCount;
+	t.restoreGrid = (unsigned)std::min<size_t>(512, (stateCount + 255) / 256);
+}
+
 // decision of a trial whose reduced solve failed + the report, one thread
 __global__ void lm_decide_failed_kernel(DeviceSystem sys, double* lmState, Scalar* lmLam, double* lmRing)
 {
@@ -636,6 +683,16 @@ void launch_lm_decide_failed(const DeviceSystem& sys, const LmDevice& lm, hipStr
 }
 
 // the reference's pop() when -- and only when -- the decision before it was a rejection
+__global__ __launch_bounds__(256) void restore_if_rejected_batch_kernel(const BatchEntry* __restrict__ tab)
+{
+	const BatchTrial& t = tab[blockIdx.y].t;
+	if (blockIdx.x >= t.restoreGrid || t.lmState[5] != 0.0) return;
+	const size_t stride = (size_t)t.restoreGrid * 256;
+	const Scalar* __restrict__ backup = t.backupDst;
+	Scalar* __restrict__ state = t.state;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < t.stateCount; i += stride) state[i] = backup[i];
+}
+
 __global__ __launch_bounds__(256) void restore_if_rejected_kernel(Scalar* __restrict__ state, const Scalar* __restrict__ backup, size_t count, const double* lmState)
 {
 	if (lmState[5] != 0.0) return;
@@ -647,6 +704,13 @@ void launch_restore_if_rejected(Scalar* state, const Scalar* backup, size_t coun
 {
 	const unsigned grid = (unsigned)std::min<size_t>(512, (count + 255) / 256);
 	if (grid) hipLaunchKernelGGL(restore_if_rejected_kernel, dim3(grid), dim3(256), 0, s, state, backup, count, lm.state);
+}
+
+void launch_batch_tail(const BatchEntry* tab, int n, unsigned tailGridMax, unsigned restoreGridMax, hipStream_t s)
+{
+	if (tailGridMax) hipLaunchKernelGGL(trial_tail_batch_kernel, dim3(tailGridMax, n), dim3(LIN_BLOCK), 0, s, tab);
+	hipLaunchKernelGGL(reduce_report_batch_kernel, dim3(n), dim3(1024), 0, s, tab);
+	if (restoreGridMax) hipLaunchKernelGGL(restore_if_rejected_batch_kernel, dim3(restoreGridMax, n), dim3(256), 0, s, tab);
 }
 
 }  // namespace cubahip

@@ -212,12 +212,36 @@ void launch_pcg_iteration(const DeviceGraph& g, const DeviceStructure& st, const
 // ---- batched execution (cuba_hip_optimize_batch): the PCG iterations of several graphs as ONE launch chain ---------------------------
 // Device table entry of one graph: what its kernels otherwise receive as kernel arguments.  The batched kernels take blockIdx.y as the
 // graph number; a graph whose reduced solve has finished keeps its entry (its `done` flag makes its workgroups return at once).
+struct LmDevice;
+struct BatchTrial               // per-graph arguments of the batched launches around the iterations (a grid of 0: the graph sits this launch out)
+{
+	// landmark pass (+ state backup), pose + block pass
+	unsigned lmGroups = 0, lmGrid = 0; const Scalar* backupSrc = nullptr; Scalar* backupDst = nullptr; size_t backupCount = 0;
+	int poseGroups = 0; unsigned schurGrid = 0;
+	// PCG set-up launch (+ row-ordered copy + copy of a fresh coarse inverse), first preconditioner application
+	int nSetup = 0; size_t expandTotal = 0; unsigned nExpand = 0; const Scalar* copySrc = nullptr; Scalar* copyDst = nullptr; size_t copyPairs = 0; unsigned setupGrid = 0;
+	int fusedOn = 0;
+	// trial tail, sums + decision + report, conditional restore
+	const Scalar* old = nullptr; Scalar *scParts = nullptr, *chiParts = nullptr, *scaleParts = nullptr; int nLm = 0, poseBlocks = 0, nScale = 0; unsigned tailGrid = 0; int nA = 0;
+	double* lmState = nullptr; Scalar* lmLam = nullptr; double* lmRing = nullptr; int reportOn = 0;
+	Scalar* state = nullptr; size_t stateCount = 0; unsigned restoreGrid = 0;
+};
 struct BatchEntry
 {
 	DeviceGraph g; DeviceStructure st; DeviceSystem sys;
 	int maxIter = 0;
 	int gridSpmv = 0;              // workgroups of this graph's SpMV launch (the batched grid is the maximum over the graphs)
+	BatchTrial t;
 };
+// the batched launches of one trial (every graph's kernels, arguments and order as launch_linearize_dm / launch_pcg_setup_expand /
+// launch_pcg2_fused(k = 0) / launch_trial_tail_fused + launch_restore_if_rejected issue them for one graph)
+void batch_fill_linearize(const DeviceGraph& g, const DeviceStructure& st, const Scalar* backupSrc, Scalar* backupDst, size_t backupCount, BatchTrial& t);
+void launch_batch_linearize(const BatchEntry* tab, int n, unsigned lmGridMax, unsigned schurGridMax, bool mixed, hipStream_t s);
+void batch_fill_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const Scalar* copySrc, Scalar* copyDst, size_t copyCount, BatchTrial& t);
+void launch_batch_setup(const BatchEntry* tab, int n, unsigned gridMax, hipStream_t s);
+void launch_batch_first_precond(const BatchEntry* tab, int n, const DeviceSystem& sys0, int ncMax, size_t ldsMax, Scalar tol2, hipStream_t s);
+void batch_fill_tail(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const Scalar* old, const LmDevice& lm, Scalar* state, size_t stateCount, BatchTrial& t);
+void launch_batch_tail(const BatchEntry* tab, int n, unsigned tailGridMax, unsigned restoreGridMax, hipStream_t s);
 int batch_kernel_class(const DeviceGraph& g, const DeviceSystem& sys);       // graphs of one batch must agree on it; -1 = not batchable
 size_t batch_pcg2_lds_bytes(const DeviceSystem& sys);
 // one PCG iteration (chunk-local k) of all n graphs of the table: SpMV + fused two-level kernel, 2 launches

@@ -57,13 +57,13 @@ __device__ __forceinline__ void load_pose_as(const DeviceGraph& g, int ip, ET q[
 
 // Workgroups beyond nLmGroups (optimize() only) copy the state into its backup: the push() of the LM loop rides in this launch.
 template <int MODE, typename ET>
-__global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
-	unsigned nLmGroups, const Scalar* __restrict__ backupSrc, Scalar* __restrict__ backupDst, size_t backupCount)
+__device__ __forceinline__ void lm_pass_body(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, Scalar lambda,
+	unsigned nLmGroups, const Scalar* __restrict__ backupSrc, Scalar* __restrict__ backupDst, size_t backupCount, unsigned gridX)
 {
 	__shared__ Scalar lds_all[(LIN_BLOCK / WAVE) * WAVE * 9];
 	if (blockIdx.x >= nLmGroups)
 	{
-		const size_t stride = (size_t)(gridDim.x - nLmGroups) * LIN_BLOCK;
+		const size_t stride = (size_t)(gridX - nLmGroups) * LIN_BLOCK;
 		for (size_t i = (size_t)(blockIdx.x - nLmGroups) * LIN_BLOCK + threadIdx.x; i < backupCount; i += stride) backupDst[i] = backupSrc[i];
 		return;
 	}
@@ -154,6 +154,23 @@ __global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, Devic
 		m = wave_max(m);
 		if (lane == 0) atomic_max_nonneg(sys.maxdiag + (wave & 63), m);
 	}
+}
+
+
+template <int MODE, typename ET>
+__global__ __launch_bounds__(LIN_BLOCK) void lm_pass_kernel(DeviceGraph g, DeviceStructure st, DeviceSystem sys, Scalar lambda,
+	unsigned nLmGroups, const Scalar* __restrict__ backupSrc, Scalar* __restrict__ backupDst, size_t backupCount)
+{
+	lm_pass_body<MODE, ET>(g, st, sys, lambda, nLmGroups, backupSrc, backupDst, backupCount, gridDim.x);
+}
+
+// batched forms (cuba_hip_optimize_batch): blockIdx.y = graph, arguments from the device table, the damping from device memory
+template <typename ET>
+__global__ __launch_bounds__(LIN_BLOCK) void lm_pass_batch_kernel(const BatchEntry* __restrict__ tab)
+{
+	const BatchEntry& e = tab[blockIdx.y];
+	if (blockIdx.x >= e.t.lmGrid) return;
+	lm_pass_body<1, ET>(e.g, e.st, e.sys, Scalar(-1), e.t.lmGroups, e.t.backupSrc, e.t.backupDst, e.t.backupCount, e.t.lmGrid);
 }
 
 // landmarks with more than 64 observations: one workgroup each
@@ -522,6 +539,15 @@ __global__ __launch_bounds__(256) void schur_pass_kernel(DeviceGraph g, DeviceSt
 	else block_pass_body<ET>(g, st, sys, blockIdx.x - nPoseGroups);
 }
 
+template <typename ET>
+__global__ __launch_bounds__(256) void schur_pass_batch_kernel(const BatchEntry* __restrict__ tab)
+{
+	const BatchEntry& e = tab[blockIdx.y];
+	if (blockIdx.x >= e.t.schurGrid) return;
+	if ((int)blockIdx.x < e.t.poseGroups) pose_pass_body<1, ET>(e.g, e.st, e.sys, blockIdx.x);
+	else block_pass_body<ET>(e.g, e.st, e.sys, blockIdx.x - e.t.poseGroups);
+}
+
 static DeviceStructure block_pass_view(const DeviceStructure& st, const BlockPassRange& r)
 {
 	DeviceStructure v = st;
@@ -570,6 +596,32 @@ void launch_linearize_dm(const DeviceGraph& g, const DeviceStructure& st, const 
 {
 	if (st.mixed && sizeof(Scalar) == 8) launch_linearize_dm_t<float>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount, range);
 	else launch_linearize_dm_t<Scalar>(g, st, sys, mode, lambda, s, backupSrc, backupDst, backupCount, range);
+}
+
+// what launch_linearize_dm_t (mode 1, whole graph, no landmark with more than 64 observations, no duplicate observation) launches for one
+// graph, as grid sizes of the batched launches
+void batch_fill_linearize(const DeviceGraph& g, const DeviceStructure& st, const Scalar* backupSrc, Scalar* backupDst, size_t backupCount, BatchTrial& t)
+{
+	t.lmGroups = (st.nWaves + (LIN_BLOCK / WAVE) - 1) / (LIN_BLOCK / WAVE);
+	const unsigned nCopy = backupSrc ? (unsigned)std::min<size_t>(512, (backupCount + LIN_BLOCK - 1) / LIN_BLOCK) : 0;
+	t.lmGrid = t.lmGroups + nCopy;
+	t.backupSrc = backupSrc; t.backupDst = backupDst; t.backupCount = backupCount;
+	t.poseGroups = (g.Pf + 3) / 4;
+	t.schurGrid = (unsigned)(t.poseGroups + block_pass_groups(st.nOd, st.nHeavy));
+}
+
+void launch_batch_linearize(const BatchEntry* tab, int n, unsigned lmGridMax, unsigned schurGridMax, bool mixed, hipStream_t s)
+{
+	if (mixed && sizeof(Scalar) == 8)
+	{
+		hipLaunchKernelGGL((lm_pass_batch_kernel<float>), dim3(lmGridMax, n), dim3(LIN_BLOCK), 0, s, tab);
+		hipLaunchKernelGGL((schur_pass_batch_kernel<float>), dim3(schurGridMax, n), dim3(256), 0, s, tab);
+	}
+	else
+	{
+		hipLaunchKernelGGL((lm_pass_batch_kernel<Scalar>), dim3(lmGridMax, n), dim3(LIN_BLOCK), 0, s, tab);
+		hipLaunchKernelGGL((schur_pass_batch_kernel<Scalar>), dim3(schurGridMax, n), dim3(256), 0, s, tab);
+	}
 }
 
 void launch_block_pass(const DeviceGraph& g, const DeviceStructure& stAll, const DeviceSystem& sys, const BlockPassRange& range, hipStream_t s)

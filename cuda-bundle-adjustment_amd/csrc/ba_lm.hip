@@ -381,10 +381,17 @@ bool cuba_hip_solver::solveBegin(SolveCtx& sc)
 		takeInverse = true; pendingInv = -1;
 	}
 	// block-Jacobi inverses, r0 / z0, flags (clears `done` and the iteration offset) + row-ordered copy of the damped matrix for the SpMV
-	if (fp32Inverse())     // the overlapped inversion left an fp32 copy in the staging buffer: that is what moves into the buffer in use
-		launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? reinterpret_cast<const Scalar*>(d_coarse32[1].data()) : nullptr,
-			reinterpret_cast<Scalar*>(d_coarse32[0].data()), inv32Count() / 2);
-	else launch_pcg_setup_expand(g, st, sys, lambda, stream, takeInverse ? d_coarse[0].data() : nullptr, d_coarse[2].data(), invCount);
+	// (cuba_hip_optimize_batch issues this launch and the first preconditioner application for all its graphs at once -- except for the
+	// first solve of a run, which puts a copy or an in-line inversion between the two)
+	const bool deferred = sc.deferLaunch && twoLevel && coarseValid;
+	{
+		const bool f32 = fp32Inverse();      // the overlapped inversion left an fp32 copy in the staging buffer: that is what moves into the buffer in use
+		const Scalar* cpSrc = !takeInverse ? nullptr : f32 ? reinterpret_cast<const Scalar*>(d_coarse32[1].data()) : d_coarse[0].data();
+		Scalar* cpDst = f32 ? reinterpret_cast<Scalar*>(d_coarse32[0].data()) : d_coarse[2].data();
+		const size_t cpCount = f32 ? inv32Count() / 2 : invCount;
+		if (deferred) { sc.deferred = true; sc.copySrc = cpSrc; sc.copyDst = cpDst; sc.copyCount = cpCount; }
+		else launch_pcg_setup_expand(g, st, sys, lambda, stream, cpSrc, cpDst, cpCount);
+	}
 	if (twoLevel)
 	{
 		// the sweep ping-pongs between two buffers: start in the one that leaves the inverse in d_coarse[0]
@@ -433,12 +440,12 @@ bool cuba_hip_solver::solveBegin(SolveCtx& sc)
 			if (regular) sideAge = 0;
 			if (regular)
 			{
-				HIP_TRY(hipEventRecord(evSetup, stream));
+				if (!deferred) HIP_TRY(hipEventRecord(evSetup, stream));        // (deferred: the batch's common event behind the batched set-up launch)
 				if (sc.deferCoarse)
 				{
 					// cuba_hip_optimize_batch sweeps the coarse matrices of all its graphs together (one launch per step for all of them, on
 					// the first handle's side stream): only the decision is taken here, launchCoarseJobs enqueues the work
-					sc.deferCoarse->push_back(CoarseJob{ this, first, firstInvPending });
+					sc.deferCoarse->push_back(CoarseJob{ this, first, firstInvPending, !deferred });
 					if (firstInvPending) { firstInvPending = false; firstInvValid = true; }
 				}
 				else
@@ -460,7 +467,7 @@ bool cuba_hip_solver::solveBegin(SolveCtx& sc)
 				assemblePending = true; cntCoarseRefresh++;
 			}
 		}
-		launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
+		if (!deferred) launch_pcg2_fused(g, sys, 0, 0, maxIter, tol2, 0, stream);
 	}
 	// first solve on this structure: the usual chunk lengths are ordered at once (the helper thread builds them while this solve runs
 	// on plain launches), longest first -- the first batches of a run are the long ones
@@ -534,8 +541,11 @@ bool cuba_hip_solver::solveReducedOnce()
 		int todo = std::max(4, std::min(target, sc.budget) - k0);
 		while (todo > 0)
 		{
-			int c = 256;
-			for (; c > 4 && c > todo; c >>= 1) {}   // largest of 256, 128, ..., 4 that fits: few graphs per batch (each hand-over costs ~9 us)
+			// without hipGraphs (the default): the whole batch as one chunk of plain launches -- chunk-local iteration numbers, then the
+			// advance / stop test / report launch, so that a batch of exactly the needed length is recognised as converged without a
+			// further look; with hipGraphs: the largest of 256, 128, ..., 4 that fits (few graphs per batch, each hand-over costs ~9 us)
+			int c = graphs ? 256 : todo;
+			for (; graphs && c > 4 && c > todo; c >>= 1) {}
 			// a batch length that comes back (repeated runs on one structure) gets a graph of exactly that length: one hand-over per
 			// batch instead of one per power of two.  Not on the first request -- the reference's timing protocol meets most lengths for
 			// the first time inside its timed part, and an instantiation costs ~2 us per node.
@@ -546,17 +556,15 @@ bool cuba_hip_solver::solveReducedOnce()
 			}
 			hipGraphExec_t exec = graphs ? pcgGraphIfReady(c, maxIter, tol2) : nullptr;
 			if (exec) { HIP_TRY(hipGraphLaunch(exec, stream)); noteReport(); }     // (every graph reports; the host waits for the last)
-			else if (graphs)
+			else
 			{
-				// the same chunk as plain launches: chunk-local iteration numbers + the advance / stop test / report node
+				// the chunk as plain launches: chunk-local iteration numbers + the advance / stop test / report node
 				for (int k = 0; k < c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 				launch_pcg_advance(sys, c, stream, tol2); noteReport();
-				eagerIters += c; cntPcgPlain += c;
+				if (graphs) { eagerIters += c; cntPcgPlain += c; }
 			}
-			else for (int k = k0; k < k0 + c; k++) enqueuePcgIteration(k, maxIter, tol2, stream);
 			k0 += c; todo -= c;
 		}
-		if (!graphs) { launch_pcg_report(sys, stream); noteReport(); }       // (graphs and chunks of plain launches end with this report)
 		waitReport();
 		if (sc.hInts[0] != 0) return solveBrokeDown(sc);
 		if (sc.hInts[2] != 0 || sc.hInts[1] < std::min(k0, maxIter)) converged = true;   // the device-side stop test fired
@@ -700,10 +708,16 @@ bool cuba_hip_solver::lmBeforeTrial(LmRun& r)
 }
 
 // after the reduced solve of trial r.enq (whose host looks follow every earlier trial's decision in the stream): false = the run has ended
-bool cuba_hip_solver::lmAfterSolve(LmRun& r, bool ok)
+bool cuba_hip_solver::lmAfterSolveHost(LmRun& r)
 {
 	lmAbsorb(r, r.enq);
 	if (r.stop) { cntTrials--; return false; }      // (an outcome nobody could foresee ended the run: the device has halted, this trial is void)
+	return true;
+}
+
+bool cuba_hip_solver::lmAfterSolve(LmRun& r, bool ok)
+{
+	if (!lmAfterSolveHost(r)) return false;
 	if (ok) launch_trial_tail_fused(g, st, sys, (Scalar)-1, d_backup.data(), stream, &r.lm);
 	else launch_lm_decide_failed(sys, r.lm, stream);
 	noteReport();
@@ -733,6 +747,12 @@ int cuba_hip_solver::optimizeDeviceDecision(int niter, double* chi2Out)
 	return lmRunEnd(r);
 }
 
+// every launch of a trial batched (one stream for all graphs): the standard launch sequence only
+bool cuba_hip_solver::fullyBatchable() const
+{
+	return batchable() && st.nBig == 0 && st.nDiagProd == 0 && st.nOd > 0 && st.nWaves > 0 && redParts.empty();
+}
+
 bool cuba_hip_solver::batchable() const
 {
 	return !profile && partHi < 0 && Pf > 0 && Lf > 0 && E > 0 && trial_tail_parts(g, st) <= d_parts.size() && batch_kernel_class(g, sys) >= 0;
@@ -741,7 +761,7 @@ bool cuba_hip_solver::batchable() const
 // The overlapped coarse inversions a batch's handles decided on in this trial (solveBegin, `regular` schedule), enqueued together on
 // THIS handle's side stream: per graph what the solo path enqueues -- wait for its set-up launch, zero + assemble, [sweep], conversion,
 // copy for the next run's first solve, events -- with the sweeps of all graphs as one launch per step (launch_dense_inverse_batch).
-void cuba_hip_solver::launchCoarseJobs(std::vector<CoarseJob>& jobs)
+void cuba_hip_solver::launchCoarseJobs(std::vector<CoarseJob>& jobs, hipEvent_t common)
 {
 	if (jobs.empty()) return;
 	ensureOverlapObjects();
@@ -755,7 +775,7 @@ void cuba_hip_solver::launchCoarseJobs(std::vector<CoarseJob>& jobs)
 	{
 		cuba_hip_solver* h = jobs[a].h;
 		const int Nc = 6 * h->sys.cl * h->sys.nc;
-		HIP_TRY(hipStreamWaitEvent(side, h->evSetup, 0));
+		HIP_TRY(hipStreamWaitEvent(side, jobs[a].ownEvent || !common ? h->evSetup : common, 0));
 		launch_coarse_assemble(h->g, h->st, h->sys, h->d_coarse[jobs[a].first].data(), side);
 		GjJob& j = h_gjTab[a];
 		j.buf[0] = h->d_coarse[jobs[a].first].data(); j.buf[1] = h->d_coarse[1 - jobs[a].first].data();
@@ -786,6 +806,160 @@ void cuba_hip_solver::launchCoarseJobs(std::vector<CoarseJob>& jobs)
 	jobs.clear();
 }
 
+// cuba_hip_optimize_batch, every launch of a trial batched: all graphs share the first handle's stream for the duration of the call, and
+// per trial the host issues -- for ALL graphs together -- landmark pass + Schur pass, the PCG set-up launch, the first preconditioner
+// application, the iterations, the trial tail + sums / decision / report + conditional restore, and on the side stream one sweep of all
+// coarse matrices that are due.  What stays per graph: host bookkeeping, the first solve of a run (a copy or an in-line inversion sits
+// between its set-up launch and its first preconditioner application), exact solves, failed solves.
+static int cuba_hip_optimize_batch_full(cuba_hip_solver** hs, int n, int niter, double* chi2, int* nDone)
+{
+	cuba_hip_solver* lead = hs[0];
+	hipStream_t bs = lead->stream;
+	struct StreamGuard
+	{
+		cuba_hip_solver** hs; int n; std::vector<hipStream_t> own;
+		StreamGuard(cuba_hip_solver** h, int m, hipStream_t s) : hs(h), n(m), own((size_t)m)
+		{
+			for (int i = 0; i < n; i++) { own[i] = hs[i]->stream; (void)hipStreamSynchronize(own[i]); hs[i]->stream = s; }
+		}
+		~StreamGuard() { if (n > 0) (void)hipStreamSynchronize(hs[0]->stream); for (int i = 0; i < n; i++) hs[i]->stream = own[i]; }
+	} streamGuard(hs, n, bs);
+	std::vector<cuba_hip_solver::LmRun> runs((size_t)n);
+	std::vector<cuba_hip_solver::SolveCtx> ctx((size_t)n);
+	lead->ensureOverlapObjects();
+	std::vector<cuba_hip_solver::CoarseJob> coarseJobs;
+	// three tables (pinned host + device), one per phase of a trial: a phase's copy has long executed when the next trial rewrites it
+	// (the host waits for the PCG reports of every trial in between)
+	if (lead->h_batchTab && lead->batchTabEntries < 3 * CUBA_HIP_BATCH_MAX) { (void)hipHostFree(lead->h_batchTab); lead->h_batchTab = nullptr; }
+	if (!lead->h_batchTab) { HIP_TRY(hipHostMalloc((void**)&lead->h_batchTab, sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX * 3, hipHostMallocDefault)); lead->batchTabEntries = 3 * CUBA_HIP_BATCH_MAX; }
+	lead->d_batchTab.resize(sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX * 3);
+	BatchEntry* hTab[3]; const BatchEntry* dTab[3];
+	for (int k = 0; k < 3; k++) { hTab[k] = lead->h_batchTab + (size_t)k * CUBA_HIP_BATCH_MAX; dTab[k] = reinterpret_cast<const BatchEntry*>(lead->d_batchTab.data()) + (size_t)k * CUBA_HIP_BATCH_MAX; }
+	auto upload = [&](int k, int m) { HIP_TRY(hipMemcpyAsync(const_cast<BatchEntry*>(dTab[k]), hTab[k], sizeof(BatchEntry) * m, hipMemcpyHostToDevice, bs)); };
+	for (int i = 0; i < n; i++) hs[i]->lmRunBegin(runs[i], niter, chi2 ? chi2 + (size_t)i * niter : nullptr);
+	const bool mixed = hs[0]->st.mixed != 0;
+	std::vector<int> act;
+	std::vector<char> okv((size_t)n), inPcg((size_t)n);
+	int batchSolves = 0;
+	for (;;)
+	{
+		act.clear();
+		for (int i = 0; i < n; i++) if (hs[i]->lmBeforeTrial(runs[i])) act.push_back(i);
+		if (act.empty()) break;
+		const int m = (int)act.size();
+		// ---- phase A: linearise + Schur (the state backup rides in the landmark pass's launch)
+		unsigned lmMax = 0, schurMax = 0;
+		for (int a = 0; a < m; a++)
+		{
+			cuba_hip_solver* h = hs[act[a]];
+			h->zeroReduced();
+			BatchEntry& e = hTab[0][a];
+			e = BatchEntry();
+			e.g = h->g; e.st = h->st; e.sys = h->sys;
+			batch_fill_linearize(h->g, h->st, h->d_state.data(), h->d_backup.data(), h->d_state.size(), e.t);
+			lmMax = std::max(lmMax, e.t.lmGrid); schurMax = std::max(schurMax, e.t.schurGrid);
+		}
+		upload(0, m);
+		launch_batch_linearize(dTab[0], m, lmMax, schurMax, mixed, bs);
+		// ---- phase B: front half of the reduced solves
+		unsigned setupMax = 0; int gridSpmvMax = 0, ncMax = 0; size_t ldsMax = 0; int target = 4, budgetMax = 0, nPcg = 0, nFused = 0;
+		Scalar tol2 = 0;
+		for (int a = 0; a < m; a++)
+		{
+			const int i = act[a];
+			cuba_hip_solver* h = hs[i];
+			ctx[i] = cuba_hip_solver::SolveCtx(); ctx[i].batched = true; ctx[i].deferCoarse = &coarseJobs; ctx[i].deferLaunch = true;
+			BatchEntry& e = hTab[1][a];
+			e = BatchEntry();
+			const bool finished = h->solveBegin(ctx[i]);
+			e.g = h->g; e.st = h->st; e.sys = h->sys;
+			if (finished) { okv[i] = ctx[i].result; inPcg[i] = 0; continue; }      // (an exact solve at once: the graph sits the batched launches out)
+			inPcg[i] = 1; nPcg++;
+			tol2 = ctx[i].tol2;
+			e.maxIter = ctx[i].maxIter;
+			e.gridSpmv = (h->g.Pf + h->sys.spmv_rows - 1) / h->sys.spmv_rows;
+			if (ctx[i].deferred) { batch_fill_setup(h->g, h->st, h->sys, ctx[i].copySrc, ctx[i].copyDst, ctx[i].copyCount, e.t); e.t.fusedOn = 1; nFused++; }
+			setupMax = std::max(setupMax, e.t.setupGrid);
+			gridSpmvMax = std::max(gridSpmvMax, e.gridSpmv); ncMax = std::max(ncMax, h->sys.nc); ldsMax = std::max(ldsMax, batch_pcg2_lds_bytes(h->sys));
+			target = std::max(target, (ctx[i].predicted + 3) / 4 * 4); budgetMax = std::max(budgetMax, ctx[i].budget);
+		}
+		if (nPcg > 0)
+		{
+			upload(1, m);
+			if (nFused > 0) launch_batch_setup(dTab[1], m, setupMax, bs);
+			HIP_TRY(hipEventRecord(lead->evSetup, bs));
+			lead->launchCoarseJobs(coarseJobs, lead->evSetup);
+			if (nFused > 0) launch_batch_first_precond(dTab[1], m, lead->sys, ncMax, ldsMax, tol2, bs);
+			// ---- the iterations of all graphs
+			int k0 = 0, looks = 0;
+			std::vector<char> conv((size_t)n, 0), broke((size_t)n, 0);
+			bool all = false;
+			while (k0 < budgetMax && !all)
+			{
+				int todo = std::max(4, std::min(target, budgetMax) - k0);
+				while (todo > 0)
+				{
+					const int c = todo;
+					for (int k = 0; k < c; k++) launch_pcg_batch_iteration(dTab[1], m, lead->g, lead->sys, gridSpmvMax, ncMax, ldsMax, k, tol2, bs);
+					launch_pcg_batch_advance(dTab[1], m, c, bs, tol2);
+					for (int i : act) if (inPcg[i]) hs[i]->noteReport();
+					k0 += c; todo -= c;
+				}
+				all = true;
+				for (int i : act)
+				{
+					if (!inPcg[i]) continue;
+					cuba_hip_solver* h = hs[i];
+					h->waitReport();
+					const volatile int* f = ctx[i].hInts;
+					if (f[0] != 0) broke[i] = 1;
+					else if (f[2] != 0 || f[1] < std::min(k0, ctx[i].maxIter)) conv[i] = 1;
+					if (!broke[i] && !conv[i] && k0 < ctx[i].budget) all = false;
+					h->cntPcgLooks++; h->cntHostLooks++;
+				}
+				target = k0 + ((looks == 0 && k0 <= 96) ? 4 : std::max(8, k0 / 8 / 4 * 4));
+				looks++;
+			}
+			for (int i : act)
+			{
+				if (!inPcg[i]) continue;
+				cuba_hip_solver::SolveCtx& sc = ctx[i];
+				sc.k0 = std::min(k0, std::max(sc.budget, 4)); sc.looks = looks; sc.eagerIters = 0; sc.converged = conv[i] != 0;
+				okv[i] = hs[i]->retryWithFp64Inverse(broke[i] ? hs[i]->solveBrokeDown(sc) : hs[i]->solveEnd(sc));
+			}
+			batchSolves++;
+		}
+		else lead->launchCoarseJobs(coarseJobs, nullptr);
+		// ---- phase C: trial tails, decisions, reports, conditional restores
+		unsigned tailMax = 0, restoreMax = 0;
+		for (int a = 0; a < m; a++)
+		{
+			const int i = act[a];
+			cuba_hip_solver* h = hs[i];
+			BatchEntry& e = hTab[2][a];
+			e = BatchEntry();
+			e.g = h->g; e.st = h->st; e.sys = h->sys;
+			if (!h->lmAfterSolveHost(runs[i])) continue;          // (the run has ended: nothing of this trial is launched)
+			batch_fill_tail(h->g, h->st, h->sys, h->d_backup.data(), runs[i].lm, h->d_state.data(), h->d_state.size(), e.t);
+			e.t.backupDst = h->d_backup.data();
+			if (!okv[i])
+			{
+				// (a failed reduced solve: the decision alone, at once; the batched restore launch follows it in the stream)
+				launch_lm_decide_failed(h->sys, runs[i].lm, bs);
+				e.t.tailGrid = 0; e.t.reportOn = 0;
+			}
+			tailMax = std::max(tailMax, e.t.tailGrid); restoreMax = std::max(restoreMax, e.t.restoreGrid);
+			h->noteReport();
+			runs[i].enq++;
+		}
+		upload(2, m);
+		launch_batch_tail(dTab[2], m, tailMax, restoreMax, bs);
+		(void)hipStreamQuery(bs);
+	}
+	for (int i = 0; i < n; i++) nDone[i] = hs[i]->lmRunEnd(runs[i]);
+	return batchSolves;
+}
+
 // Several graphs, one launch chain (include/cuba_hip.h: cuba_hip_optimize_batch).  Every handle runs ITS OWN Levenberg-Marquardt loop --
 // decisions on the device, per graph -- and everything of a trial but the PCG iterations on its own stream (linearise + Schur, set-up
 // launch, coarse inverse, trial tail: they overlap across the streams); the iterations of all graphs go out as ONE chain of batched
@@ -806,6 +980,9 @@ int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double*
 		for (int i = 0; i < n; i++) nDone[i] = hs[i]->optimize(niter, chi2 ? chi2 + (size_t)i * niter : nullptr);
 		return 0;
 	}
+	bool full = true;
+	for (int i = 0; i < n && full; i++) full = hs[i]->fullyBatchable() && hs[i]->st.mixed == hs[0]->st.mixed;
+	if (full) return cuba_hip_optimize_batch_full(hs, n, niter, chi2, nDone);
 	cuba_hip_solver* lead = hs[0];
 	hipStream_t bs = lead->stream;
 	std::vector<cuba_hip_solver::LmRun> runs((size_t)n);
@@ -813,8 +990,8 @@ int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double*
 	std::vector<hipEvent_t>& evJoin = lead->batchEvents;
 	while ((int)evJoin.size() < n + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evJoin.push_back(e); }
 	hipEvent_t evFork = evJoin[n];
-	if (!lead->h_batchTab) HIP_TRY(hipHostMalloc((void**)&lead->h_batchTab, sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX, hipHostMallocDefault));
-	lead->d_batchTab.resize(sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX);
+	if (!lead->h_batchTab) { HIP_TRY(hipHostMalloc((void**)&lead->h_batchTab, sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX * 3, hipHostMallocDefault)); lead->batchTabEntries = 3 * CUBA_HIP_BATCH_MAX; }
+	lead->d_batchTab.resize(sizeof(BatchEntry) * CUBA_HIP_BATCH_MAX * 3);
 	BatchEntry* hTab = lead->h_batchTab;
 	const BatchEntry* dTab = reinterpret_cast<const BatchEntry*>(lead->d_batchTab.data());
 	lead->ensureOverlapObjects();
@@ -861,9 +1038,8 @@ int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double*
 				int todo = std::max(4, std::min(target, budgetMax) - k0);
 				while (todo > 0)
 				{
-					int c = 256;
-					for (; c > 4 && c > todo; c >>= 1) {}
-					// chunk-local iteration numbers + the advance / stop test / report launch, as a lone handle enqueues a chunk it has no hipGraph for
+					const int c = todo;
+					// chunk-local iteration numbers + the advance / stop test / report launch, as a lone handle enqueues its batches
 					for (int k = 0; k < c; k++) launch_pcg_batch_iteration(dTab, m, lead->g, lead->sys, gridSpmvMax, ncMax, ldsMax, k, tol2, bs);
 					launch_pcg_batch_advance(dTab, m, c, bs, tol2);
 					for (int a = 0; a < m; a++) hs[inPcg[a]]->noteReport();

@@ -174,6 +174,22 @@ __global__ __launch_bounds__(256) void pcg_setup_expand_kernel(DeviceGraph g, De
 	}
 }
 
+__global__ __launch_bounds__(256) void pcg_setup_expand_batch_kernel(const BatchEntry* __restrict__ tab)
+{
+	const BatchEntry& e = tab[blockIdx.y];
+	const BatchTrial& t = e.t;
+	if (blockIdx.x >= t.setupGrid) return;
+	if ((int)blockIdx.x < t.nSetup) pcg_setup_body<true>(e.g, e.st, e.sys, Scalar(-1), blockIdx.x, t.nSetup);
+	else if (blockIdx.x < t.nSetup + t.nExpand) hsc_expand_body<true>(e.st, e.sys, t.expandTotal, blockIdx.x - t.nSetup);
+	else
+	{
+		const Scalar2* __restrict__ src = reinterpret_cast<const Scalar2*>(t.copySrc);
+		Scalar2* __restrict__ dst = reinterpret_cast<Scalar2*>(t.copyDst);
+		const size_t stride = (size_t)(t.setupGrid - t.nSetup - t.nExpand) * 256;
+		for (size_t i = (size_t)(blockIdx.x - t.nSetup - t.nExpand) * 256 + threadIdx.x; i < t.copyPairs; i += stride) dst[i] = src[i];
+	}
+}
+
 void launch_hsc_expand(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, hipStream_t s)
 {
 	const size_t total = (size_t)g.Pf * st.ell_m * 20 * 36;
@@ -191,6 +207,23 @@ void launch_pcg_setup_expand(const DeviceGraph& g, const DeviceStructure& st, co
 	const unsigned nCopy = pairs ? (unsigned)std::min<size_t>(1024, (pairs + 255) / 256) : 0;
 	hipLaunchKernelGGL(pcg_setup_expand_kernel, dim3(nSetup + nExpand + nCopy), dim3(256), 0, s, g, st, sys, lambda, nSetup, total, nExpand,
 		reinterpret_cast<const Scalar2*>(copySrc), reinterpret_cast<Scalar2*>(copyDst), pairs);
+}
+
+// launch_pcg_setup_expand's grid composition for one graph of a batch
+void batch_fill_setup(const DeviceGraph& g, const DeviceStructure& st, const DeviceSystem& sys, const Scalar* copySrc, Scalar* copyDst, size_t copyCount, BatchTrial& t)
+{
+	t.expandTotal = sys.upper ? 0 : (size_t)g.Pf * st.ell_m * 20 * 36;
+	t.nSetup = (g.Pf + PCG_SETUP_POSES - 1) / PCG_SETUP_POSES;
+	t.nExpand = (unsigned)((t.expandTotal + 255) / 256);
+	t.copyPairs = copySrc ? copyCount / 2 : 0;
+	const unsigned nCopy = t.copyPairs ? (unsigned)std::min<size_t>(1024, (t.copyPairs + 255) / 256) : 0;
+	t.copySrc = copySrc; t.copyDst = copyDst;
+	t.setupGrid = t.nSetup + t.nExpand + nCopy;
+}
+
+void launch_batch_setup(const BatchEntry* tab, int n, unsigned gridMax, hipStream_t s)
+{
+	if (gridMax) hipLaunchKernelGGL(pcg_setup_expand_batch_kernel, dim3(gridMax, n), dim3(256), 0, s, tab);
 }
 
 // N entries of one lane at once: all 9 N (16-byte) loads are issued before the first use. Padding entries (column -1)
@@ -857,7 +890,9 @@ template <int CL, int AC, int AC2, int W>
 __global__ __launch_bounds__(PCG2_T) void pcg2_fused_batch_kernel(const BatchEntry* __restrict__ tab, int k, int kOut, Scalar tol2, int doUpdate)
 {
 	const BatchEntry& e = tab[blockIdx.y];
-	if ((int)blockIdx.x >= e.sys.nc) return;
+	// (a graph whose solve is not part of the iterations -- it went to the exact solver -- has gridSpmv = 0; doUpdate = 0: the first
+	// application, flagged graphs only)
+	if ((int)blockIdx.x >= e.sys.nc || e.gridSpmv == 0 || (doUpdate == 0 && e.t.fusedOn == 0)) return;
 	pcg2_fused_body<CL, AC, AC2, W, false>(e.g, e.sys, k, kOut, e.maxIter, tol2, doUpdate);
 }
 
@@ -1257,6 +1292,7 @@ __global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n
 
 __global__ __launch_bounds__(64) void pcg_advance_batch_kernel(const BatchEntry* __restrict__ tab, int n, int report, Scalar tol2)
 {
+	if (tab[blockIdx.x].gridSpmv == 0) return;
 	pcg_advance_body(tab[blockIdx.x].sys, n, report, tol2);
 }
 
@@ -1317,6 +1353,11 @@ void launch_pcg_batch_iteration(const BatchEntry* tab, int n, const DeviceGraph&
 	void* spmv = 2LL * gridSpmvMax * n * 2 > 3 * 1024 || spmv_wants_occupancy(g0) ? (void*)pcg_spmv_batch_kernel<2, 4> : (void*)pcg_spmv_batch_kernel<2, 1>;
 	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, Scalar))spmv, dim3(gridSpmvMax, n), dim3(256), 0, s, tab, k, tol2);
 	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(PCG2_T), ldsMax, s, tab, k, k + 1, tol2, 1);
+}
+
+void launch_batch_first_precond(const BatchEntry* tab, int n, const DeviceSystem& sys0, int ncMax, size_t ldsMax, Scalar tol2, hipStream_t s)
+{
+	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(PCG2_T), ldsMax, s, tab, 0, 0, tol2, 0);
 }
 
 void launch_pcg_batch_advance(const BatchEntry* tab, int n, int iters, hipStream_t s, Scalar tol2)

@@ -618,8 +618,8 @@ struct cuba_hip_solver
 	bool ensureDirectPlan();
 	bool solveDirect();
 
-	struct CoarseJob { cuba_hip_solver* h; int first; bool firstInvCopy; };
-	void launchCoarseJobs(std::vector<CoarseJob>& jobs);
+	struct CoarseJob { cuba_hip_solver* h; int first; bool firstInvCopy; bool ownEvent; };
+	void launchCoarseJobs(std::vector<CoarseJob>& jobs, hipEvent_t common = nullptr);
 	GjJob* h_gjTab = nullptr; DevBuf<unsigned char> d_gjTab; hipEvent_t evGjTab = nullptr;
 	struct SolveCtx
 	{
@@ -628,6 +628,9 @@ struct cuba_hip_solver
 		bool twoLevel = false, direct = false, graphs = false, converged = false, result = false;
 		bool batched = false;               // the iterations run in another handle's launch chain (cuba_hip_optimize_batch): no hipGraphs
 		std::vector<CoarseJob>* deferCoarse = nullptr;      // ... and the overlapped coarse inversion is only decided here, enqueued by launchCoarseJobs
+		bool deferLaunch = false;           // ... and neither are the set-up launch and the first preconditioner application (when `deferred` comes back true)
+		bool deferred = false;
+		const Scalar* copySrc = nullptr; Scalar* copyDst = nullptr; size_t copyCount = 0;      // the set-up launch's copy of a fresh coarse inverse
 		volatile int* hInts = nullptr;
 		Clock::time_point tSolve0;
 	};
@@ -670,11 +673,13 @@ struct cuba_hip_solver
 	void lmRunBegin(LmRun& r, int niter, double* chi2Out);
 	void lmAbsorb(LmRun& r, int upto);
 	bool lmBeforeTrial(LmRun& r);
+	bool lmAfterSolveHost(LmRun& r);
 	bool lmAfterSolve(LmRun& r, bool ok);
+	bool fullyBatchable() const;
 	int lmRunEnd(LmRun& r);
 	bool batchable() const;
 	std::vector<hipEvent_t> batchEvents;        // (the lead handle of a batch owns the join / fork events and the device table)
-	BatchEntry* h_batchTab = nullptr;
+	BatchEntry* h_batchTab = nullptr; int batchTabEntries = 0;
 	DevBuf<unsigned char> d_batchTab;
 	DevBuf<double> d_lmState; DevBuf<Scalar> d_lamS;
 	double* h_lmRing = nullptr; double* lmRingDev = nullptr;

@@ -836,6 +836,16 @@ def test_batched_execution_is_bit_identical_to_solo_runs(solvers):
         h.set_state(fp.q, fp.t, fp.Xw)
     again, batched2 = optimize_batch(hs, n_it)
     assert batched2 > 0 and all(rel(a, b) < 1e-8 for a, b in zip(again, solo))
+    # graphs outside the standard launch sequence (a landmark with more than 64 observations): the iterations are still batched, the rest of
+    # a trial runs per graph on its own stream -- same results
+    gb, _ = graph_with_big_landmarks()
+    fpb = flatten(gb)
+    want_b = HipSolver(fpb, RK_HUBER).optimize(6)["chi2"]
+    hb = [HipSolver(fpb, RK_HUBER), HipSolver(fps[1], RK_HUBER)]
+    rb, bb = optimize_batch(hb, 6)
+    assert bb > 0 and np.array_equal(rb[0], want_b) and np.array_equal(rb[1], solo[1][:6])
+    for h in hb:
+        h.close()
     # a handle of another size class in the batch: the call falls back to one handle after the other
     small = flatten(synth_ba(40, 600, 2400, seed=1))
     want_small = HipSolver(small, RK_HUBER).optimize(5)["chi2"]
