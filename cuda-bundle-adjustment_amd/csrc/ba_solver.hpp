@@ -71,6 +71,10 @@ public:
 		{
 			release();
 			if (n) HIP_TRY(hipMalloc((void**)&ptr_, n * sizeof(T)));
+			// (debugging aid, CUBA_HIP_POISON=1: fresh device memory is filled with 0xff bytes -- NaN as floating point, -1 as an index --
+			// so that a read of memory nobody wrote shows at once instead of depending on what the allocator hands back)
+			static const bool poison = std::getenv("CUBA_HIP_POISON") != nullptr;
+			if (n && poison) HIP_TRY(hipMemset(ptr_, 0xff, n * sizeof(T)));
 			cap_ = n;
 		}
 		size_ = n;

@@ -315,6 +315,29 @@ def test_shuffled_pose_ids(solvers, name):
     assert np.all(np.abs(got - ref_ord) <= CHI2_TOL * ref_ord)
 
 
+def test_exact_solver_for_every_solve(solvers):
+    """Option reduced_solver = 1: EVERY reduced solve is the exact sparse Cholesky (the reference's behaviour: its SparseLinearSolver is the
+    only solver it has, src/cuda_linear_solver.cpp:386-415) -- on an id-ordered graph, on shuffled pose ids (the solver's tile order is
+    built on the INTERNAL pose order, its increment comes back in the caller's), and with fixed vertices: the oracle's trajectory to 1e-9 (both
+    sides solve exactly), estimates to 1e-9 m, no PCG iteration at all, repeat runs bit-identical; one solve's increment against the oracle's."""
+    from conftest import with_fixed
+    HipSolver, OracleSolver = solvers
+    g = synth_ba(200, 8000, 32000, seed=13)
+    for label, gg in (("ordered", g), ("shuffled ids", shuffled_pose_ids(g, seed=2)), ("fixed vertices", with_fixed(g, fixed_pose_rows=[3, 4, 20], fixed_lm_rows=list(range(0, 300, 7))))):
+        fp = flatten(gg)
+        o = OracleSolver(fp, RK_HUBER); ro = o.optimize(8)["chi2"]
+        h = HipSolver(fp, RK_HUBER, reduced_solver=1); rh = h.optimize(8)["chi2"]
+        assert len(rh) == len(ro) and np.all(np.abs(rh - ro) <= 1e-9 * ro), (label, np.abs(rh / ro - 1).max())
+        for a, b in zip(h.state(), o.state()):
+            assert np.abs(a - b).max() <= 1e-9, label
+        assert h.counter("pcg_iterations") == 0 and h.counter("exact_solve_fallbacks") == h.counters()["lm_trials"] and h.counter("exact_solve_failures") == 0, label
+        h2 = HipSolver(fp, RK_HUBER, reduced_solver=1)
+        assert np.array_equal(h2.optimize(8)["chi2"], rh), label
+        o2 = OracleSolver(fp, RK_HUBER); o2.compute_errors(); o2.build_system(); lam = 1e-6 * o2.max_diagonal(); o2.set_lambda(lam); assert o2.solve()
+        h2.set_state(fp.q, fp.t, fp.Xw); h2.max_diagonal(); h2.set_lambda(lam); assert h2.solve()
+        assert np.abs(h2.array("xp") - o2.array("xp")).max() <= 1e-9 * np.abs(o2.array("xp")).max(), label
+
+
 def test_shuffled_pose_ids_stage_outputs_keep_the_callers_numbering(solvers):
     """With the internal renumbering active every host-pointer entry point still speaks the caller's pose order: bp, bsc, xp,
     the block pattern and the block values of Hsc, the solution -- all against the oracle in the caller's order; set_state /
