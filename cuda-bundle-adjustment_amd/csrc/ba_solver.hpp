@@ -71,10 +71,10 @@ public:
 		{
 			release();
 			if (n) HIP_TRY(hipMalloc((void**)&ptr_, n * sizeof(T)));
-			// (debugging aid, CUBA_HIP_POISON=1: fresh device memory is filled with 0xff bytes -- NaN as floating point, -1 as an index --
+			// (debugging aid, CUBA_HIP_POISON=1: fresh device memory is filled with 0x7f bytes -- 1.4e306 as a double, 3.4e38 as a float, 2^31 - 8 * 2^20 as an index (finite, so that a masked 0 x garbage stays 0) --
 			// so that a read of memory nobody wrote shows at once instead of depending on what the allocator hands back)
 			static const bool poison = std::getenv("CUBA_HIP_POISON") != nullptr;
-			if (n && poison) HIP_TRY(hipMemset(ptr_, 0xff, n * sizeof(T)));
+			if (n && poison) { HIP_TRY(hipMemset(ptr_, 0x7f, n * sizeof(T))); HIP_TRY(hipDeviceSynchronize()); }     // (the handle's streams do not wait for the null stream)
 			cap_ = n;
 		}
 		size_ = n;
