@@ -307,7 +307,7 @@ public:
 	}
 
 	// ---- optimize: the LM loop runs behind the ABI (ref :793-857) -----------------------------------
-	void optimize(int niterations) override
+	void prepareOptimize()
 	{
 		if (!initialized_) throw std::runtime_error("optimize() called before initialize()");
 		static const bool dbg = std::getenv("CUBA_HIP_DEBUG") != nullptr;      // phase breakdown of the contract wall on stderr
@@ -350,11 +350,31 @@ public:
 			(void)cuba_hip_get_counter(solver_, "graph_uploads", &uploadGeneration_);
 		}
 		lap("create + set_graph");
+	}
+
+	// (optimize() in three steps, so that cuba::optimizeBatch can run the middle one for several objects at once)
+	void optimize(int niterations) override
+	{
+		prepareOptimize();
 		std::vector<double> chi2(std::max(niterations, 1), 0.0);
 		int done = 0;
 		check(cuba_hip_optimize(solver_, niterations, chi2.data(), &done), "cuba_hip_optimize");
+		finishOptimize(chi2.data(), done);
+	}
+
+	cuba_hip_solver* handle() const { return solver_; }
+
+	void finishOptimize(const double* chi2, int done)
+	{
+		static const bool dbg = std::getenv("CUBA_HIP_DEBUG") != nullptr;
+		auto tl = std::chrono::steady_clock::now();
+		auto lap = [&](const char* what) {
+			if (!dbg) return;
+			const auto now = std::chrono::steady_clock::now();
+			std::fprintf(stderr, "[cuba host] %-28s %7.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - tl).count());
+			tl = now;
+		};
 		for (int i = 0; i < done; i++) stats_.push_back({ i, chi2[i] });
-		lap("cuba_hip_optimize");
 
 		// finalize (ref :512-526): estimates back into the caller's vertices
 		check(cuba_hip_get_solution(solver_, q_.data(), t_.data(), Xw_.data()), "cuba_hip_get_solution");
@@ -557,5 +577,27 @@ CudaBundleAdjustment::Ptr CudaBundleAdjustment::createChecked(const size_t* layo
 }
 
 CudaBundleAdjustment::~CudaBundleAdjustment() = default;
+
+// Extension (no counterpart in the reference's API): optimize() of several objects in ONE device launch chain (cuba_hip_optimize_batch).
+// Every object ends exactly where its own optimize(niterations) would have ended -- estimates written back into its vertices,
+// batchStatistics(), chiSquared() -- bit for bit; objects the device library cannot batch are run one after the other by it.
+void optimizeBatch(CudaBundleAdjustment* const* objects, int n, int niterations)
+{
+	if (n <= 0) return;
+	std::vector<HipBundleAdjustment*> impl((size_t)n);
+	std::vector<cuba_hip_solver*> handles((size_t)n);
+	for (int i = 0; i < n; i++)
+	{
+		impl[i] = dynamic_cast<HipBundleAdjustment*>(objects[i]);
+		if (!impl[i]) throw std::runtime_error("cuba::optimizeBatch: not an object of this library");
+		impl[i]->prepareOptimize();
+		handles[i] = impl[i]->handle();
+	}
+	std::vector<double> chi2((size_t)n * std::max(niterations, 1), 0.0);
+	std::vector<int> done((size_t)n, 0);
+	const int rc = cuba_hip_optimize_batch(handles.data(), n, niterations, chi2.data(), done.data(), nullptr);
+	if (rc != CUBA_HIP_OK) throw std::runtime_error(std::string("cuba_hip_optimize_batch failed: ") + cuba_hip_last_error(handles[0]));
+	for (int i = 0; i < n; i++) impl[i]->finishOptimize(chi2.data() + (size_t)i * std::max(niterations, 1), done[i]);
+}
 
 }  // namespace cuba

@@ -193,3 +193,25 @@ def test_sample_binary_on_a_graph_with_shuffled_pose_ids(tmp_path):
         got[name] = np.array([float(m) for m in re.findall(r"iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)])
     assert len(got["ordered"]) == len(got["shuffled"]) == 10
     assert np.all(np.abs(got["ordered"] - got["shuffled"]) <= 1e-6 * got["ordered"])
+
+
+@pytest.mark.gpu
+def test_batch_windows_cpp_api(tmp_path):
+    """cuba::optimizeBatch (this library's extension of the C++ API over cuba_hip_optimize_batch): four copies of a graph, each with its own
+    vertex / edge objects and a slightly different start, optimised one optimize() after the other and, from the same starts, together:
+    the sample itself compares every window's chi2 per iteration bit for bit (exit code), and the chi2 it prints are the C ABI path's."""
+    from cuba_amd.capi import HipSolver
+    from cuba_amd.synth import synth_ba
+    g = synth_ba(120, 6000, 24000, seed=9)
+    path = str(tmp_path / "graph.json")
+    g.to_json(path)
+    exe = os.path.join(HOST, "samples", "batch_windows")
+    out = subprocess.run([exe, path, "4", "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bit-identical: yes" in out.stdout
+    chi = [float(m) for m in re.findall(r"batch ([0-9.eE+-]+)", out.stdout)]
+    assert len(chi) == 4 and len(set(chi)) == 4                       # four different runs
+    from cuba_amd.graph import flatten
+    ref = HipSolver(flatten(g), RK_HUBER).optimize(6)["chi2"]          # window 0 = the graph file's start
+    assert abs(chi[0] - ref[-1]) <= 1e-8 * ref[-1]
+    print("\n" + out.stdout.strip().splitlines()[-1])
