@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: matrix-core busy cycles of the sparse exact solve's factorisation launches (PMC pass on its own, kernel-trace only beside it), G4M shape
 out=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/r06j_pmc -- python $GRAFT_REPO_ROOT/scripts/r06/exact_only.py g4m 5 > $out/r06j_pmc.log 2>&1
 tail -2 $out/r06j_pmc.log | cut -c1-200
 python3 - <<'PY'
