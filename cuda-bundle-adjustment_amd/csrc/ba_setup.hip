@@ -593,16 +593,34 @@ cuba_hip_solver::CoarseCfg cuba_hip_solver::coarseConfig() const
 	// that small for this many poses is widened
 	// (round 6: this used to be one loop that doubled the aggregate until BOTH conditions held -- which never happens once the aggregate's
 	// own 12 agg numbers exceed the LDS budget (a user-chosen aggregate above ~600 poses, or the automatic one beyond ~47 000 poses): the
-	// doubling ran until the integer overflowed and the division below trapped.  Now: widen for the coarse dimension only, cap the
-	// aggregate at 600 poses, and when the two vectors + the aggregate's rows still do not fit, fall back to constant coarse functions
-	// (half the coarse dimension) and finally to block-Jacobi alone.)
+	// doubling ran until the integer overflowed and the division below trapped.  Now: the aggregate is capped at 600 poses and widened by
+	// doubling only while that helps; failing that, the aggregate size that MINIMISES the footprint (12 (cl Pf / agg + agg) numbers:
+	// agg = sqrt(cl Pf)) is tried, first with the configured coarse functions, then with constant ones (half the coarse dimension: good
+	// to ~97 000 poses), and only then the preconditioner falls back to block-Jacobi alone -- where the exact solver takes over after
+	// the iteration budget anyway.)
 	int clOut = cl;
-	auto ldsFits = [&](int c, int n, int a) { return sizeof(Scalar) * (12 * (size_t)c * n + 12 * (size_t)a + 200) <= 60 * 1024; };
-	if (agg > 600) agg = 600 / spmvRows * spmvRows;
-	if (agg > 0) nc = (Pf + agg - 1) / agg;
-	while (agg > 0 && agg < 600 && (clOut * nc > 600 || !ldsFits(clOut, nc, agg))) { agg = std::min(600 / spmvRows * spmvRows, agg * 2); nc = (Pf + agg - 1) / agg; }
-	if (agg > 0 && (clOut * nc > 600 || !ldsFits(clOut, nc, agg)) && clOut == 2) clOut = 1;
-	if (agg > 0 && (clOut * nc > 600 || !ldsFits(clOut, nc, agg))) { agg = 0; nc = 0; }
+	const int aggMax = 600 / spmvRows * spmvRows;
+	auto ncOf = [&](int a) { return (Pf + a - 1) / a; };
+	auto fits = [&](int c, int a) { const int n = ncOf(a); return c * n <= 600 && sizeof(Scalar) * (12 * (size_t)c * n + 12 * (size_t)a + 200) <= 60 * 1024; };
+	if (agg > aggMax) agg = aggMax;
+	if (agg > 0)
+	{
+		bool ok = false;
+		for (int c = cl; c >= 1 && !ok; c--)
+		{
+			int a = agg;
+			while (a < aggMax && !fits(c, a)) a = std::min(aggMax, 2 * a);
+			if (!fits(c, a))
+			{
+				int m = ((int)std::ceil(std::sqrt((double)c * Pf)) + spmvRows - 1) / spmvRows * spmvRows;
+				m = std::min(aggMax, std::max(agg, m));
+				if (fits(c, m)) a = m;
+			}
+			if (fits(c, a)) { agg = a; clOut = c; ok = true; }
+		}
+		if (!ok) agg = 0;
+	}
+	nc = agg > 0 ? ncOf(agg) : 0;
 	if (nc < 2) { agg = 0; nc = 0; }
 	return CoarseCfg{ agg, agg > 0 ? clOut : cl, nc, spmvRows };
 }

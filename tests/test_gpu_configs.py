@@ -338,6 +338,33 @@ def test_exact_solver_for_every_solve(solvers):
         assert np.abs(h2.array("xp") - o2.array("xp")).max() <= 1e-9 * np.abs(o2.array("xp")).max(), label
 
 
+def test_fifty_thousand_poses(solvers):
+    """Five times configs[4]'s pose count (50 000 / 250 000 / 1 000 000): beyond round 5's limits in three places -- the dense exact solver
+    refused above 10 922 poses (the sparse one factorises this trajectory's 10 000 tile columns), the aggregate size rule of the two-level
+    preconditioner doubled without end beyond ~47 000 poses and died in an integer division (it now lands on the footprint-minimising
+    aggregate), and the row-update launch of the upper-triangle iteration truncated aggregates above 170 poses.  No oracle at this size in
+    the suite's time budget: the two reduced solvers of the library check each other -- the block PCG (default) against an exact solve in
+    every trial (reduced_solver = 1) -- over three LM iterations, and one increment to 1e-5."""
+    HipSolver, _ = solvers
+    fp = flatten(synth_ba(50000, 250000, 1000000, seed=50))
+    assert fp.Pf > 49000
+    a = HipSolver(fp, RK_HUBER); ra = a.optimize(3)["chi2"]
+    c = a.counters()
+    b = HipSolver(fp, RK_HUBER, reduced_solver=1); rb = b.optimize(3)["chi2"]
+    print(f"\n[50 k poses] chi2 {ra.tolist()} (PCG: iterations per solve {a.pcg_history()[0].tolist()}, coarse dimension {c['coarse_dim']}, "
+          f"exact hand-overs {a.counter('exact_solve_fallbacks')}) vs {rb.tolist()} (exact: {b.counter('exact_solve_fallbacks')} solves)")
+    assert len(ra) == len(rb) == 3 and np.all(np.diff(ra) < 0)
+    assert np.all(np.abs(ra - rb) <= 1e-6 * rb), np.abs(ra / rb - 1).max()
+    assert c["coarse_dim"] > 0                                       # the two-level preconditioner is in force at this size
+    assert b.counter("exact_solve_fallbacks") == b.counters()["lm_trials"] and b.counter("exact_solve_failures") == 0 and b.counter("pcg_iterations") == 0
+    lam = 1e-5 * a.max_diagonal()
+    a.set_option("pcg_tol", 1e-11); a.set_option("direct_fallback", 0); a.set_lambda(lam); assert a.solve()
+    b.max_diagonal(); b.set_lambda(lam); assert b.solve()
+    xa, xb = a.array("xp"), b.array("xp")
+    # (the PCG's tolerance bounds its residual in the preconditioned norm; at this size the increment's error is ~1e5 times that)
+    assert np.abs(xa - xb).max() <= 1e-5 * np.abs(xb).max(), np.abs(xa - xb).max() / np.abs(xb).max()
+
+
 def test_shuffled_pose_ids_stage_outputs_keep_the_callers_numbering(solvers):
     """With the internal renumbering active every host-pointer entry point still speaks the caller's pose order: bp, bsc, xp,
     the block pattern and the block values of Hsc, the solution -- all against the oracle in the caller's order; set_state /
