@@ -590,7 +590,7 @@ bool cuba_hip_solver::solveEnd(SolveCtx& sc)
 		std::fprintf(stderr, "[cuba_hip] PCG: %d iterations, %d enqueued (%d as plain launches), %d host looks (prediction %d), lambda %.3e, r0.z0 %.6e, solve %.3f ms, graphs built so far %lld\n",
 			sc.hInts[1], k0, eagerIters, looks, predicted, lambda, rz0, 1e3 * std::chrono::duration<double>(tSolve1 - sc.tSolve0).count(), (long long)gb.builds.load());
 	}
-	const int itersDone = sc.hInts[1];
+	const int itersDone = sc.itersDone >= 0 ? sc.itersDone : sc.hInts[1];
 	cntPcgIters += itersDone; cntPcgEnqueued += k0;
 	if (runIters.empty()) firstSolveIters = itersDone;
 	runIters.push_back(itersDone);
@@ -924,7 +924,11 @@ static int cuba_hip_optimize_batch_full(cuba_hip_solver** hs, int n, int niter, 
 			{
 				if (!inPcg[i]) continue;
 				cuba_hip_solver::SolveCtx& sc = ctx[i];
-				sc.k0 = std::min(k0, std::max(sc.budget, 4)); sc.looks = looks; sc.eagerIters = 0; sc.converged = conv[i] != 0;
+				sc.k0 = std::min(k0, std::max(sc.budget, 4)); sc.looks = looks; sc.eagerIters = 0;
+				// (a graph alone stops at ITS iteration budget and hands the solve over; in a batch its iterations run on while the others
+				// need them -- harmless, the exact solve replaces the iterate -- but convergence counts only within the budget)
+				sc.converged = conv[i] != 0 && sc.hInts[1] <= sc.budget;
+				if (!sc.converged && !broke[i]) sc.itersDone = std::min((int)sc.hInts[1], sc.budget);
 				okv[i] = hs[i]->retryWithFp64Inverse(broke[i] ? hs[i]->solveBrokeDown(sc) : hs[i]->solveEnd(sc));
 			}
 			batchSolves++;
@@ -1067,7 +1071,11 @@ int cuba_hip_optimize_batch_impl(cuba_hip_solver** hs, int n, int niter, double*
 				cuba_hip_solver* h = hs[i];
 				if (h != lead) HIP_TRY(hipStreamWaitEvent(h->stream, evFork, 0));
 				cuba_hip_solver::SolveCtx& sc = ctx[i];
-				sc.k0 = std::min(k0, std::max(sc.budget, 4)); sc.looks = looks; sc.eagerIters = 0; sc.converged = conv[a] != 0;
+				sc.k0 = std::min(k0, std::max(sc.budget, 4)); sc.looks = looks; sc.eagerIters = 0;
+				// (a graph alone stops at ITS iteration budget and hands the solve over; in a batch its iterations run on while the others
+				// need them -- harmless, the exact solve replaces the iterate -- but convergence counts only within the budget)
+				sc.converged = conv[a] != 0 && sc.hInts[1] <= sc.budget;
+				if (!sc.converged && !broke[a]) sc.itersDone = std::min((int)sc.hInts[1], sc.budget);
 				okv[i] = h->retryWithFp64Inverse(broke[a] ? h->solveBrokeDown(sc) : h->solveEnd(sc));
 			}
 			batchSolves++;

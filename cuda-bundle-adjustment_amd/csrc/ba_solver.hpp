@@ -628,6 +628,7 @@ struct cuba_hip_solver
 	struct SolveCtx
 	{
 		int maxIter = 0, budget = 0, predicted = 32, k0 = 0, looks = 0, eagerIters = 0;
+		int itersDone = -1;                 // >= 0: the iterations that count for this solve (a batch ran past the graph's own budget)
 		Scalar tol2 = 0;
 		bool twoLevel = false, direct = false, graphs = false, converged = false, result = false;
 		bool batched = false;               // the iterations run in another handle's launch chain (cuba_hip_optimize_batch): no hipGraphs

@@ -836,6 +836,19 @@ def test_batched_execution_is_bit_identical_to_solo_runs(solvers):
         h.set_state(fp.q, fp.t, fp.Xw)
     again, batched2 = optimize_batch(hs, n_it)
     assert batched2 > 0 and all(rel(a, b) < 1e-8 for a, b in zip(again, solo))
+    # a graph whose solves are handed to the exact solver in the middle of the batch (direct_after = 8: its first solve uses up the budget
+    # inside the batched iterations, the rest of its run goes to the exact solver at once and sits the batched launches out), beside one
+    # with every solve exact and two plain ones: each as alone
+    opts = [dict(direct_after=8), dict(reduced_solver=1), dict(), dict()]
+    want_m, hm = [], []
+    for fp, o in zip(fps[:3] + [fps[0]], opts):
+        h = HipSolver(fp, RK_HUBER, **o); want_m.append((h.optimize(6)["chi2"], h.counter("exact_solve_fallbacks"))); h.close()
+        hm.append(HipSolver(fp, RK_HUBER, **o))
+    rm, bm = optimize_batch(hm, 6)
+    assert bm > 0 and want_m[0][1] >= 5 and want_m[1][1] == 6 and want_m[2][1] == 0
+    for h, r, (w, nd) in zip(hm, rm, want_m):
+        assert np.array_equal(r, w) and h.counter("exact_solve_fallbacks") == nd
+        h.close()
     # graphs outside the standard launch sequence (a landmark with more than 64 observations): the iterations are still batched, the rest of
     # a trial runs per graph on its own stream -- same results
     gb, _ = graph_with_big_landmarks()
