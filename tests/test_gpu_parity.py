@@ -849,6 +849,15 @@ def test_batched_execution_is_bit_identical_to_solo_runs(solvers):
     for h, r, (w, nd) in zip(hm, rm, want_m):
         assert np.array_equal(r, w) and h.counter("exact_solve_fallbacks") == nd
         h.close()
+    # the all-fp32 library (the reference's USE_FLOAT32 build) batches the same way
+    solo32 = []
+    for fp in fps[:2]:
+        h = HipSolver(fp, RK_HUBER, precision="f32"); solo32.append(h.optimize(6)["chi2"]); h.close()
+    h32 = [HipSolver(fp, RK_HUBER, precision="f32") for fp in fps[:2]]
+    r32, b32 = optimize_batch(h32, 6)
+    assert b32 > 0 and all(np.array_equal(a, b) for a, b in zip(r32, solo32))
+    for h in h32:
+        h.close()
     # graphs outside the standard launch sequence (a landmark with more than 64 observations): the iterations are still batched, the rest of
     # a trial runs per graph on its own stream -- same results
     gb, _ = graph_with_big_landmarks()
