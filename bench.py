@@ -173,7 +173,17 @@ def profile_evidence(shape, keys):
     import csv
     import re
     ev = {"pmc_file": None, "stats_file": None, "stale": None, "kernels": {}}
-    pmc_path, stats_path = newest_profile(f"*_{shape}_pmc_traffic.json"), newest_profile(f"*_{shape}_kernel_stats.csv")
+    # (the traffic file taken with THESE kernel sources if there is one -- file times do not survive a checkout --, else the newest; the
+    # kernel-trace statistics of the same profiling round beside it)
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{shape}_pmc_traffic.json")), key=lambda f: (os.path.getmtime(f), f))
+    same = [f for f in cands if json.load(open(f)).get("kernel_source_sha16") == source_sha16()]
+    pmc_path = (same or cands or [None])[-1]
+    stats_path = newest_profile(f"*_{shape}_kernel_stats.csv")
+    if pmc_path:
+        twin = pmc_path.replace("_pmc_traffic.json", "_kernel_stats.csv")
+        if os.path.exists(twin):
+            stats_path = twin
     pk, sk = {}, {}
     if pmc_path:
         pj = json.load(open(pmc_path))
