@@ -73,8 +73,12 @@ public:
 			if (n) HIP_TRY(hipMalloc((void**)&ptr_, n * sizeof(T)));
 			// (debugging aid, CUBA_HIP_POISON=1: fresh device memory is filled with 0x7f bytes -- 1.4e306 as a double, 3.4e38 as a float, 2^31 - 8 * 2^20 as an index (finite, so that a masked 0 x garbage stays 0) --
 			// so that a read of memory nobody wrote shows at once instead of depending on what the allocator hands back)
-			static const bool poison = std::getenv("CUBA_HIP_POISON") != nullptr;
-			if (n && poison) { HIP_TRY(hipMemset(ptr_, 0x7f, n * sizeof(T))); HIP_TRY(hipDeviceSynchronize()); }     // (the handle's streams do not wait for the null stream)
+			// (CUBA_HIP_POISON=2: a different finite byte pattern for every allocation, so that two handles that should agree bit for bit
+			// stop doing so if either one reads memory it did not write)
+			static const int poison = std::getenv("CUBA_HIP_POISON") ? std::max(1, std::atoi(std::getenv("CUBA_HIP_POISON"))) : 0;
+			static std::atomic<unsigned> poisonCount{ 0 };
+			static const int pattern[4] = { 0x3f, 0x40, 0x3e, 0x41 };
+			if (n && poison) { HIP_TRY(hipMemset(ptr_, poison >= 2 ? pattern[poisonCount++ & 3] : 0x7f, n * sizeof(T))); HIP_TRY(hipDeviceSynchronize()); }     // (the handle's streams do not wait for the null stream)
 			cap_ = n;
 		}
 		size_ = n;
