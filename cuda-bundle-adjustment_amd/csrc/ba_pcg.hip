@@ -581,19 +581,7 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(DeviceGraph g, DeviceSt
 // P^T q_k is summed from the per-workgroup row sums the SpMV kernel leaves in sys.qpart.  Together with the local-k
 // slot addressing every global load of the kernel is issued in its first instructions (one memory round trip).
 // doUpdate = 0 (once per solve: z_0 = M^-1 r_0) still restricts r directly.
-// Workgroup size: 512 threads; 256 for coarse dimensions up to 512 (KITTI-07 shape: 504), where thread t < 256 still holds its pair of
-// restricted sums.  A lone graph does not care -- between 256 and 512 threads a run stays inside the box's 2 % noise, 768 threads (one wave
-// per row of the coarse inverse) cost 3 %, 1024 threads 50 % (profiles/r06n_fused_wg_ab.txt): the kernel is a chain of one memory round trip
-// and three barriers, not a matter of how many waves or compute units carry its loads -- but the kernel needs 165-200 registers, so a
-// compute unit holds ONE 512-thread workgroup and TWO of 256 threads: a batch of eight such graphs (336 aggregates) is one round of workgroups
-// instead of two.  (Capping the batched instantiations at 128 registers instead spills 80-120 of them: 4 x KITTI-00 18.4 -> 22.7 ms,
-// profiles/r06p_batch_waves_ab.txt.)  CUBA_PCG2_T_SMALL is the A/B knob of the build (`make libcuba_hip_wg512.so`).
-#ifndef CUBA_PCG2_T_SMALL
-#define CUBA_PCG2_T_SMALL 256
-#endif
-constexpr int PCG2_T = 512, PCG2_T_SMALL = CUBA_PCG2_T_SMALL;      // (multiples of 64, 128 ... 512)
-constexpr int PCG2_SMALL_NC = 512;                                  // coarse dimensions up to this run the small workgroup
-constexpr int pcg2_threads_for(int AC, int W) { return 64 * W * AC <= PCG2_SMALL_NC ? PCG2_T_SMALL : PCG2_T; }
+constexpr int PCG2_T = 512;
 
 // CL = coarse functions per aggregate and pose component: 1 = constant, 2 = constant + linear in the pose index.  Coarse
 // unknown (aggregate J, function a, component c) has index (6 CL) J + 6 a + c.
@@ -616,8 +604,6 @@ template <int CL, int AC, int AC2, int W, bool PRE>
 __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	constexpr int CD = 6 * CL;         // coarse unknowns per aggregate
-	constexpr int NT = pcg2_threads_for(AC, W), NW = NT / 64;      // threads, waves
-	static_assert(NT % 64 == 0 && NT >= 128 && NT <= 512, "workgroup size");
 	constexpr int QV = 16;             // SpMV-workgroup partials prefetched per coarse unknown
 	typedef typename std::conditional<W == 4, float, Scalar>::type PT;       // storage type of the coarse inverse
 	typedef typename InvVec<PT, W>::type AV;
@@ -630,7 +616,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	Scalar* sQ = sR + NcP;
 	Scalar* part = sQ + NcP;          // [8 waves][CD], reused for the 8 x CD partial sums of P^T r_{k+1}
 	Scalar* yc = part + 8 * CD;
-	Scalar* wsum = yc + CD;           // [4][NW]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
+	Scalar* wsum = yc + CD;           // [4][8]: per-wave partials of r_k.z_k, r_0.z_0, p.Ap and of the new r.z
 	Scalar* rown = wsum + 32;
 	Scalar* qown = rown + 6 * sys.agg;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -656,7 +642,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	// coarse inverse: rows CD I .. CD I + CD - 1 (= columns: symmetric, contiguous).  Wave w applies rows w, w + 8 (< CD) to
 	// the whole coarse vector -- lane l takes the columns l, l + 64, ... -- so that a row costs ONE wave reduction in one
 	// wave (a thread-per-column layout needs CD reductions in every wave plus a cross-wave stage).
-	constexpr int AR = (CD + NW - 1) / NW;   // rows per wave
+	constexpr int AR = (CD + 7) / 8;   // rows per wave
 	// AC = prefetched column PAIRS per lane and row (covers a coarse dimension of 128 AC; the rest is read later): 6 for
 	// coarse dimensions up to 768 (KITTI-00: 672), 12 beyond -- every prefetch slot past the row's end is still a load
 	// instruction on the workgroup's one CU, which is what bounds this kernel
@@ -668,7 +654,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 		if (t < sys.nrz) e_k = rz_slot(sys, k)[t];
 		if (t < sys.nrz0) e_0 = sys.rz[t];
 		if (!PRE && t < sys.npq) e_q0 = pq_slot(sys, k)[t];
-		if (!PRE && t + NT < sys.npq) e_q1 = pq_slot(sys, k)[t + NT];
+		if (!PRE && t + PCG2_T < sys.npq) e_q1 = pq_slot(sys, k)[t + PCG2_T];
 	}
 	if (t < ownN)
 	{
@@ -691,9 +677,9 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	{
 #pragma unroll
 		for (int m = 0; m < AC; m++) ainv[a][m] = AV(0);
-		if (wv + NW * a < CD)                               // wave-uniform
+		if (wv + 8 * a < CD)                               // wave-uniform
 		{
-			const PT* Arow = acinv + (size_t)(CD * I + wv + NW * a) * ld;
+			const PT* Arow = acinv + (size_t)(CD * I + wv + 8 * a) * ld;
 #pragma unroll
 			for (int m = 0; m < AC; m++) ainv[a][m] = *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * m, ld - W));   // ld is a multiple of W
 		}
@@ -703,12 +689,12 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	Scalar a_k = e_k, a_0 = e_0, a_q = e_q0 + e_q1;
 	if (doUpdate)
 	{
-		for (int u = t + NT; u < sys.nrz; u += NT) a_k += rz_slot(sys, k)[u];
-		for (int u = t + NT; u < sys.nrz0; u += NT) a_0 += sys.rz[u];
-		if (!PRE) for (int u = t + 2 * NT; u < sys.npq; u += NT) a_q += pq_slot(sys, k)[u];
+		for (int u = t + PCG2_T; u < sys.nrz; u += PCG2_T) a_k += rz_slot(sys, k)[u];
+		for (int u = t + PCG2_T; u < sys.nrz0; u += PCG2_T) a_0 += sys.rz[u];
+		if (!PRE) for (int u = t + 2 * PCG2_T; u < sys.npq; u += PCG2_T) a_q += pq_slot(sys, k)[u];
 	}
 	if (t < ownN) { rown[t] = pre_r; qown[t] = pre_q; }
-	for (int w = t + NT; w < ownN; w += NT)
+	for (int w = t + PCG2_T; w < ownN; w += PCG2_T)
 	{
 		rown[w] = rin[own0 + w];
 		qown[w] = doUpdate && !PRE ? sys.ap[own0 + w] : Scalar(0);
@@ -716,7 +702,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	// restricted sums P^T r_k and P^T q_k (fixed summation order => reproducible)
 	if (doUpdate)
 	{
-		for (int pj = t; 2 * pj < Nc; pj += NT)
+		for (int pj = t; 2 * pj < Nc; pj += PCG2_T)
 		{
 			Scalar2 s1, s2 = { 0, 0 };
 			if (pj == t)
@@ -742,7 +728,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	}
 	else
 	{
-		for (int jc = t; jc < Nc; jc += NT)       // once per solve: P^T r_0 from the residual itself
+		for (int jc = t; jc < Nc; jc += PCG2_T)       // once per solve: P^T r_0 from the residual itself
 		{
 			const int Jj = jc / CD, rem = jc - CD * Jj;
 			const int a = rem / 6, c = rem - 6 * a;
@@ -766,14 +752,14 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 #pragma unroll
 		for (int a = 0; a < AR; a++)
 		{
-			const PT* Arow = acinv + (size_t)(CD * I + min(wv + NW * a, CD - 1)) * ld;
+			const PT* Arow = acinv + (size_t)(CD * I + min(wv + 8 * a, CD - 1)) * ld;
 #pragma unroll
 			for (int m = 0; m < AC2; m++) ainv2[a][m] = *reinterpret_cast<const AV*>(Arow + min(W * lane + 64 * W * (AC + m), ld - W));
 		}
 	}
 	TRACE_MARK();
 	a_k = wave_sum(a_k); a_0 = wave_sum(a_0); a_q = wave_sum(a_q);
-	if (lane == 0) { wsum[wv] = a_k; wsum[NW + wv] = a_0; wsum[2 * NW + wv] = a_q; }
+	if (lane == 0) { wsum[wv] = a_k; wsum[8 + wv] = a_0; wsum[16 + wv] = a_q; }
 	__syncthreads();
 	Scalar alpha = 0;
 	const int kabs = k + __builtin_amdgcn_readfirstlane(kb_v);
@@ -782,7 +768,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	{
 		Scalar rzk = 0, rz0 = 0, pqk = 0;
 #pragma unroll
-		for (int w = 0; w < NW; w++) { rzk += wsum[w]; rz0 += wsum[NW + w]; pqk += wsum[2 * NW + w]; }
+		for (int w = 0; w < PCG2_T / 64; w++) { rzk += wsum[w]; rz0 += wsum[8 + w]; pqk += wsum[16 + w]; }
 		if (!(kabs < maxIter && failed == 0 && rzk > tol2 * rz0 && rzk == rzk))
 		{
 			if (blockIdx.x == 0 && threadIdx.x == 0) { *sys.done = 1; if (!(rzk == rzk)) *sys.fail = 3; }
@@ -801,7 +787,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	TRACE_MARK();
 	// ---- own rows: r_{k+1}, x_{k+1} ---------------------------------------------------------------------------
 	const int ow = t;
-	for (int w = ow; w < ownN; w += NT)
+	for (int w = ow; w < ownN; w += PCG2_T)
 	{
 		const Scalar r = rown[w] - alpha * qown[w];      // rown[w] / qown[w] were written by this very thread
 		rown[w] = r;
@@ -815,7 +801,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 #pragma unroll
 	for (int a = 0; a < AR; a++)
 	{
-		const int row = wv + NW * a;
+		const int row = wv + 8 * a;
 		Scalar acc = 0;
 #pragma unroll
 		for (int m = 0; m < AC; m++)
@@ -849,7 +835,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	TRACE_MARK();
 	// ---- z = Minv r + P yc for the poses of this aggregate; r.z ---------------------------------------------------
 	Scalar dot = 0;
-	for (int w = ow; w < ownN; w += NT)
+	for (int w = ow; w < ownN; w += PCG2_T)
 	{
 		const int il = w / 6, comp = w - 6 * il;
 		Scalar z = yc[comp];
@@ -861,7 +847,7 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 		dot += rown[w] * z;
 	}
 	dot = wave_sum(dot);
-	if (lane == 0) wsum[3 * NW + wv] = dot;
+	if (lane == 0) wsum[24 + wv] = dot;
 	// P^T r_{k+1} of the own aggregate for the next iteration, from the updated rows themselves: 8 interleaved partial
 	// sums per coarse unknown here, folded after the barrier (a single thread per unknown would chain `agg` LDS reads)
 	if (!PRE && t < 8 * CD)
@@ -885,23 +871,23 @@ __device__ __forceinline__ void pcg2_fused_body(const DeviceGraph& g, const Devi
 	{
 		Scalar s2 = 0;
 #pragma unroll
-		for (int w = 0; w < NW; w++) s2 += wsum[3 * NW + w];
+		for (int w = 0; w < PCG2_T / 64; w++) s2 += wsum[24 + w];
 		rz_slot_w(sys, kOut)[blockIdx.x] = s2;
 		if (!doUpdate) sys.rz[blockIdx.x] = s2;          // r_0.z_0: kept in slot 0 for the stop test
 		if (doUpdate && blockIdx.x == 0) *sys.iters = kabs + 1;
 	}
 	TRACE_MARK();
-	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (NT / 64) + wv);
+	if (doUpdate) TRACE_FLUSH(1, blockIdx.x * (PCG2_T / 64) + wv);
 }
 
 template <int CL, int AC, int AC2, int W, bool PRE = false>
-__global__ __launch_bounds__(pcg2_threads_for(AC, W)) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
+__global__ __launch_bounds__(PCG2_T) void pcg2_fused_kernel(DeviceGraph g, DeviceSystem sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate)
 {
 	pcg2_fused_body<CL, AC, AC2, W, PRE>(g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
 template <int CL, int AC, int AC2, int W>
-__global__ __launch_bounds__(pcg2_threads_for(AC, W)) void pcg2_fused_batch_kernel(const BatchEntry* __restrict__ tab, int k, int kOut, Scalar tol2, int doUpdate)
+__global__ __launch_bounds__(PCG2_T) void pcg2_fused_batch_kernel(const BatchEntry* __restrict__ tab, int k, int kOut, Scalar tol2, int doUpdate)
 {
 	const BatchEntry& e = tab[blockIdx.y];
 	// (a graph whose solve is not part of the iterations -- it went to the exact solver -- has gridSpmv = 0; doUpdate = 0: the first
@@ -917,16 +903,13 @@ static void* pcg2_kernel_sel(const DeviceSystem& sys)
 	if (sys.acinv32 && sizeof(Scalar) == 8)
 	{
 		// fp32 storage of the coarse inverse: a 16-byte load carries 4 columns, 3 / 6 / 6 + 3 loads per lane and row cover 768 / 1536 / 2304
-		if (Nc <= PCG2_SMALL_NC) return sys.cl == 2 ? (void*)pcg2_fused_kernel<2, 2, 0, 4, PRE> : (void*)pcg2_fused_kernel<1, 2, 0, 4, PRE>;
 		if (sys.cl == 2) return Nc <= 768 ? (void*)pcg2_fused_kernel<2, 3, 0, 4, PRE> : Nc <= 1536 ? (void*)pcg2_fused_kernel<2, 6, 0, 4, PRE> : (void*)pcg2_fused_kernel<2, 6, 3, 4, PRE>;
 		return Nc <= 768 ? (void*)pcg2_fused_kernel<1, 3, 0, 4, PRE> : Nc <= 1536 ? (void*)pcg2_fused_kernel<1, 6, 0, 4, PRE> : (void*)pcg2_fused_kernel<1, 6, 3, 4, PRE>;
 	}
-	if (Nc <= PCG2_SMALL_NC) return sys.cl == 2 ? (void*)pcg2_fused_kernel<2, 4, 0, 2, PRE> : (void*)pcg2_fused_kernel<1, 4, 0, 2, PRE>;
 	const bool small = Nc <= 768;
 	if (sys.cl == 2) return small ? (void*)pcg2_fused_kernel<2, 6, 0, 2, PRE> : (void*)pcg2_fused_kernel<2, 12, 6, 2, PRE>;
 	return small ? (void*)pcg2_fused_kernel<1, 6, 0, 2, PRE> : (void*)pcg2_fused_kernel<1, 12, 6, 2, PRE>;
 }
-static unsigned pcg2_threads(const DeviceSystem& sys) { return 6 * sys.cl * sys.nc <= PCG2_SMALL_NC ? PCG2_T_SMALL : PCG2_T; }      // = pcg2_threads_for of the instantiation chosen above
 static void* pcg2_kernel_for(const DeviceSystem& sys, bool precondOnly = false) { return precondOnly ? pcg2_kernel_sel<true>(sys) : pcg2_kernel_sel<false>(sys); }
 
 static size_t pcg2_lds_bytes(const DeviceSystem& sys)
@@ -939,7 +922,7 @@ static size_t pcg2_lds_bytes(const DeviceSystem& sys)
 void launch_pcg2_fused(const DeviceGraph& g, const DeviceSystem& sys, int k, int kOut, int maxIter, Scalar tol2, int doUpdate, hipStream_t s)
 {
 	const size_t lds = pcg2_lds_bytes(sys);
-	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys), dim3(sys.nc), dim3(pcg2_threads(sys)), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
+	hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T), lds, s, g, sys, k, kOut, maxIter, tol2, doUpdate);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1248,7 +1231,7 @@ void launch_pcg_upper_iteration(const DeviceGraph& g, const DeviceStructure& st,
 	if (which & 1) hipLaunchKernelGGL((K3)spmv_upper_kernel_for(sys), dim3(spmv_upper_grid(g.Pf)), dim3(64 * UPPER_WAVES), 0, s, g, st, sys, k, maxIter, tol2);
 	if (which & 2) hipLaunchKernelGGL(pcg_rows_kernel_for(sys), dim3(sys.nc), dim3(ROWS_T), rows_lds_bytes(sys), s, g, st, sys, k, maxIter, tol2);
 	if (which & 4)
-		hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(pcg2_threads(sys)), pcg2_lds_bytes(sys), s,
+		hipLaunchKernelGGL((void (*)(DeviceGraph, DeviceSystem, int, int, int, Scalar, int))pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(PCG2_T), pcg2_lds_bytes(sys), s,
 			g, sys, k, k + 1, maxIter, tol2, 1);
 }
 
@@ -1345,11 +1328,9 @@ static void* pcg2_batch_kernel_for(const DeviceSystem& sys)
 	const int Nc = 6 * sys.cl * sys.nc;
 	if (sys.acinv32 && sizeof(Scalar) == 8)
 	{
-		if (Nc <= PCG2_SMALL_NC) return sys.cl == 2 ? pcg2_batch_fn<2, 2, 0, 4>() : pcg2_batch_fn<1, 2, 0, 4>();
 		if (sys.cl == 2) return Nc <= 768 ? pcg2_batch_fn<2, 3, 0, 4>() : Nc <= 1536 ? pcg2_batch_fn<2, 6, 0, 4>() : pcg2_batch_fn<2, 6, 3, 4>();
 		return Nc <= 768 ? pcg2_batch_fn<1, 3, 0, 4>() : Nc <= 1536 ? pcg2_batch_fn<1, 6, 0, 4>() : pcg2_batch_fn<1, 6, 3, 4>();
 	}
-	if (Nc <= PCG2_SMALL_NC) return sys.cl == 2 ? pcg2_batch_fn<2, 4, 0, 2>() : pcg2_batch_fn<1, 4, 0, 2>();
 	const bool small = Nc <= 768;
 	if (sys.cl == 2) return small ? pcg2_batch_fn<2, 6, 0, 2>() : pcg2_batch_fn<2, 12, 6, 2>();
 	return small ? pcg2_batch_fn<1, 6, 0, 2>() : pcg2_batch_fn<1, 12, 6, 2>();
@@ -1359,7 +1340,7 @@ int batch_kernel_class(const DeviceGraph& g, const DeviceSystem& sys)
 {
 	if (sys.agg <= 0 || sys.upper || sys.spmv_rows != 2) return -1;          // (block-Jacobi-only, upper-triangle and row-per-wave iterations run one graph at a time)
 	const int Nc = 6 * sys.cl * sys.nc;
-	const int cls = (sys.acinv32 && sizeof(Scalar) == 8) ? (Nc <= PCG2_SMALL_NC ? 5 : Nc <= 768 ? 0 : Nc <= 1536 ? 1 : 2) : (Nc <= PCG2_SMALL_NC ? 6 : Nc <= 768 ? 3 : 4);
+	const int cls = (sys.acinv32 && sizeof(Scalar) == 8) ? (Nc <= 768 ? 0 : Nc <= 1536 ? 1 : 2) : (Nc <= 768 ? 3 : 4);
 	return (cls * 2 + (sys.cl == 2 ? 1 : 0)) * 2 + (spmv_wants_occupancy(g) ? 1 : 0);
 }
 
@@ -1371,12 +1352,12 @@ void launch_pcg_batch_iteration(const BatchEntry* tab, int n, const DeviceGraph&
 	// batch's rows need more than one round of workgroups -- same source, same arithmetic, same bits)
 	void* spmv = 2LL * gridSpmvMax * n * 2 > 3 * 1024 || spmv_wants_occupancy(g0) ? (void*)pcg_spmv_batch_kernel<2, 4> : (void*)pcg_spmv_batch_kernel<2, 1>;
 	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, Scalar))spmv, dim3(gridSpmvMax, n), dim3(256), 0, s, tab, k, tol2);
-	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(pcg2_threads(sys0)), ldsMax, s, tab, k, k + 1, tol2, 1);
+	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(PCG2_T), ldsMax, s, tab, k, k + 1, tol2, 1);
 }
 
 void launch_batch_first_precond(const BatchEntry* tab, int n, const DeviceSystem& sys0, int ncMax, size_t ldsMax, Scalar tol2, hipStream_t s)
 {
-	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(pcg2_threads(sys0)), ldsMax, s, tab, 0, 0, tol2, 0);
+	hipLaunchKernelGGL((void (*)(const BatchEntry*, int, int, Scalar, int))pcg2_batch_kernel_for(sys0), dim3(ncMax, n), dim3(PCG2_T), ldsMax, s, tab, 0, 0, tol2, 0);
 }
 
 void launch_pcg_batch_advance(const BatchEntry* tab, int n, int iters, hipStream_t s, Scalar tol2)
@@ -1416,14 +1397,14 @@ hipError_t graph_add_pcg_chunk(hipGraph_t graph, const DeviceGraph& g, const Dev
 		{
 			e = add_kernel_node(graph, last, spmv_upper_kernel_for(sys), dim3(spmv_upper_grid(g.Pf)), dim3(64 * UPPER_WAVES), 0, g, st, sys, k, maxIter, tol2);
 			if (e == hipSuccess) e = add_kernel_node(graph, last, (void*)pcg_rows_kernel_for(sys), dim3(sys.nc), dim3(ROWS_T), (unsigned)rows_lds_bytes(sys), g, st, sys, k, maxIter, tol2);
-			if (e == hipSuccess) e = add_kernel_node(graph, last, pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(pcg2_threads(sys)), (unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
+			if (e == hipSuccess) e = add_kernel_node(graph, last, pcg2_kernel_for(sys, true), dim3(sys.nc), dim3(PCG2_T), (unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
 			continue;
 		}
 		e = add_kernel_node(graph, last, spmv_kernel_for(g, sys), dim3((g.Pf + sys.spmv_rows - 1) / sys.spmv_rows), spmv_block_for(sys), 0, g, st, sys, k, maxIter, tol2);
 		if (e != hipSuccess) break;
 		if (sys.agg > 0)
 		{
-			e = add_kernel_node(graph, last, pcg2_kernel_for(sys), dim3(sys.nc), dim3(pcg2_threads(sys)),
+			e = add_kernel_node(graph, last, pcg2_kernel_for(sys), dim3(sys.nc), dim3(PCG2_T),
 				(unsigned)pcg2_lds_bytes(sys), g, sys, k, k + 1, maxIter, tol2, 1);
 		}
 		else e = add_kernel_node(graph, last, (void*)pcg_update_kernel, dim3((g.Pf + 39) / 40), dim3(256), 0, g, st, sys, k, maxIter, tol2);
