@@ -437,7 +437,7 @@ private:
 	static constexpr size_t kPrefetch = 12;      // objects ahead of the one being read in the pointer-chasing loops
 	static unsigned hostThreads(size_t items)
 	{
-		static const size_t grain = 20000;   // items per host thread
+		static const size_t grain = std::getenv("CUBA_HOST_GRAIN") ? (size_t)std::max(1000, std::atoi(std::getenv("CUBA_HOST_GRAIN"))) : 20000;   // items per host thread
 		return (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)cubahip::HostPool::instance().maxThreads(), items / grain + 1));
 	}
 
