@@ -649,7 +649,10 @@ void cuba_hip_solver::lmRunBegin(LmRun& r, int niter, double* chi2Out)
 	const double tau = 1e-5;
 	if (!h_lmRing)
 	{
-		HIP_TRY(hipHostMalloc((void**)&h_lmRing, sizeof(double) * LM_RING * LM_REC, hipHostMallocMapped));
+		// (coherent, like the flag block: the host reads a record as soon as it sees the ticket that follows it -- from the very kernel that wrote
+		// the record, which has not ended then; memory mapped without the flag is only guaranteed to show a kernel's stores once the kernel has
+		// completed, and a run then now and again reported 0 or a stale value as an iteration's chi2 while its estimates were right)
+		HIP_TRY(hipHostMalloc((void**)&h_lmRing, sizeof(double) * LM_RING * LM_REC, hipHostMallocMapped | hipHostMallocCoherent));
 		HIP_TRY(hipHostGetDevicePointer((void**)&lmRingDev, h_lmRing, 0));
 	}
 	coarseValid = false;

@@ -157,6 +157,23 @@ def test_two_step_set_graph_equals_the_one_call_form(solvers, small_fp):
         assert c.compute_errors() == HipSolver(fp, RK_HUBER, **opts).compute_errors()
 
 
+def test_reported_chi2_of_many_short_runs(solvers, small_fp):
+    """The per-iteration chi2 a run reports comes from records the deciding kernel writes into mapped host memory ahead of its ticket.  That
+    memory has to be coherent: round 6 found it mapped without the flag, and now and again (once in a few hundred runs) a run reported 0 or a
+    stale value for an iteration whose estimates were right -- the host had seen the ticket before the record.  Many short runs on fresh
+    handles (fresh mapped memory), PCG and exact reduced solver: every reported trajectory is the first one's, bit for bit."""
+    HipSolver, _ = solvers
+    for opts in ({}, dict(reduced_solver=1)):
+        first = None
+        for _ in range(120):
+            h = HipSolver(small_fp, RK_HUBER, **opts)
+            r = h.optimize(3)["chi2"]
+            h.close()
+            assert len(r) == 3 and np.all(r > 0)
+            if first is None: first = r
+            assert np.array_equal(r, first), (opts, r, first)
+
+
 def test_snapshot_slots_and_named_counters(solvers, small_fp):
     """cuba_hip_snapshot_state_slot / _restore_state_slot: several device-side copies of the estimates (bench.py's non-replay
     protocol); slot 0 is the slot-less pair; an absent or out-of-range slot is a reported error.  cuba_hip_get_counter: the
