@@ -243,4 +243,19 @@ __device__ __forceinline__ void linearize_edge(const DeviceGraph& g, int e, Lane
 	edge_jacobians(Xc, R, cam, out.stereo, out.lin);
 }
 
+// The report a host spins on (cuba_hip_solver::waitReport): {failure code, iterations done, stop flag} and, LAST, the ticket -- all in the
+// handle's coherent mapped host block; results the same thread stored before (the LM decision record, the sum slots) must have LANDED before
+// the ticket does.  A system-scope release fence alone is not enough here: on this compiler the wait for the outstanding stores behind the
+// fence's write-back can be dropped when the wave's store counter is provably empty at that point (microarchitecture guide, "compiler
+// hazard"), and a store to another address may then reach the host after the ticket -- seen as an iteration's chi2 reported 0 or stale once
+// in a few hundred short runs.  The explicit wait is invisible to that pass.
+__device__ __forceinline__ void publish_report(const DeviceSystem& sys)
+{
+	sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
+	__threadfence_system();
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	const int t = ++(*sys.ticket);
+	__hip_atomic_store(&sys.host_flags[3], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace cubahip

@@ -257,7 +257,8 @@ __device__ __forceinline__ void lm_decide(double* st, Scalar* lamOut, double* ri
 		if (!(fabs(lamN) <= 1.7e308)) haltN = true;           // (not finite)
 	}
 	double* rec = ring + (size_t)(trial % LM_RING) * LM_REC;
-	rec[0] = ok ? Fhat : 0.0; rec[1] = scale; rec[2] = rho; rec[3] = lamN; rec[4] = Fn; rec[5] = acc ? 1.0 : 0.0; rec[6] = haltN ? 1.0 : 0.0; rec[7] = nuN;
+	// (rec[7]: the record's identity -- run nonce and trial number -- by which the host tells a record that has landed from what the slot held before)
+	rec[0] = ok ? Fhat : 0.0; rec[1] = scale; rec[2] = rho; rec[3] = lamN; rec[4] = Fn; rec[5] = acc ? 1.0 : 0.0; rec[6] = haltN ? 1.0 : 0.0; rec[7] = st[8] + (double)(trial + 1);
 	st[0] = Fn; st[1] = lamN; st[2] = nuN; st[3] = haltN ? 1.0 : 0.0; st[4] = (double)(trial + 1); st[5] = acc ? 1.0 : 0.0; st[6] = rej;
 	lamOut[0] = (Scalar)lamN;
 }
@@ -279,13 +280,9 @@ __device__ __forceinline__ void reduce_report_body(const DeviceSystem& sys, cons
 		if (lmState && threadIdx.x == 0) lm_decide(lmState, lmLam, lmRing, 1, (double)tA, (double)tB, (double)tC);
 	}
 	__threadfence_system();          // every writer's results before the ticket
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (and landed: see publish_report)
 	__syncthreads();
-	if (threadIdx.x == 0 && sys.host_flags)
-	{
-		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
-		__threadfence_system();
-		sys.host_flags[3] = ++(*sys.ticket);
-	}
+	if (threadIdx.x == 0 && sys.host_flags) publish_report(sys);
 }
 
 
@@ -669,12 +666,7 @@ __global__ void lm_decide_failed_kernel(DeviceSystem sys, double* lmState, Scala
 	if (threadIdx.x != 0) return;
 	lm_decide(lmState, lmLam, lmRing, 0, 0.0, 0.0, 0.0);
 	__threadfence_system();
-	if (sys.host_flags)
-	{
-		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
-		__threadfence_system();
-		sys.host_flags[3] = ++(*sys.ticket);
-	}
+	if (sys.host_flags) publish_report(sys);
 }
 
 void launch_lm_decide_failed(const DeviceSystem& sys, const LmDevice& lm, hipStream_t s)

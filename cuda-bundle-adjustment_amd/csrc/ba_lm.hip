@@ -664,9 +664,10 @@ void cuba_hip_solver::lmRunBegin(LmRun& r, int niter, double* chi2Out)
 	{
 		double* st8 = reinterpret_cast<double*>(hostStage());          // (pinned staging block)
 		st8[0] = r.F; st8[1] = r.lam; st8[2] = 2.0; st8[3] = 0.0; st8[4] = 0.0; st8[5] = 1.0; st8[6] = 0.0; st8[7] = (double)LmRun::maxq;
-		Scalar* l1 = reinterpret_cast<Scalar*>(st8 + 8);
+		r.tagBase = 65536.0 * (double)(++lmRunNonce); st8[8] = r.tagBase;      // (every record of this run carries tagBase + trial number + 1)
+		Scalar* l1 = reinterpret_cast<Scalar*>(st8 + 12);
 		l1[0] = (Scalar)r.lam;
-		HIP_TRY(hipMemcpyAsync(d_lmState.data(), st8, sizeof(double) * 8, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_lmState.data(), st8, sizeof(double) * 9, hipMemcpyHostToDevice, stream));
 		HIP_TRY(hipMemcpyAsync(d_lamS.data(), l1, sizeof(Scalar), hipMemcpyHostToDevice, stream));
 	}
 	r.lm.state = d_lmState.data(); r.lm.lam = d_lamS.data(); r.lm.ring = lmRingDev;
@@ -679,6 +680,18 @@ void cuba_hip_solver::lmAbsorb(LmRun& r, int upto)
 	for (; r.seen < upto && !r.stop; r.seen++)
 	{
 		const volatile double* rec = h_lmRing + (size_t)(r.seen % LM_RING) * LM_REC;
+		// the record must be THIS run's record of THIS trial.  The ticket the caller waited for is stored after it by the same device thread
+		// behind a system-scope release (publish_report) -- and still, once in a few hundred short runs, a record had not landed when its
+		// ticket had (round 6: an iteration's chi2 came back as 0): whatever reorders the two on the way to host memory, a stream
+		// synchronisation ends it
+		const double tag = r.tagBase + (double)(r.seen + 1);
+		if (rec[7] != tag)
+		{
+			cntLateRecords++;
+			sync();
+			std::atomic_thread_fence(std::memory_order_acquire);
+			if (rec[7] != tag) throw StateError{ "the device's decision record of an LM trial never arrived" };
+		}
 		const bool acc = rec[5] != 0.0;
 		const double rho = rec[2];
 		r.lam = rec[3]; r.F = rec[4];

@@ -1280,12 +1280,7 @@ __device__ __forceinline__ void pcg_advance_body(const DeviceSystem& sys, int n,
 	}
 	if (threadIdx.x != 0) return;
 	*sys.kbase += n;
-	if (report && sys.host_flags)
-	{
-		sys.host_flags[0] = *sys.fail; sys.host_flags[1] = *sys.iters; sys.host_flags[2] = *sys.done;
-		__threadfence_system();
-		sys.host_flags[3] = ++(*sys.ticket);      // the host spins on this word instead of paying a stream-synchronise round trip
-	}
+	if (report && sys.host_flags) publish_report(sys);      // the host spins on the ticket instead of paying a stream-synchronise round trip
 }
 
 __global__ __launch_bounds__(64) void pcg_advance_kernel(DeviceSystem sys, int n, int report, Scalar tol2) { pcg_advance_body(sys, n, report, tol2); }

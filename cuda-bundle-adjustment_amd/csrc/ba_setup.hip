@@ -762,7 +762,7 @@ void cuba_hip_solver::publishStructure(int nblk, int nWaves, int nBig, int nOd, 
 	d_qpart.resize(agg > 0 ? (size_t)(agg / spmvRows) * 6 * cl * nc : 1); d_gjPivots.resize(2 * 32 * 32); sys.gj_pivots = d_gjPivots.data();
 	sys.qpart = d_qpart.data();   // [workgroup within its aggregate][coarse unknown]
 	d_qpart.zero(stream);        // sets of SpMV workgroups the last aggregate does not have are read as zeros by the two-level kernel
-	d_lamS.resize(1); d_lmState.resize(8); sys.lam_dev = d_lamS.data();
+	d_lamS.resize(1); d_lmState.resize(16); sys.lam_dev = d_lamS.data();
 	// (the row-update launch of the upper-triangle iteration keeps an aggregate's 6 agg row entries in the registers of one workgroup:
 	// beyond pcg_rows_max_aggregate() poses -- a user-set pcg_aggregate, or ~120 000 poses with the automatic one -- the two-launch form serves)
 	sys.upper = agg > 0 && agg <= pcg_rows_max_aggregate() && (spmvUpper < 0 ? spmvRows == 4 : spmvUpper != 0) ? 1 : 0;

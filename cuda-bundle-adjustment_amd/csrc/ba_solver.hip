@@ -380,6 +380,7 @@ int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value)
 		else if (k == "exact_solve_failures") *value = s->cntDirectFailed;
 		else if (k == "graph_uploads") *value = s->cntUploads;
 		else if (k == "value_bytes_uploaded") *value = s->cntValueBytes;
+		else if (k == "late_decision_records") *value = s->cntLateRecords;
 		else throw ArgError{ "unknown counter: " + k };
 	});
 }

@@ -675,7 +675,7 @@ struct cuba_hip_solver
 		static constexpr int maxq = 10;
 		int niter = 0, enq = 0, seen = 0, done = 0, rejRun = 0;
 		bool stop = false;
-		double lam = 0, F = 0;
+		double lam = 0, F = 0, tagBase = 0;
 		double* chi2Out = nullptr;
 		LmDevice lm;
 	};
@@ -691,7 +691,7 @@ struct cuba_hip_solver
 	BatchEntry* h_batchTab = nullptr; int batchTabEntries = 0;
 	DevBuf<unsigned char> d_batchTab;
 	DevBuf<double> d_lmState; DevBuf<Scalar> d_lamS;
-	double* h_lmRing = nullptr; double* lmRingDev = nullptr;
+	double* h_lmRing = nullptr; double* lmRingDev = nullptr; uint64_t lmRunNonce = 0; int64_t cntLateRecords = 0;
 	int64_t cntHostLooks = 0;           // waits of the host for a device report (PCG looks + LM decisions it had to see)
 
 	// chi2 of the trial estimate and sum x (lambda x + b) of the step that led to it, read back with ONE synchronisation

@@ -303,7 +303,9 @@ int cuba_hip_get_counters(cuba_hip_solver* s, int64_t counters[8]);
    are on: graph not instantiated yet), "graph_uploads" (successful cuba_hip_set_graph[_begin] calls in the
    life of the handle, never reset: a caller that keeps state about "what the device holds" -- the promises of cuba_hip_hint_unchanged --
    stores this number with it and distrusts its state when the two differ), "value_bytes_uploaded" (bytes of measurements and
-   information that crossed PCIe in the life of the handle: 32 per edge and full upload, 36 per OWNED edge for cuba_hip_set_graph_partition).
+   information that crossed PCIe in the life of the handle: 32 per edge and full upload, 36 per OWNED edge for cuba_hip_set_graph_partition),
+   "late_decision_records" (life of the handle: LM decision records that had not reached host memory when the report behind them had, and
+   were fetched by a stream synchronisation instead; 0 in normal operation).
    Unknown name: CUBA_HIP_ERR_INVALID_ARGUMENT. */
 int cuba_hip_get_counter(cuba_hip_solver* s, const char* name, int64_t* value);
 
