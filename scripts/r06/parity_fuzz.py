@@ -11,12 +11,13 @@ from oracle.oracle import OracleSolver
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 only = int(sys.argv[2]) if len(sys.argv) > 2 else -1       # details of one draw
+sizes = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [3, 5, 8, 13, 24, 40, 77, 130, 260, 420]      # pose counts to draw from
 rng = np.random.default_rng(2026)
 KINDS = [((0, 0.0), (0, 0.0)), ((1, float(np.sqrt(5.991))), (1, float(np.sqrt(7.815)))), ((2, 4.0), (2, 5.0)), ((1, 2.0), (2, 6.0))]
 bad = 0; soft = 0; skipped = 0; used = 0; worst = dict(chi=0.0, q=0.0, t=0.0, X=0.0, chi_exact=0.0)
 kept = []
 for it in range(n):
-    P = int(rng.choice([3, 5, 8, 13, 24, 40, 77, 130, 260, 420]))
+    P = int(rng.choice(sizes))
     L = int(rng.integers(max(20, 4 * P), 40 * P + 50))
     E = int(L * rng.uniform(2.2, 6.0))
     try:
