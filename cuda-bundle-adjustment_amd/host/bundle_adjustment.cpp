@@ -325,6 +325,7 @@ public:
 			check(cuba_hip_create(dev ? std::atoi(dev) : 0, &solver_), "cuba_hip_create");
 			if (const char* p = std::getenv("CUBA_HIP_PROFILE")) check(cuba_hip_set_option(solver_, "profile", std::atof(p)), "set_option");
 			if (const char* p = std::getenv("CUBA_HIP_PCG_TOL")) check(cuba_hip_set_option(solver_, "pcg_tol", std::atof(p)), "set_option");
+			if (const char* p = std::getenv("CUBA_HIP_HEURISTICS")) check(cuba_hip_set_option(solver_, "heuristics", std::atof(p)), "set_option");      // (0: no run-to-run memories, samples/edit_fuzz.cpp)
 		}
 		for (int et = 0; et < 2; et++) check(cuba_hip_set_robust_kernel(solver_, et, robustKind_[et], robustDelta_[et]), "set_robust_kernel");
 		if (graphDirty_)

@@ -215,3 +215,19 @@ def test_batch_windows_cpp_api(tmp_path):
     ref = HipSolver(flatten(g), RK_HUBER).optimize(6)["chi2"]          # window 0 = the graph file's start
     assert abs(chi[0] - ref[-1]) <= 1e-8 * ref[-1]
     print("\n" + out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_random_edit_sequences_through_the_cpp_api(tmp_path):
+    """host/samples/edit_fuzz.cpp: one long-lived cuba::CudaBundleAdjustment object edited at random between optimisations (measurements, `fixed`
+    flags, edges removed and added back, a landmark removed, estimates moved, nothing at all) against a fresh object built from the same vertices,
+    edges and estimates -- every estimate, the chi2 trajectory and sampled per-edge chi2 bit for bit (heuristics off: the device library's run-to-run
+    memories are what a fresh object cannot have).  What the host layer caches between calls must never show in a result."""
+    from cuba_amd.synth import synth_ba
+    path = str(tmp_path / "graph.json")
+    synth_ba(120, 6000, 24000, seed=9).to_json(path)
+    exe = os.path.join(HOST, "samples", "edit_fuzz")
+    for seed in ("1", "2"):
+        out = subprocess.run([exe, path, "30", seed], capture_output=True, text=True, timeout=300, env={**os.environ, "CUBA_HIP_HEURISTICS": "0"})
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert "30 rounds, 0 failures" in out.stdout
