@@ -658,6 +658,7 @@ def main():
         c["coarse_inline_inversions"] = solver.counter("coarse_inline_inversions")
         c["pcg_graph_instantiations"] = solver.counter("pcg_graph_instantiations")
         c["exact_solve_fallbacks"] = solver.counter("exact_solve_fallbacks")
+        c["late_decision_records"] = solver.counter("late_decision_records")
         if native is not None:
             c["lm_trials"] = native.counters()["lm_trials"]      # the native driver runs the trial loop, not the solver handle
         return c
@@ -770,6 +771,7 @@ def main():
             "lm_trials": trials, "hsc_blocks": nblk, "schur_products": c1["schur_products"],
             "coarse_inline_inversions": c1["coarse_inline_inversions"] - c0["coarse_inline_inversions"],
             "exact_solve_fallbacks": c1["exact_solve_fallbacks"] - c0["exact_solve_fallbacks"],
+            "late_decision_records": c1["late_decision_records"],      # (life of the handle: LM decision records fetched behind a stream synchronisation; 0 in normal operation)
             "pcg_graph_instantiations_in_timed_region": c1["pcg_graph_instantiations"] - c0["pcg_graph_instantiations"],
             "final_chi2": float(chi2[-1]),
             "protocol": {"timed_runs": "each optimize(%d) from its own seeded perturbation of the warm state" % LM_RUN, **PERTURB,
